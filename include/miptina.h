@@ -1,0 +1,149 @@
+/*
+ * miptina.h -- C ABI of libmiptina.so, the MI355X (gfx950) path-trace hot path that sits
+ * underneath PTina's Python object API.
+ *
+ * The reference (archibate/ptina) has no FFI of its own: the path is reached through Python
+ * singletons whose flattest statement is ptina/worker.py:11-87.  Each entry point below names
+ * the reference call it replaces (file:line relative to the reference tree); the Python
+ * package ptina_amd binds them with ctypes and keeps the reference's class and method names.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a host pointer borrowed for the duration of the
+ *     call (inputs are copied to the device, outputs are written into caller buffers);
+ *   - functions return 0 on success, non-zero on error; mpt_last_error() gives the message
+ *     (the Python layer raises RuntimeError with it, as the reference raises);
+ *   - a context is NOT re-entrant: one caller thread per context (the reference funnels
+ *     every call through one thread, ptina/tools/mtworker.py:22-42);
+ *   - mpt_render* only ENQUEUE work (the reference's kernel launches are asynchronous too);
+ *     the read-backs and mpt_synchronize block.  Consecutive mpt_render calls are batched
+ *     into one launch at the next flush point.
+ */
+#ifndef MIPTINA_H
+#define MIPTINA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpt_ctx mpt_ctx;
+
+/* capacities, ptina/things.py:12-19 (init_things keyword arguments) */
+typedef struct {
+    int32_t max_faces;       /* 2^21 */
+    int32_t max_texels;      /* 2^22 */
+    int32_t max_materials;   /* 2^6  */
+    int32_t max_textures;    /* 2^6  */
+    int32_t max_lights;      /* 2^6  */
+    int32_t max_filmsize;    /* 2^21 */
+    int32_t max_filmpasses;  /* 3    */
+} mpt_caps;
+
+/* work counters of the traversal actually run (for the roofline's algorithmic bytes) */
+typedef struct {
+    uint64_t samples;        /* camera samples traced                    */
+    uint64_t rays;           /* BVH traversals (closest-hit + shadow)    */
+    uint64_t n_box;          /* box tests                                */
+    uint64_t n_tri;          /* triangle tests                           */
+    uint64_t n_shade;        /* shaded hits                              */
+    uint64_t n_draws;        /* Sobol draws                              */
+    uint64_t bounces;        /* path-loop iterations                     */
+    uint64_t n_node;         /* internal-node records fetched            */
+} mpt_counters;
+
+#define MPT_LIGHT_POINT 1    /* LightPool.TYPES, ptina/light/__init__.py:11 */
+#define MPT_LIGHT_AREA  2
+
+/* render modes (mpt_set_option "mode") */
+#define MPT_MODE_FAST   0    /* ordered, depth-culled traversal; any-hit shadow rays; FMA + native rcp/sin/cos */
+#define MPT_MODE_STRICT 1    /* the reference's traversal order and IEEE arithmetic without contraction        */
+
+const char *mpt_last_error(void);
+int  mpt_device_count(void);
+int  mpt_version(void);
+
+/* init_things(), ptina/things.py:12-28 */
+mpt_ctx *mpt_create(const mpt_caps *caps, int device);
+void mpt_destroy(mpt_ctx *ctx);
+
+/* "mode" (MPT_MODE_*), "batch" (max frames per launch, 1..64), "chunk" (frames per work item,
+ * 0 = auto), "count" (1 = accumulate mpt_counters, slower) */
+int mpt_set_option(mpt_ctx *ctx, const char *key, int value);
+int mpt_get_option(mpt_ctx *ctx, const char *key, int *value);
+
+/* FilmTable.set_size / nx,ny, ptina/filmtable.py:41-42,16-24; worker.set_size/get_size, worker.py:29-34 */
+int mpt_set_size(mpt_ctx *ctx, int nx, int ny);
+int mpt_get_size(mpt_ctx *ctx, int *nx, int *ny);
+/* multi-GPU: this context renders film columns x in [x0, x1) only (no reference counterpart) */
+int mpt_set_slab(mpt_ctx *ctx, int x0, int x1);
+
+/* ModelPool.from_numpy, ptina/model.py:54-60: verts [3n][8] = pos3 nrm3 uv2, mtlids [n] or NULL (= -1) */
+int mpt_load_model(mpt_ctx *ctx, const float *verts, const int32_t *mtlids, int n);
+/* MaterialPool.load, ptina/mtllib.py:58-77: fac [m][12][4], tex [m][12] (-1 = none) */
+int mpt_load_materials(mpt_ctx *ctx, const float *fac, const int32_t *tex, int m);
+/* ImagePool.load / load_one, ptina/image.py:69-96: rgba [nx][ny][4] f32; returns image id via *id */
+int mpt_reset_images(mpt_ctx *ctx);
+int mpt_load_image(mpt_ctx *ctx, const float *rgba, int nx, int ny, int *id);
+/* BVHTree.build, ptina/tree/lbvh.py:297-305 */
+int mpt_build_tree(mpt_ctx *ctx);
+/* test/inspection: reference-layout tree arrays (tree/lbvh.py:48-56); any pointer may be NULL */
+int mpt_get_tree(mpt_ctx *ctx, int32_t *child /*[n-1][2]*/, int32_t *leaf /*[n]*/,
+                 float *bmin /*[n-1][3]*/, float *bmax /*[n-1][3]*/, int32_t *mc /*[n]*/, int32_t *depth);
+
+/* Camera.set_perspective, ptina/camera.py:19-22: the two f32 matrices the reference stores
+ * (V2W = inv(pers) computed by the caller in f64 exactly as the reference does) */
+int mpt_set_camera(mpt_ctx *ctx, const float v2w[16], const float w2v[16]);
+
+/* LightPool.clear / add, ptina/light/__init__.py:31-49 (pos/axes already extracted from the world matrix) */
+int mpt_clear_lights(mpt_ctx *ctx);
+int mpt_add_light(mpt_ctx *ctx, int type, const float color[3], const float pos[3],
+                  const float axes[9], float size, int *index);
+/* WorldLight.set, ptina/light/world.py:18-20 */
+int mpt_set_world_light(mpt_ctx *ctx, const float fac[4], int tex);
+
+/* SobolSampler.__init__ / reset / update, ptina/sampling/sobol.py:75-105.
+ * V = direction-number grid [rows][dim] (bit pattern, i32) from calc_sobol_vgrid */
+int mpt_sobol_init(mpt_ctx *ctx, const int32_t *V, int rows, int dim);
+int mpt_sobol_reset(mpt_ctx *ctx, int skip);
+int mpt_sobol_update(mpt_ctx *ctx, int count);
+int mpt_sobol_get(mpt_ctx *ctx, int32_t *X, float *P, int32_t *time);
+
+/* PathEngine.render, ptina/engine/path.py:75-77 : nframes x (Sobol update + one sample per pixel) */
+int mpt_render(mpt_ctx *ctx, int nframes);
+/* PreviewEngine.render, ptina/engine/preview.py:18-41 : albedo -> pass 1, normal -> pass 2 */
+int mpt_render_preview(mpt_ctx *ctx, int nframes);
+/* launch everything enqueued so far (does not wait) */
+int mpt_flush(mpt_ctx *ctx);
+/* worker.synchronize, ptina/worker.py:17-18 */
+int mpt_synchronize(mpt_ctx *ctx);
+
+/* FilmTable.clear, ptina/filmtable.py:44-45 (zeroes every pass, whatever `pass` says, as the reference does) */
+int mpt_clear(mpt_ctx *ctx, int pass);
+/* FilmTable.get_image, ptina/filmtable.py:47-63 : out [nx][ny][4] */
+int mpt_get_image(mpt_ctx *ctx, int pass, float *out);
+/* FilmTable.fast_export_image, ptina/filmtable.py:66-79 : out [ny*nx*3] */
+int mpt_fast_export_image(mpt_ctx *ctx, int pass, float *out);
+/* raw accumulators [nx*ny][4] (rgb sums, sample count) */
+int mpt_get_film_raw(mpt_ctx *ctx, int pass, float *out);
+/* device-side resolve only (no read-back): what get_image does before the copy */
+int mpt_resolve(mpt_ctx *ctx, int pass);
+
+/* measurement */
+int mpt_get_counters(mpt_ctx *ctx, mpt_counters *out);
+int mpt_reset_counters(mpt_ctx *ctx);
+/* HIP-event time of the render kernels launched since the last call (ms) and their count */
+int mpt_kernel_time(mpt_ctx *ctx, double *ms, int *launches);
+
+/* multi-GPU film gather over RCCL (one process per GPU).  uid = ncclUniqueId bytes (128). */
+int mpt_comm_unique_id(char uid[128]);
+int mpt_comm_init(mpt_ctx *ctx, const char uid[128], int nranks, int rank);
+int mpt_comm_gather_film(mpt_ctx *ctx, int pass, int root);
+int mpt_comm_barrier(mpt_ctx *ctx);
+int mpt_comm_allreduce_max(mpt_ctx *ctx, double *value);
+int mpt_comm_destroy(mpt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,123 @@
+// aux_kernels.hip -- the small kernels around the megakernel: Sobol state advance for a whole
+// batch of frames, film combine / resolve / export.  All are streaming, HBM-bound passes over
+// float4 records (dwordx4 per lane, consecutive lanes on consecutive addresses).
+
+#include <hip/hip_runtime.h>
+#include "mpt_types.h"
+
+// SobolSampler.update, sampling/sobol.py:99-105, for `count` consecutive frames in one launch:
+// thread j owns dimension j, keeps X[j] in a register, and emits P[f][j] for every frame.
+// count_low_bits(time) (sobol.py:11-17) is uniform, so it stays on the scalar unit.
+__device__ __forceinline__ int count_low_bits(int i) {
+    int bits = 1;
+    int value = i;
+    while (value & 1) { value >>= 1; bits += 1; }
+    return bits;
+}
+
+// construct_float, sobol.py:20-29: MSB-first accumulation in f32 (exact for <= 24 significant
+// bits; kept literal so that wider direction grids round exactly as the reference does)
+__device__ __forceinline__ float construct_float(int i) {
+    float ret = 0.0f;
+    unsigned value = (unsigned)i;
+    float term = 0.5f;
+    while (value) {
+        if (value & 0x80000000u) ret += term;
+        value <<= 1;
+        term *= 0.5f;
+    }
+    return ret;
+}
+
+__global__ __launch_bounds__(256) void sobol_update_kernel(int *__restrict__ X, const int *__restrict__ V,
+                                                           float *__restrict__ P, int dim, int rows, int time0,
+                                                           int count, int pstride_frames) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= dim) return;
+    int x = X[j];
+    for (int f = 0; f < count; f++) {
+        int i = count_low_bits(time0 + f);
+        if (i < rows) x ^= V[(size_t)i * dim + j];
+        // only the last `pstride_frames` frames are kept when count exceeds the P capacity
+        // (reset's skipped updates never read P)
+        if (f >= count - pstride_frames) P[(size_t)(f - (count - pstride_frames)) * dim + j] = construct_float(x);
+    }
+    X[j] = x;
+}
+
+// film[pix] += partial[0][pix] + partial[1][pix] + ... in chunk order (deterministic)
+__global__ __launch_bounds__(256) void combine_kernel(MptVec4 *__restrict__ film, const MptVec4 *__restrict__ partial,
+                                                      int nx, int ny, int x0, int x1, int nchunks) {
+    size_t npix = (size_t)nx * ny;
+    size_t lo = (size_t)x0 * ny, hi = (size_t)x1 * ny;
+    size_t t = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= hi) return;
+    MptVec4 a = film[t];
+    for (int c = 0; c < nchunks; c++) {
+        MptVec4 b = partial[(size_t)c * npix + t];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    film[t] = a;
+}
+
+// FilmTable._get_image, filmtable.py:53-63 : out[x][y] = rgb / w, w -> 1; empty -> (0.9, 0.4, 0.9, 0)
+__global__ __launch_bounds__(256) void resolve_kernel(const MptVec4 *__restrict__ film, MptVec4 *__restrict__ out,
+                                                      size_t npix) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npix) return;
+    MptVec4 v = film[t];
+    if (v.w != 0.0f) {
+        v.x /= v.w; v.y /= v.w; v.z /= v.w;
+        v.w = 1.0f;
+    } else {
+        v.x = 0.9f; v.y = 0.4f; v.z = 0.9f; v.w = 0.0f;
+    }
+    out[t] = v;
+}
+
+// FilmTable.fast_export_image, filmtable.py:66-79 : flat RGB at (y * nx + x) * 3.
+// One thread per OUTPUT pixel (consecutive x) so the 12-byte stores are contiguous across the wave.
+__global__ __launch_bounds__(256) void export_kernel(const MptVec4 *__restrict__ film, float *__restrict__ out,
+                                                     int nx, int ny) {
+    size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= (size_t)nx * ny) return;
+    int y = (int)(o / nx), x = (int)(o - (size_t)y * nx);
+    MptVec4 v = film[(size_t)x * ny + y];
+    if (v.w != 0.0f) {
+        v.x /= v.w; v.y /= v.w; v.z /= v.w;
+    } else {
+        v.x = 0.9f; v.y = 0.4f; v.z = 0.9f;
+    }
+    out[o * 3 + 0] = v.x; out[o * 3 + 1] = v.y; out[o * 3 + 2] = v.z;
+}
+
+extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0,
+                                              int count, int keep, hipStream_t stream) {
+    int grid = (dim + 255) / 256;
+    hipLaunchKernelGGL(sobol_update_kernel, dim3(grid), dim3(256), 0, stream, X, V, P, dim, rows, time0, count, keep);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
+                                         int nchunks, hipStream_t stream) {
+    size_t n = (size_t)(x1 - x0) * ny;
+    if (n == 0) return hipSuccess;
+    int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(combine_kernel, dim3(grid), dim3(256), 0, stream, film, partial, nx, ny, x0, x1, nchunks);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t stream) {
+    if (npix == 0) return hipSuccess;
+    int grid = (int)((npix + 255) / 256);
+    hipLaunchKernelGGL(resolve_kernel, dim3(grid), dim3(256), 0, stream, film, out, npix);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t stream) {
+    size_t n = (size_t)nx * ny;
+    if (n == 0) return hipSuccess;
+    int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(export_kernel, dim3(grid), dim3(256), 0, stream, film, out, nx, ny);
+    return hipGetLastError();
+}

@@ -1,0 +1,1002 @@
+// miptina.cpp -- host runtime behind the C ABI of include/miptina.h.
+//
+// Owns the device state of one PTina "scene" (the singletons of ptina/things.py:20-28 collapsed
+// into one context), builds the LBVH, batches enqueued frames into single launches, and gathers
+// film slabs across GPUs with RCCL.  No PyTorch, no Python: plain HIP runtime calls.
+
+#include "../../include/miptina.h"
+#include "mpt_types.h"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// kernel launchers (render_kernel.hip x2, aux_kernels.hip)
+extern "C" hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
+extern "C" hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
+extern "C" hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
+extern "C" hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
+extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
+                                              int keep, hipStream_t);
+extern "C" hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
+                                         int nchunks, hipStream_t);
+extern "C" hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
+extern "C" hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+static int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *mpt_last_error(void) { return g_err.c_str(); }
+extern "C" int mpt_version(void) { return 100; }
+
+extern "C" int mpt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------ RCCL, bound lazily
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.h) return 0;
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    void *h = nullptr;
+    for (const char *nm : names) {
+        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail("cannot load librccl: %s", dlerror());
+#define SYM(field, name)                                                        \
+    *(void **)(&g_rccl.field) = dlsym(h, name);                                 \
+    if (!g_rccl.field) return fail("librccl lacks symbol %s", name);
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.h = h;
+    return 0;
+}
+
+#define NCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(r_));  \
+    } while (0)
+
+// ------------------------------------------------------------------ context
+struct mpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mpt_caps caps{};
+
+    // options
+    int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0;
+
+    // film
+    int nx = 0, ny = 0, x0 = 0, x1 = 0;
+    MptVec4 *film[3] = { nullptr, nullptr, nullptr };
+    size_t film_cap = 0;                 // pixels allocated per pass
+    MptVec4 *resolved = nullptr;         // nx*ny float4 (get_image staging on device)
+    float *exported = nullptr;           // nx*ny*3
+    MptVec4 *partial = nullptr;
+    size_t partial_cap = 0;              // float4 elements
+
+    // model (host copy kept for the tree build)
+    int nfaces = 0;
+    std::vector<float> verts;            // [3n][8]
+    std::vector<int32_t> mtlids;
+    bool tree_valid = false;
+    int tree_depth = 0;
+    std::vector<int32_t> h_child, h_leaf, h_mc;
+    std::vector<float> h_bmin, h_bmax;
+    MptVec4 *snode = nullptr, *fnode = nullptr, *tgeo = nullptr, *tshade = nullptr;
+    size_t node_cap = 0, tri_cap = 0;
+
+    // materials / images / lights / world / camera
+    MptMaterial *mats = nullptr;
+    MptImage *images = nullptr;
+    std::vector<MptImage> h_images;
+    MptVec4 *texels = nullptr;
+    size_t texels_used = 0;
+    MptLight *lights = nullptr;
+    std::vector<MptLight> h_lights;
+    float world_fac[4] = { 0.1f, 0.1f, 0.1f, 0.1f };   // light/world.py:14-16
+    int world_tex = -1;                                 // documented deviation Q6 (reference default 0)
+    float v2w[16], w2v[16];
+
+    // sobol
+    int sdim = 0, srows = 0;
+    int32_t stime = 0;
+    int *sV = nullptr, *sX = nullptr;
+    float *sP = nullptr;                 // [MPT_MAX_BATCH][sdim]
+
+    // command batching
+    int pending = 0;
+
+    // measurement
+    unsigned long long *d_counters = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<hipEvent_t> event_pool;
+
+    // comm
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    double *d_scratch = nullptr;
+};
+
+static int use(mpt_ctx *c) {
+    if (!c) return fail("null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+template <class T>
+static int dev_alloc(T **p, size_t count) {
+    HIP_TRY(hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return 0;
+}
+
+static void default_light(mpt_ctx *c) {
+    // light/__init__.py:22-28: one POINT light at (1,2,3), radius 0.5, colour 32
+    MptLight L{};
+    L.color_size = { 32.f, 32.f, 32.f, 0.5f };
+    L.pos_type = { 1.f, 2.f, 3.f, 0.f };
+    int t = MPT_LIGHT_POINT;
+    memcpy(&L.pos_type.w, &t, 4);
+    c->h_lights.assign(1, L);
+}
+
+static int upload_lights(mpt_ctx *c) {
+    if (!c->h_lights.empty())
+        HIP_TRY(hipMemcpyAsync(c->lights, c->h_lights.data(), c->h_lights.size() * sizeof(MptLight),
+                               hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        fail("no HIP device available (%s): the MI355X path has no CPU fallback",
+             e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { fail("device %d out of range (%d devices)", device, ndev); return nullptr; }
+    mpt_ctx *c = new mpt_ctx();
+    c->device = device;
+    mpt_caps d = { 1 << 21, 1 << 22, 1 << 6, 1 << 6, 1 << 6, 1 << 21, 3 };
+    c->caps = caps ? *caps : d;
+    if (c->caps.max_lights > MPT_MAX_LIGHTS) c->caps.max_lights = MPT_MAX_LIGHTS;
+    if (c->caps.max_filmpasses < 3) c->caps.max_filmpasses = 3;
+    auto bail = [&](const char *what) -> mpt_ctx * {
+        std::string m = g_err;
+        fail("mpt_create: %s: %s", what, m.c_str());
+        delete c;
+        return nullptr;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail("stream");
+    if (dev_alloc(&c->mats, c->caps.max_materials)) return bail("materials");
+    if (dev_alloc(&c->images, c->caps.max_textures)) return bail("images");
+    if (dev_alloc(&c->lights, MPT_MAX_LIGHTS)) return bail("lights");
+    if (dev_alloc(&c->d_counters, 8)) return bail("counters");
+    if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
+    hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream);
+    {   // unset materials: factor 0 (field-zero, mtllib.py:12-13), texture -1 (deviation Q6)
+        std::vector<MptMaterial> z(c->caps.max_materials);
+        for (auto &m : z) { memset(&m, 0, sizeof m); for (int k = 0; k < 12; k++) m.tex[k] = -1; }
+        hipMemcpyAsync(c->mats, z.data(), z.size() * sizeof(MptMaterial), hipMemcpyHostToDevice, c->stream);
+        hipStreamSynchronize(c->stream);
+    }
+    for (int i = 0; i < 16; i++) c->v2w[i] = c->w2v[i] = (i % 5 == 0) ? 1.f : 0.f;
+    default_light(c);
+    if (upload_lights(c)) return bail("lights upload");
+    return c;
+}
+
+extern "C" void mpt_destroy(mpt_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    for (auto &pr : c->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto &ev : c->event_pool) hipEventDestroy(ev);
+    for (int p = 0; p < 3; p++) hipFree(c->film[p]);
+    hipFree(c->resolved); hipFree(c->exported); hipFree(c->partial);
+    hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade);
+    hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
+    hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
+    hipFree(c->d_counters); hipFree(c->d_scratch);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------ options
+extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    std::string k = key ? key : "";
+    if (k == "mode") {
+        if (value != MPT_MODE_FAST && value != MPT_MODE_STRICT) return fail("mode must be 0 (fast) or 1 (strict)");
+        c->mode = value;
+    } else if (k == "batch") {
+        if (value < 1 || value > MPT_MAX_BATCH) return fail("batch must be in 1..%d", MPT_MAX_BATCH);
+        c->batch = value;
+    } else if (k == "chunk") {
+        if (value < 0) return fail("chunk must be >= 0");
+        c->chunk = value;
+    } else if (k == "count") {
+        c->count = value ? 1 : 0;
+    } else {
+        return fail("unknown option '%s'", k.c_str());
+    }
+    return 0;
+}
+
+extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
+    if (!c || !value) return fail("null argument");
+    std::string k = key ? key : "";
+    if (k == "mode") *value = c->mode;
+    else if (k == "batch") *value = c->batch;
+    else if (k == "chunk") *value = c->chunk;
+    else if (k == "count") *value = c->count;
+    else if (k == "tree_depth") *value = c->tree_depth;
+    else if (k == "pending") *value = c->pending;
+    else return fail("unknown option '%s'", k.c_str());
+    return 0;
+}
+
+// ------------------------------------------------------------------ film
+extern "C" int mpt_set_size(mpt_ctx *c, int nx, int ny) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (nx <= 0 || ny <= 0) return fail("film size must be positive, got %dx%d", nx, ny);
+    size_t npix = (size_t)nx * ny;
+    if (npix > (size_t)c->caps.max_filmsize)
+        return fail("film %dx%d exceeds max_filmsize=%d (init_things(max_filmsize=...))", nx, ny, c->caps.max_filmsize);
+    if (npix > c->film_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int p = 0; p < 3; p++) { hipFree(c->film[p]); c->film[p] = nullptr; }
+        hipFree(c->resolved); c->resolved = nullptr;
+        hipFree(c->exported); c->exported = nullptr;
+        for (int p = 0; p < 3; p++) {
+            if (dev_alloc(&c->film[p], npix)) return 1;
+            HIP_TRY(hipMemsetAsync(c->film[p], 0, npix * sizeof(MptVec4), c->stream));
+        }
+        if (dev_alloc(&c->resolved, npix)) return 1;
+        if (dev_alloc(&c->exported, npix * 3)) return 1;
+        c->film_cap = npix;
+    }
+    // the reference keeps one flat buffer and only changes `res` (filmtable.py:41-42): stale sums
+    // of another resolution are the caller's to clear(); same here.
+    c->nx = nx; c->ny = ny; c->x0 = 0; c->x1 = nx;
+    return 0;
+}
+
+extern "C" int mpt_get_size(mpt_ctx *c, int *nx, int *ny) {
+    if (!c) return fail("null context");
+    if (nx) *nx = c->nx;
+    if (ny) *ny = c->ny;
+    return 0;
+}
+
+extern "C" int mpt_set_slab(mpt_ctx *c, int x0, int x1) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (x0 < 0 || x1 > c->nx || x0 > x1) return fail("slab [%d,%d) outside film width %d", x0, x1, c->nx);
+    c->x0 = x0; c->x1 = x1;
+    return 0;
+}
+
+// ------------------------------------------------------------------ scene upload
+extern "C" int mpt_load_model(mpt_ctx *c, const float *verts, const int32_t *mtlids, int n) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (n < 0 || (n > 0 && !verts)) return fail("bad model arguments");
+    if (n >= c->caps.max_faces) return fail("too many faces");                // model.py:84
+    c->nfaces = n;
+    c->verts.assign(verts, verts + (size_t)n * 24);
+    if (mtlids) c->mtlids.assign(mtlids, mtlids + n);
+    else c->mtlids.assign(n, -1);                                             // model.py:80-81
+    for (int i = 0; i < n; i++)
+        if (c->mtlids[i] < -1 || c->mtlids[i] >= c->caps.max_materials)
+            return fail("material id %d of face %d outside [-1, %d)", c->mtlids[i], i, c->caps.max_materials);
+    c->tree_valid = false;
+    return 0;
+}
+
+extern "C" int mpt_load_materials(mpt_ctx *c, const float *fac, const int32_t *tex, int m) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (m < 0 || m > c->caps.max_materials) return fail("%d materials exceed max_materials=%d", m, c->caps.max_materials);
+    std::vector<MptMaterial> h(std::max(m, 1));
+    for (int i = 0; i < m; i++) {
+        MptMaterial &M = h[i];
+        memset(&M, 0, sizeof M);
+        const float *f = fac + (size_t)i * 48;
+        M.p[0] = f[0]; M.p[1] = f[1]; M.p[2] = f[2];                          // basecolor .xyz, mtllib.py:82
+        for (int k = 1; k < 12; k++) M.p[2 + k] = f[k * 4];                   // scalars take .x, mtllib.py:83-93
+        M.any_tex = 0;
+        for (int k = 0; k < 12; k++) {
+            int t = tex ? tex[(size_t)i * 12 + k] : -1;
+            if (t < -1 || t >= c->caps.max_textures) return fail("texture id %d outside [-1, %d)", t, c->caps.max_textures);
+            M.tex[k] = t;
+            if (t != -1) M.any_tex = 1;
+        }
+    }
+    if (m) HIP_TRY(hipMemcpyAsync(c->mats, h.data(), (size_t)m * sizeof(MptMaterial), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mpt_reset_images(mpt_ctx *c) {                                  // image.py:90-92
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    c->h_images.clear();
+    c->texels_used = 0;
+    return 0;
+}
+
+extern "C" int mpt_load_image(mpt_ctx *c, const float *rgba, int nx, int ny, int *id) {   // image.py:51-88
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if ((int)c->h_images.size() >= c->caps.max_textures) return fail("Out of ID!");       // allocator.py:53
+    size_t need = (size_t)nx * ny;
+    if (c->texels_used + need > (size_t)c->caps.max_texels) return fail("Out of memory!"); // allocator.py:24
+    if (!c->texels) { if (dev_alloc(&c->texels, (size_t)c->caps.max_texels)) return 1; }
+    HIP_TRY(hipMemcpyAsync(c->texels + c->texels_used, rgba, need * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
+    MptImage im = { nx, ny, (int32_t)c->texels_used, 0 };
+    c->h_images.push_back(im);
+    c->texels_used += need;
+    HIP_TRY(hipMemcpyAsync(c->images, c->h_images.data(), c->h_images.size() * sizeof(MptImage),
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (id) *id = (int)c->h_images.size() - 1;
+    return 0;
+}
+
+extern "C" int mpt_set_camera(mpt_ctx *c, const float v2w[16], const float w2v[16]) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    memcpy(c->v2w, v2w, sizeof c->v2w);
+    if (w2v) memcpy(c->w2v, w2v, sizeof c->w2v);
+    return 0;
+}
+
+extern "C" int mpt_clear_lights(mpt_ctx *c) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    c->h_lights.clear();
+    return 0;
+}
+
+extern "C" int mpt_add_light(mpt_ctx *c, int type, const float color[3], const float pos[3], const float axes[9],
+                             float size, int *index) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (type != MPT_LIGHT_POINT && type != MPT_LIGHT_AREA) return fail("unknown light type %d", type);
+    if ((int)c->h_lights.size() >= c->caps.max_lights) return fail("too many lights (max_lights=%d)", c->caps.max_lights);
+    MptLight L{};
+    L.color_size = { color[0], color[1], color[2], size };
+    L.pos_type = { pos[0], pos[1], pos[2], 0.f };
+    memcpy(&L.pos_type.w, &type, 4);
+    L.ax0 = { axes[0], axes[1], axes[2], 0.f };
+    L.ax1 = { axes[3], axes[4], axes[5], 0.f };
+    L.ax2 = { axes[6], axes[7], axes[8], 0.f };
+    c->h_lights.push_back(L);
+    if (index) *index = (int)c->h_lights.size() - 1;
+    return upload_lights(c);
+}
+
+extern "C" int mpt_set_world_light(mpt_ctx *c, const float fac[4], int tex) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    memcpy(c->world_fac, fac, sizeof c->world_fac);
+    c->world_tex = tex;
+    return 0;
+}
+
+// ------------------------------------------------------------------ LBVH build (tree/lbvh.py:169-305)
+// Same algorithm as the reference (30-bit Morton codes of centroids, sorted, Karras hierarchy,
+// bottom-up boxes) with two robustness changes: the sort key is (code << 32 | index), so equal
+// codes cannot corrupt the hierarchy, and the boxes are fitted in one post-order
+// pass instead of <=64 level-synchronous launches with a read-back each (lbvh.py:251-261).
+// With distinct codes the tree is node-for-node the reference's.
+
+static inline uint32_t expand_bits(uint32_t v) {                               // lbvh.py:13-17
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+static inline int quant1024(float x) {                                         // clamp(ifloor(v * 1024), 0, 1023), lbvh.py:29
+    float f = floorf(x * 1024.0f);
+    if (!(f == f) || f < 0.f) return 0;
+    if (f > 1023.f) return 1023;
+    return (int)f;
+}
+
+static inline int delta(const std::vector<uint64_t> &key, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __builtin_clzll(key[i] ^ key[j]);
+}
+
+extern "C" int mpt_build_tree(mpt_ctx *c) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    const int n = c->nfaces;
+    const float *V = c->verts.data();
+    auto pos = [&](int f, int k) { return V + ((size_t)f * 3 + k) * 8; };
+
+    // genMortonCodes, lbvh.py:169-183
+    float bmin[3] = { 1e6f, 1e6f, 1e6f }, bmax[3] = { -1e6f, -1e6f, -1e6f };
+    std::vector<float> cen((size_t)n * 3);
+    for (int f = 0; f < n; f++)
+        for (int a = 0; a < 3; a++) {
+            float ctr = ((pos(f, 0)[a] + pos(f, 1)[a]) + pos(f, 2)[a]) / 3.0f;   // lbvh.py:164
+            cen[(size_t)f * 3 + a] = ctr;
+            bmin[a] = fminf(bmin[a], ctr);
+            bmax[a] = fmaxf(bmax[a], ctr);
+        }
+    std::vector<uint64_t> key(n);
+    for (int f = 0; f < n; f++) {
+        uint32_t w[3];
+        for (int a = 0; a < 3; a++) w[a] = expand_bits((uint32_t)quant1024((cen[(size_t)f * 3 + a] - bmin[a]) / (bmax[a] - bmin[a])));
+        uint32_t code = w[0] * 4 + w[1] * 2 + w[2];
+        key[f] = ((uint64_t)code << 32) | (uint32_t)f;
+    }
+    std::sort(key.begin(), key.end());                                          // lbvh.py:204-208
+
+    c->h_leaf.resize(n); c->h_mc.resize(n);
+    for (int i = 0; i < n; i++) { c->h_leaf[i] = (int32_t)(key[i] & 0xffffffffu); c->h_mc[i] = (int32_t)(key[i] >> 32); }
+
+    const int ni = n > 1 ? n - 1 : 0;
+    c->h_child.assign((size_t)std::max(ni, 1) * 2, 0);
+    c->h_bmin.assign((size_t)std::max(ni, 1) * 3, 0.f);
+    c->h_bmax.assign((size_t)std::max(ni, 1) * 3, 0.f);
+
+    // genHierarchy, lbvh.py:212-231 (determineRange :93-146, findSplit :62-89)
+    for (int i = 0; i < ni; i++) {
+        int l, r;
+        if (i == 0) { l = 0; r = n - 1; }
+        else {
+            int d = delta(key, n, i, i + 1) > delta(key, n, i, i - 1) ? 1 : -1;
+            int dmin = delta(key, n, i, i - d);
+            int lmax = 2;
+            while (delta(key, n, i, i + lmax * d) > dmin) lmax <<= 1;
+            int s = 0;
+            for (int t = lmax >> 1; t > 0; t >>= 1)
+                if (delta(key, n, i, i + (s + t) * d) > dmin) s += t;
+            l = i; r = i + s * d;
+            if (d < 0) std::swap(l, r);
+        }
+        int cp = delta(key, n, l, r);
+        int m = l, s = r - l;
+        for (;;) {
+            s = (s + 1) >> 1;
+            int q = m + s;
+            if (q < r && delta(key, n, l, q) > cp) m = q;
+            if (s <= 1) break;
+        }
+        c->h_child[(size_t)i * 2 + 0] = (m == l) ? m : m + n;
+        c->h_child[(size_t)i * 2 + 1] = (m + 1 == r) ? m + 1 : m + 1 + n;
+    }
+
+    // boxes: iterative post-order from the root (also yields the depth the LDS stack must hold)
+    auto leaf_box = [&](int slot, float *lo, float *hi) {                       // lbvh.py:155-158
+        int f = c->h_leaf[slot];
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(fminf(pos(f, 0)[a], pos(f, 1)[a]), pos(f, 2)[a]);
+            hi[a] = fmaxf(fmaxf(pos(f, 0)[a], pos(f, 1)[a]), pos(f, 2)[a]);
+        }
+    };
+    int depth = 0;
+    if (ni > 0) {
+        std::vector<int> order; order.reserve(ni);
+        std::vector<std::pair<int, int>> st; st.push_back({ 0, 1 });
+        std::vector<char> seen(ni, 0);
+        while (!st.empty()) {
+            auto [i, dpt] = st.back(); st.pop_back();
+            if (i < 0 || i >= ni || seen[i]) return fail("AABB step never stop! hierarchy corrupted?");   // lbvh.py:259
+            seen[i] = 1;
+            order.push_back(i);
+            depth = std::max(depth, dpt);
+            for (int k = 0; k < 2; k++) {
+                int ch = c->h_child[(size_t)i * 2 + k];
+                if (ch >= n) st.push_back({ ch - n, dpt + 1 });
+            }
+        }
+        if ((int)order.size() != ni) return fail("AABB step never stop! hierarchy corrupted?");
+        for (int t = ni - 1; t >= 0; t--) {                                     // children before parents
+            int i = order[t];
+            float lo[2][3], hi[2][3];
+            for (int k = 0; k < 2; k++) {
+                int ch = c->h_child[(size_t)i * 2 + k];
+                if (ch < n) leaf_box(ch, lo[k], hi[k]);
+                else for (int a = 0; a < 3; a++) { lo[k][a] = c->h_bmin[(size_t)(ch - n) * 3 + a]; hi[k][a] = c->h_bmax[(size_t)(ch - n) * 3 + a]; }
+            }
+            for (int a = 0; a < 3; a++) {
+                c->h_bmin[(size_t)i * 3 + a] = fminf(lo[0][a], lo[1][a]);
+                c->h_bmax[(size_t)i * 3 + a] = fmaxf(hi[0][a], hi[1][a]);
+            }
+        }
+    }
+    c->tree_depth = depth;
+    if (depth + 2 > 64) return fail("LBVH depth %d exceeds the 64-entry traversal stack", depth);
+
+    // pack device records
+    std::vector<MptVec4> snode((size_t)std::max(ni, 1) * 2), fnode((size_t)std::max(ni, 1) * 4);
+    std::vector<MptVec4> tgeo((size_t)std::max(n, 1) * 4), tshade((size_t)std::max(n, 1) * 4);
+    auto asf = [](int32_t v) { float f; memcpy(&f, &v, 4); return f; };
+    for (int i = 0; i < ni; i++) {
+        const float *lo = &c->h_bmin[(size_t)i * 3], *hi = &c->h_bmax[(size_t)i * 3];
+        int c0 = c->h_child[(size_t)i * 2], c1 = c->h_child[(size_t)i * 2 + 1];
+        snode[(size_t)i * 2 + 0] = { lo[0], lo[1], lo[2], asf(c0) };
+        snode[(size_t)i * 2 + 1] = { hi[0], hi[1], hi[2], asf(c1) };
+        float l[2][3], h[2][3];
+        int id[2];
+        for (int k = 0; k < 2; k++) {
+            int ch = k ? c1 : c0;
+            if (ch < n) { leaf_box(ch, l[k], h[k]); id[k] = ~ch; }
+            else {
+                for (int a = 0; a < 3; a++) { l[k][a] = c->h_bmin[(size_t)(ch - n) * 3 + a]; h[k][a] = c->h_bmax[(size_t)(ch - n) * 3 + a]; }
+                id[k] = ch - n;
+            }
+        }
+        fnode[(size_t)i * 4 + 0] = { l[0][0], l[0][1], l[0][2], h[0][0] };
+        fnode[(size_t)i * 4 + 1] = { h[0][1], h[0][2], l[1][0], l[1][1] };
+        fnode[(size_t)i * 4 + 2] = { l[1][2], h[1][0], h[1][1], h[1][2] };
+        fnode[(size_t)i * 4 + 3] = { asf(id[0]), asf(id[1]), 0.f, 0.f };
+    }
+    for (int slot = 0; slot < n; slot++) {
+        int f = c->h_leaf[slot];
+        const float *p0 = pos(f, 0), *p1 = pos(f, 1), *p2 = pos(f, 2);
+        // hoisted terms of Face.intersect, geometries.py:120-122,134-136,140 (same f32 operations)
+        float u[3], v[3], nn[3];
+        for (int a = 0; a < 3; a++) { u[a] = p1[a] - p0[a]; v[a] = p2[a] - p0[a]; }
+        nn[0] = u[1] * v[2] - u[2] * v[1];
+        nn[1] = u[2] * v[0] - u[0] * v[2];
+        nn[2] = u[0] * v[1] - u[1] * v[0];
+        float uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+        float uv = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
+        float vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        float D = uv * uv - uu * vv;
+        tgeo[(size_t)slot * 4 + 0] = { p0[0], p0[1], p0[2], D };
+        tgeo[(size_t)slot * 4 + 1] = { u[0], u[1], u[2], uu };
+        tgeo[(size_t)slot * 4 + 2] = { v[0], v[1], v[2], uv };
+        tgeo[(size_t)slot * 4 + 3] = { nn[0], nn[1], nn[2], vv };
+        tshade[(size_t)slot * 4 + 0] = { p0[3], p0[4], p0[5], p1[3] };
+        tshade[(size_t)slot * 4 + 1] = { p1[4], p1[5], p2[3], p2[4] };
+        tshade[(size_t)slot * 4 + 2] = { p2[5], p0[6], p0[7], p1[6] };
+        tshade[(size_t)slot * 4 + 3] = { p1[7], p2[6], p2[7], asf(c->mtlids[f]) };
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((size_t)std::max(ni, 1) > c->node_cap) {
+        hipFree(c->snode); hipFree(c->fnode); c->snode = c->fnode = nullptr;
+        if (dev_alloc(&c->snode, snode.size()) || dev_alloc(&c->fnode, fnode.size())) return 1;
+        c->node_cap = std::max(ni, 1);
+    }
+    if ((size_t)std::max(n, 1) > c->tri_cap) {
+        hipFree(c->tgeo); hipFree(c->tshade); c->tgeo = c->tshade = nullptr;
+        if (dev_alloc(&c->tgeo, tgeo.size()) || dev_alloc(&c->tshade, tshade.size())) return 1;
+        c->tri_cap = std::max(n, 1);
+    }
+    HIP_TRY(hipMemcpyAsync(c->snode, snode.data(), snode.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->fnode, fnode.data(), fnode.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tgeo, tgeo.data(), tgeo.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tshade, tshade.data(), tshade.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->tree_valid = true;
+    return 0;
+}
+
+extern "C" int mpt_get_tree(mpt_ctx *c, int32_t *child, int32_t *leaf, float *bmin, float *bmax, int32_t *mc,
+                            int32_t *depth) {
+    if (!c) return fail("null context");
+    if (!c->tree_valid) return fail("BVH not built: call build_tree() after load_model()");
+    int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
+    if (child) memcpy(child, c->h_child.data(), (size_t)ni * 2 * sizeof(int32_t));
+    if (leaf) memcpy(leaf, c->h_leaf.data(), (size_t)n * sizeof(int32_t));
+    if (bmin) memcpy(bmin, c->h_bmin.data(), (size_t)ni * 3 * sizeof(float));
+    if (bmax) memcpy(bmax, c->h_bmax.data(), (size_t)ni * 3 * sizeof(float));
+    if (mc) memcpy(mc, c->h_mc.data(), (size_t)n * sizeof(int32_t));
+    if (depth) *depth = c->tree_depth;
+    return 0;
+}
+
+// ------------------------------------------------------------------ sobol
+extern "C" int mpt_sobol_init(mpt_ctx *c, const int32_t *V, int rows, int dim) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (rows < 2 || dim < 1 || !V) return fail("bad sobol grid %dx%d", rows, dim);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
+    c->sV = c->sX = nullptr; c->sP = nullptr;
+    if (dev_alloc(&c->sV, (size_t)rows * dim) || dev_alloc(&c->sX, (size_t)dim) ||
+        dev_alloc(&c->sP, (size_t)MPT_MAX_BATCH * dim)) return 1;
+    HIP_TRY(hipMemcpyAsync(c->sV, V, (size_t)rows * dim * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->sX, 0, (size_t)dim * sizeof(int), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->sdim = dim; c->srows = rows; c->stime = 0;
+    return 0;
+}
+
+static int sobol_advance(mpt_ctx *c, int count, int keep) {
+    // keep = number of trailing frames whose points are written to P[0..keep)
+    while (count > 0) {
+        int step = count;
+        int k = std::min(keep, step);
+        HIP_TRY(mpt_launch_sobol_update(c->sX, c->sV, c->sP, c->sdim, c->srows, c->stime, step, k, c->stream));
+        c->stime = (int32_t)((uint32_t)c->stime + (uint32_t)step);
+        count -= step;
+    }
+    return 0;
+}
+
+extern "C" int mpt_sobol_reset(mpt_ctx *c, int skip) {                         // sobol.py:92-97
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (!c->sV) return fail("sobol sampler not initialised");
+    c->stime = 0;
+    HIP_TRY(hipMemsetAsync(c->sX, 0, (size_t)c->sdim * sizeof(int), c->stream));
+    return sobol_advance(c, skip, 0);
+}
+
+extern "C" int mpt_sobol_update(mpt_ctx *c, int count) {                       // sobol.py:99-105
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (!c->sV) return fail("sobol sampler not initialised");
+    return sobol_advance(c, count, 0);
+}
+
+extern "C" int mpt_sobol_get(mpt_ctx *c, int32_t *X, float *P, int32_t *time) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (!c->sV) return fail("sobol sampler not initialised");
+    std::vector<int32_t> x(c->sdim);
+    HIP_TRY(hipMemcpyAsync(x.data(), c->sX, (size_t)c->sdim * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (X) memcpy(X, x.data(), (size_t)c->sdim * sizeof(int32_t));
+    if (P)
+        for (int j = 0; j < c->sdim; j++) {                                    // construct_float, sobol.py:20-29
+            float ret = 0.f, term = 0.5f;
+            for (uint32_t v = (uint32_t)x[j]; v; v <<= 1, term *= 0.5f)
+                if (v & 0x80000000u) ret += term;
+            P[j] = ret;
+        }
+    if (time) *time = c->stime;
+    return 0;
+}
+
+// ------------------------------------------------------------------ rendering
+static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
+    if (c->nx <= 0) return fail("film size not set: call set_size() first");
+    if (!c->sV) return fail("sobol sampler not initialised");
+    if (!c->tree_valid) return fail("BVH not built: call build_tree() after load_model()");
+    memset(&p, 0, sizeof p);
+    p.nx = c->nx; p.ny = c->ny; p.x0 = c->x0; p.x1 = c->x1;
+    p.nframes = nframes; p.n = c->nfaces;
+    p.sobol_dim = c->sdim; p.nlights = (int)c->h_lights.size(); p.world_tex = c->world_tex;
+    p.tiles_x = (c->x1 - c->x0 + MPT_TILE - 1) / MPT_TILE;
+    p.tiles_y = (c->ny + MPT_TILE - 1) / MPT_TILE;
+    p.ntiles = p.tiles_x * p.tiles_y;
+    memcpy(p.world_fac, c->world_fac, sizeof p.world_fac);
+    memcpy(p.v2w, c->v2w, sizeof p.v2w);
+    p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade;
+    p.mats = c->mats; p.lights = c->lights; p.images = c->images; p.texels = c->texels;
+    p.P = c->sP;
+    p.film0 = c->film[0]; p.film1 = c->film[1]; p.film2 = c->film[2];
+    p.counters = c->d_counters;
+    if (p.world_tex != -1 && (p.world_tex < 0 || p.world_tex >= (int)c->h_images.size()))
+        return fail("world light texture %d is not a loaded image", p.world_tex);
+    return 0;
+}
+
+static hipEvent_t get_event(mpt_ctx *c) {
+    hipEvent_t e = nullptr;
+    if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+    else hipEventCreate(&e);
+    return e;
+}
+
+extern "C" int mpt_flush(mpt_ctx *c) {
+    if (!c) return fail("null context");
+    if (c->pending == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    int B = c->pending;
+    c->pending = 0;
+    MptRenderParams p;
+    if (fill_params(c, p, B)) return 1;
+    if (p.ntiles == 0) return sobol_advance(c, B, 0);
+    if (sobol_advance(c, B, B)) return 1;
+
+    const int stack = (c->tree_depth + 2 <= 32) ? 32 : 64;
+    int chunk = B, nchunks = 1;
+    if (c->mode == MPT_MODE_FAST) {
+        chunk = c->chunk;
+        if (chunk <= 0) {
+            // aim for >= ~6000 work items so the dispatcher can balance them over 256 CUs
+            int want = (6144 + p.ntiles - 1) / p.ntiles;
+            want = std::max(1, std::min(want, B));
+            chunk = (B + want - 1) / want;
+            chunk = std::max(chunk, std::min(B, 4));
+        }
+        chunk = std::min(chunk, B);
+        nchunks = (B + chunk - 1) / chunk;
+    }
+    p.chunk = chunk; p.nchunks = nchunks;
+    if (nchunks > 1) {
+        size_t need = (size_t)nchunks * c->nx * c->ny;
+        if (need > c->partial_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            hipFree(c->partial); c->partial = nullptr;
+            if (dev_alloc(&c->partial, need)) return 1;
+            c->partial_cap = need;
+        }
+        p.partial = c->partial;
+    }
+    hipEvent_t e0 = get_event(c), e1 = get_event(c);
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    int grid = p.ntiles * nchunks;
+    if (c->mode == MPT_MODE_STRICT) HIP_TRY(mpt_launch_render_strict(&p, grid, stack, c->count, c->stream));
+    else HIP_TRY(mpt_launch_render_fast(&p, grid, stack, c->count, c->stream));
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    c->events.push_back({ e0, e1 });
+    if (nchunks > 1) HIP_TRY(mpt_launch_combine(c->film[0], c->partial, c->nx, c->ny, c->x0, c->x1, nchunks, c->stream));
+    return 0;
+}
+
+extern "C" int mpt_render(mpt_ctx *c, int nframes) {                           // path.py:75-77
+    if (!c) return fail("null context");
+    if (nframes < 0) return fail("nframes must be >= 0");
+    // fail at the call, not at the deferred launch
+    if (c->nx <= 0) return fail("film size not set: call set_size() first");
+    if (!c->sV) return fail("sobol sampler not initialised");
+    if (!c->tree_valid) return fail("BVH not built: call build_tree() after load_model()");
+    while (nframes > 0) {
+        int room = c->batch - c->pending;
+        int take = std::min(room, nframes);
+        c->pending += take;
+        nframes -= take;
+        if (c->pending >= c->batch && mpt_flush(c)) return 1;
+    }
+    return 0;
+}
+
+extern "C" int mpt_render_preview(mpt_ctx *c, int nframes) {                   // preview.py:18-41
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    while (nframes > 0) {
+        int B = std::min(nframes, MPT_MAX_BATCH);
+        MptRenderParams p;
+        if (fill_params(c, p, B)) return 1;
+        if (sobol_advance(c, B, B)) return 1;
+        p.chunk = B; p.nchunks = 1;
+        const int stack = (c->tree_depth + 2 <= 32) ? 32 : 64;
+        if (p.ntiles) {
+            if (c->mode == MPT_MODE_STRICT) HIP_TRY(mpt_launch_preview_strict(&p, p.ntiles, stack, c->stream));
+            else HIP_TRY(mpt_launch_preview_fast(&p, p.ntiles, stack, c->stream));
+        }
+        nframes -= B;
+    }
+    return 0;
+}
+
+extern "C" int mpt_synchronize(mpt_ctx *c) {                                   // worker.py:17-18
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mpt_clear(mpt_ctx *c, int pass) {                               // filmtable.py:44-45: every pass, `id` ignored
+    (void)pass;
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    size_t npix = (size_t)c->nx * c->ny;
+    for (int p = 0; p < 3; p++)
+        if (c->film[p]) HIP_TRY(hipMemsetAsync(c->film[p], 0, npix * sizeof(MptVec4), c->stream));
+    return 0;
+}
+
+static int check_pass(mpt_ctx *c, int pass) {
+    if (pass < 0 || pass >= 3) return fail("film pass %d out of range", pass);
+    if (!c->film[pass]) return fail("film size not set: call set_size() first");
+    return 0;
+}
+
+extern "C" int mpt_resolve(mpt_ctx *c, int pass) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (check_pass(c, pass)) return 1;
+    HIP_TRY(mpt_launch_resolve(c->film[pass], c->resolved, (size_t)c->nx * c->ny, c->stream));
+    return 0;
+}
+
+extern "C" int mpt_get_image(mpt_ctx *c, int pass, float *out) {               // filmtable.py:47-63
+    if (mpt_resolve(c, pass)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, c->resolved, (size_t)c->nx * c->ny * sizeof(MptVec4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mpt_fast_export_image(mpt_ctx *c, int pass, float *out) {       // filmtable.py:66-79
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (check_pass(c, pass)) return 1;
+    HIP_TRY(mpt_launch_export(c->film[pass], c->exported, c->nx, c->ny, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->exported, (size_t)c->nx * c->ny * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mpt_get_film_raw(mpt_ctx *c, int pass, float *out) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (check_pass(c, pass)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, c->film[pass], (size_t)c->nx * c->ny * sizeof(MptVec4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ measurement
+extern "C" int mpt_get_counters(mpt_ctx *c, mpt_counters *out) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out->samples = h[0]; out->rays = h[1]; out->n_box = h[2]; out->n_tri = h[3];
+    out->n_shade = h[4]; out->n_draws = h[5]; out->bounces = h[6]; out->n_node = h[7];
+    return 0;
+}
+
+extern "C" int mpt_reset_counters(mpt_ctx *c) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    return 0;
+}
+
+extern "C" int mpt_kernel_time(mpt_ctx *c, double *ms, int *launches) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double total = 0;
+    for (auto &pr : c->events) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second));
+        total += t;
+        c->event_pool.push_back(pr.first);
+        c->event_pool.push_back(pr.second);
+    }
+    if (ms) *ms = total;
+    if (launches) *launches = (int)c->events.size();
+    c->events.clear();
+    return 0;
+}
+
+// ------------------------------------------------------------------ multi-GPU film gather (RCCL over xGMI)
+// One process per GPU; each renders the slab [x0,x1) of a replicated scene.  Film index is
+// x*ny + y (filmtable.py:38), so a slab is ONE contiguous float4 range: every rank sends its
+// range straight into the same range of the root's film -- a one-shot gather on the
+// point-to-point xGMI links, no ring, no reduction.
+
+extern "C" int mpt_comm_unique_id(char uid[128]) {
+    if (rccl_load()) return 1;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(uid, &id, 128);
+    return 0;
+}
+
+extern "C" int mpt_comm_init(mpt_ctx *c, const char uid[128], int nranks, int rank) {
+    if (use(c)) return 1;
+    if (rccl_load()) return 1;
+    if (c->comm) return fail("communicator already initialised");
+    ncclUniqueId id;
+    memcpy(&id, uid, 128);
+    NCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+    c->nranks = nranks; c->rank = rank;
+    return 0;
+}
+
+extern "C" int mpt_comm_gather_film(mpt_ctx *c, int pass, int root) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (check_pass(c, pass)) return 1;
+    if (!c->comm) return fail("communicator not initialised");
+    // slab bounds follow the same split on every rank: x in [r*nx/R, (r+1)*nx/R)
+    const int R = c->nranks;
+    NCCL_TRY(g_rccl.GroupStart());
+    if (c->rank == root) {
+        for (int r = 0; r < R; r++) {
+            if (r == root) continue;
+            size_t lo = (size_t)((long long)r * c->nx / R) * c->ny, hi = (size_t)((long long)(r + 1) * c->nx / R) * c->ny;
+            if (hi > lo) NCCL_TRY(g_rccl.Recv(c->film[pass] + lo, (hi - lo) * 4, ncclFloat, r, c->comm, c->stream));
+        }
+    } else {
+        size_t lo = (size_t)((long long)c->rank * c->nx / R) * c->ny, hi = (size_t)((long long)(c->rank + 1) * c->nx / R) * c->ny;
+        if (hi > lo) NCCL_TRY(g_rccl.Send(c->film[pass] + lo, (hi - lo) * 4, ncclFloat, root, c->comm, c->stream));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    return 0;
+}
+
+extern "C" int mpt_comm_barrier(mpt_ctx *c) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (!c->comm) return fail("communicator not initialised");
+    HIP_TRY(hipMemsetAsync(c->d_scratch, 0, sizeof(double), c->stream));
+    NCCL_TRY(g_rccl.AllReduce(c->d_scratch, c->d_scratch, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mpt_comm_allreduce_max(mpt_ctx *c, double *value) {
+    if (use(c)) return 1;
+    if (!c->comm) return fail("communicator not initialised");
+    HIP_TRY(hipMemcpyAsync(c->d_scratch, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCL_TRY(g_rccl.AllReduce(c->d_scratch, c->d_scratch, 1, ncclDouble, ncclMax, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(value, c->d_scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mpt_comm_destroy(mpt_ctx *c) {
+    if (use(c)) return 1;
+    if (c->comm) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        NCCL_TRY(g_rccl.CommDestroy(c->comm));
+        c->comm = nullptr;
+    }
+    c->nranks = 1; c->rank = 0;
+    return 0;
+}

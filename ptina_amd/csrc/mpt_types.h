@@ -1,0 +1,65 @@
+// mpt_types.h -- structures shared by the host runtime (miptina.cpp) and the gfx950 kernels.
+//
+// HBM layout (all SoA-of-records, 16-byte aligned so every fetch is a dwordx4):
+//   snode  float4[(n-1)*2]  reference-shaped node: {bmin.xyz, child0}, {bmax.xyz, child1}
+//                           (tree/lbvh.py:48-53 keeps four separate arrays; one 32-B record here)
+//   fnode  float4[(n-1)*4]  traversal node: both CHILD boxes + child ids in one 64-B record
+//                           {c0.lo.xyz, c0.hi.x} {c0.hi.yz, c1.lo.xy} {c1.lo.z, c1.hi.xyz} {id0, id1, -, -}
+//                           id >= 0: internal node index; id < 0: leaf, slot = ~id
+//   tgeo   float4[n*4]      per-leaf-slot triangle, ray-independent terms of geometries.py:118-148
+//                           hoisted: {v0.xyz, D} {u.xyz, uu} {v.xyz, uv} {n.xyz, vv}
+//   tshade float4[n*4]      per-leaf-slot shading data: {n0.xyz, n1.x} {n1.yz, n2.xy} {n2.z, uv0.xy, uv1.x}
+//                           {uv1.y, uv2.xy, mtlid}
+//   mats   MptMaterial[m]   the 12 Disney parameters of mtllib.py:44-56 packed in 128 B
+//   P      float[B][dim]    Sobol points of the B frames of a batch (sobol.py:82-83 keeps one)
+//   film   float4[passes][nx*ny], element x*ny + y (filmtable.py:14,37-39)
+#pragma once
+
+#include <stdint.h>
+
+#define MPT_BLOCK 256          // 4 waves of 64; one 16x16 pixel tile, an 8x8 sub-tile per wave
+#define MPT_TILE 16
+#define MPT_MAX_BATCH 64       // frames per launch
+#define MPT_MAX_LIGHTS 64
+
+struct MptVec4 { float x, y, z, w; };
+
+struct MptMaterial {
+    float p[16];               // [0..2] basecolor, [3] metallic, [4] roughness, [5] specular, [6] specularTint,
+                               // [7] subsurface, [8] sheen, [9] sheenTint, [10] clearcoat, [11] clearcoatGloss,
+                               // [12] transmission, [13] ior
+    int32_t tex[12];           // per parameter texture id, -1 = none
+    int32_t any_tex;           // 1 if any tex != -1
+    int32_t pad[3];
+};
+
+struct MptLight {              // light/__init__.py:14-18
+    MptVec4 color_size;        // rgb, size
+    MptVec4 pos_type;          // xyz, type (as int bits)
+    MptVec4 ax0, ax1, ax2;     // rows of the 3x3 axes matrix
+};
+
+struct MptImage { int32_t nx, ny, base, pad; };   // image.py:14-16
+
+struct MptRenderParams {
+    int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders
+    int32_t nframes, chunk, nchunks, n;     // batch frames; frames per work item; items per tile; #triangles
+    int32_t sobol_dim, nlights, world_tex, tiles_x;
+    int32_t tiles_y, ntiles, pad0, pad1;
+    float world_fac[4];
+    float v2w[16];
+    const MptVec4 *snode;
+    const MptVec4 *fnode;
+    const MptVec4 *tgeo;
+    const MptVec4 *tshade;
+    const MptMaterial *mats;
+    const MptLight *lights;
+    const MptImage *images;
+    const MptVec4 *texels;
+    const float *P;                          // [nframes][sobol_dim]
+    MptVec4 *film0;                          // pass 0 (path) / unused by preview
+    MptVec4 *film1;                          // pass 1 (albedo)
+    MptVec4 *film2;                          // pass 2 (normal)
+    MptVec4 *partial;                        // [nchunks][nx*ny] when nchunks > 1
+    unsigned long long *counters;            // mpt_counters when counting, else unused
+};

@@ -1,0 +1,788 @@
+// pt_device.h -- gfx950 device functions of the path-trace hot path.
+//
+// Compiled twice (see Makefile):
+//   MPT_STRICT=1, -ffp-contract=off : the reference's traversal order (tree/lbvh.py:314-347),
+//       IEEE divide/sqrt, libm-grade sin/cos/pow/log.  Exists to check the logic against the CPU
+//       oracle to the last few ulps.
+//   MPT_STRICT=0, -ffp-contract=fast : the production path.  Same sampling, shading and hit
+//       predicates; the BVH is walked near-child-first with depth culling, shadow rays stop at the
+//       first occluder, divisions become v_rcp_f32, sin/cos(2 pi p) become v_sin/v_cos on turns.
+//       Differs from strict only by rounding (and by which of two equal-depth hits wins).
+//
+// Citations are file:line into the reference tree.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "mpt_types.h"
+
+#ifndef MPT_STRICT
+#define MPT_STRICT 0
+#endif
+
+#define MPT_EPS 1e-6f          // common.py:32
+#define MPT_INF 1e6f           // common.py:33
+#define MPT_PI 3.14159265358979323846f
+#define MPT_TAU 6.28318530717958647692f
+#define MPT_INV_PI 0.31830988618379067154f
+
+#define DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- math shims
+#if MPT_STRICT
+DEV float m_div(float a, float b) { return a / b; }
+DEV float m_rcp(float a) { return 1.0f / a; }
+DEV float m_sqrt(float a) { return sqrtf(a); }
+DEV float m_rnorm(float sumsq) { return 1.0f / sqrtf(sumsq); }            // Matrix.normalized(): 1 / norm
+DEV void m_sincos_turn(float p, float *s, float *c) { *c = cosf(p * MPT_TAU); *s = sinf(p * MPT_TAU); }
+DEV float m_pow5(float x) { return powf(x, 5.0f); }
+DEV float m_pow(float a, float b) { return powf(a, b); }
+DEV float m_log(float a) { return logf(a); }
+#else
+DEV float m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+DEV float m_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
+DEV float m_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+DEV float m_rnorm(float sumsq) { return __builtin_amdgcn_rsqf(sumsq); }
+// v_sin_f32 / v_cos_f32 take their argument in turns: spherical()'s p * tau needs no range reduction
+DEV void m_sincos_turn(float p, float *s, float *c) { *c = __builtin_amdgcn_cosf(p); *s = __builtin_amdgcn_sinf(p); }
+DEV float m_pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+DEV float m_pow(float a, float b) { return __builtin_amdgcn_exp2f(b * __builtin_amdgcn_logf(a)); }
+DEV float m_log(float a) { return __builtin_amdgcn_logf(a) * 0.69314718055994530942f; }
+#endif
+
+struct V3 { float x, y, z; };
+DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV V3 v3s(float s) { return v3(s, s, s); }
+DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+DEV V3 vdivs(V3 a, float s) { return v3(m_div(a.x, s), m_div(a.y, s), m_div(a.z, s)); }
+DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV float norm_sqr(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+DEV V3 normalized(V3 a) { return a * m_rnorm(norm_sqr(a)); }
+DEV float vavg(V3 a) { return m_div(a.x + a.y + a.z, 3.0f); }                 // common.py:73-77
+DEV bool any_gt0(V3 a) { return a.x > 0.0f || a.y > 0.0f || a.z > 0.0f; }
+DEV bool any_ne0(V3 a) { return a.x != 0.0f || a.y != 0.0f || a.z != 0.0f; }
+DEV float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }   // common.py:163-165
+DEV float dot_or_zero(V3 a, V3 b) { return fmaxf(0.0f, dot(a, b)); }          // common.py:178-180
+DEV float lerpf(float f, float src, float dst) { return src * (1.0f - f) + dst * f; }   // common.py:269-271
+DEV V3 lerpv(float f, V3 src, V3 dst) { return src * (1.0f - f) + dst * f; }
+DEV V3 reflectv(V3 I, V3 N) { return I - N * (2.0f * dot(N, I)); }            // common.py:247-249
+
+DEV bool refractv(V3 I, V3 N, float eta, V3 *T) {                            // common.py:252-260
+    bool has_r = false;
+    *T = v3s(0.0f);
+    float NoI = dot(N, I);
+    float discr = 1.0f - eta * eta * (1.0f - NoI * NoI);
+    if (discr > 0.0f) {
+        has_r = true;
+        *T = normalized(I * eta - N * (eta * NoI + m_sqrt(discr)));
+    }
+    return has_r;
+}
+
+DEV V3 spherical(float h, float p) {                                         // common.py:221-225
+    float s, c;
+    m_sincos_turn(p, &s, &c);
+    float r = m_sqrt(fmaxf(0.0f, 1.0f - h * h));
+    return v3(r * c, r * s, h);
+}
+
+DEV V3 tanspace_mul(V3 nrm, V3 v) {                                          // common.py:213-217
+    V3 up = v3(233.0f, 666.0f, 512.0f);
+    V3 bitan = normalized(cross(nrm, up));
+    V3 tan = cross(bitan, nrm);
+    return v3(tan.x * v.x + bitan.x * v.y + nrm.x * v.z,
+              tan.y * v.x + bitan.y * v.y + nrm.y * v.z,
+              tan.z * v.x + bitan.z * v.y + nrm.z * v.z);
+}
+
+// ---------------------------------------------------------------- sampling
+DEV int wanghash(int x) {                                                    // sampling/__init__.py:9-16
+    unsigned v = (unsigned)x;
+    v = (v ^ 61u) ^ (v >> 16);
+    v *= 9u;
+    v ^= v << 4;
+    v *= 0x27d4eb2du;
+    v ^= v >> 15;
+    return (int)v;
+}
+DEV int wanghash2(int x, int y) { return wanghash(y ^ wanghash(x)); }        // sampling/__init__.py:20-23
+
+struct Rng { const float *P; int i; int dim; };                              // SobolSampler.Proxy, sobol.py:113-125
+DEV float rng_random(Rng &r) {
+    int k = r.i % r.dim;
+    if (k < 0) k += r.dim;                                                   // Python floor-mod
+    float v = r.P[k];
+    r.i = (int)((unsigned)r.i + 1u);                                         // i32 wrap
+    return v;
+}
+DEV V3 random3(Rng &r) { float a = rng_random(r), b = rng_random(r), c = rng_random(r); return v3(a, b, c); }
+
+// ---------------------------------------------------------------- counters
+struct Cnt { unsigned rays, n_box, n_tri, n_shade, n_draws, bounces, n_node, samples; };
+
+// ---------------------------------------------------------------- geometry
+struct Hit { int hit; float depth; int index; float u, v; };
+
+DEV V3 ld3(const MptVec4 &a) { return v3(a.x, a.y, a.z); }
+
+// Face.intersect, geometries.py:118-148, with the ray-independent terms hoisted into tgeo
+DEV bool tri_test(const MptVec4 *__restrict__ tgeo, int slot, V3 ro, V3 rd, float *depth, float *s_, float *t_) {
+    const MptVec4 *g = tgeo + (size_t)slot * 4;
+    MptVec4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+    V3 v0 = ld3(g0), u = ld3(g1), v = ld3(g2), norm = ld3(g3);
+    float D = g0.w, uu = g1.w, uv = g2.w, vv = g3.w;
+    float b = dot(norm, rd);
+    bool hit = false;
+    if (fabsf(b) >= MPT_EPS) {
+        V3 w0 = ro - v0;
+        float a = -dot(norm, w0);
+        float r = m_div(a, b);
+        if (r > 0.0f) {
+            V3 ip = ro + rd * r;
+            V3 w = ip - v0;
+            float wu = dot(w, u);
+            float wv = dot(w, v);
+            float s = m_div(uv * wv - vv * wu, D);
+            float t = m_div(uv * wu - uu * wv, D);
+            if (0.0f <= s && s <= 1.0f && 0.0f <= t && s + t <= 1.0f) {
+                *depth = r; *s_ = s; *t_ = t;
+                hit = true;
+            }
+        }
+    }
+    return hit;
+}
+
+// Box.intersect, geometries.py:24-46
+DEV bool box_strict(V3 lo, V3 hi, V3 ro, V3 rd) {
+    float nearv = 0.0f, farv = MPT_INF;
+    bool hit = true;
+    const float lo_[3] = { lo.x, lo.y, lo.z }, hi_[3] = { hi.x, hi.y, hi.z };
+    const float o_[3] = { ro.x, ro.y, ro.z }, d_[3] = { rd.x, rd.y, rd.z };
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (fabsf(d_[i]) < MPT_EPS) {
+            if (o_[i] < lo_[i] || o_[i] > hi_[i]) hit = false;
+        } else {
+            float i1 = (lo_[i] - o_[i]) / d_[i];
+            float i2 = (hi_[i] - o_[i]) / d_[i];
+            if (i1 > i2) { float t = i1; i1 = i2; i2 = t; }
+            farv = fminf(farv, i2);
+            nearv = fmaxf(nearv, i1);
+            if (nearv > farv) hit = false;
+        }
+    }
+    return hit;
+}
+
+// per-lane LIFO in LDS: element [level][thread], so a wave's push/pop touches 64 consecutive
+// dwords (conflict-free); replaces GlobalStack's [thread][level] rows in global memory, stack.py:10-60
+struct Stack {
+    int *base;                 // &lds[threadIdx.x]
+    int sp;
+    DEV void push(int v) { base[sp * MPT_BLOCK] = v; sp++; }
+    DEV int pop() { sp--; return base[sp * MPT_BLOCK]; }
+};
+
+#if MPT_STRICT
+// LinearBVH.intersect, tree/lbvh.py:314-347, operation for operation.  `avoid`/index are leaf slots.
+template <bool COUNT>
+DEV Hit bvh_closest(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, Cnt &cnt) {
+    const int n = p.n;
+    Stack st; st.base = lds; st.sp = 0;
+    st.push(n);
+    Hit ret; ret.hit = 0; ret.depth = MPT_INF; ret.index = -1; ret.u = 0.0f; ret.v = 0.0f;
+    if (COUNT) cnt.rays++;
+    int ntimes = 0;
+    while (ntimes < n && st.sp != 0) {
+        int curr = st.pop();
+        if (curr < n) {
+            if (curr != avoid) {
+                if (COUNT) cnt.n_tri++;
+                float d, s, t;
+                if (tri_test(p.tgeo, curr, ro, rd, &d, &s, &t) && d < ret.depth) {
+                    ret.depth = d; ret.index = curr; ret.u = s; ret.v = t; ret.hit = 1;
+                }
+            }
+            continue;
+        }
+        int i = curr - n;
+        MptVec4 a = p.snode[(size_t)i * 2], b = p.snode[(size_t)i * 2 + 1];
+        if (COUNT) { cnt.n_box++; cnt.n_node++; }
+        if (!box_strict(ld3(a), ld3(b), ro, rd)) continue;
+        ntimes++;
+        st.push(__float_as_int(a.w));
+        st.push(__float_as_int(b.w));
+    }
+    return ret;
+}
+
+// path.py:50-51: the shadow ray is a full closest-hit query in the reference
+template <bool COUNT>
+DEV bool bvh_occluded(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, float dis, Cnt &cnt) {
+    Hit occ = bvh_closest<COUNT>(p, lds, ro, rd, avoid, cnt);
+    return !(occ.hit == 0 || occ.depth > dis);
+}
+
+#else  // ---------------------------------------------------------------- production traversal
+
+// slab test against [0, tmax] with precomputed 1/d and o/d; returns entry distance
+DEV bool box_fast(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                  V3 inv, V3 oinv, float tmax, float *tnear) {
+    float t1x = __builtin_fmaf(lox, inv.x, -oinv.x), t2x = __builtin_fmaf(hix, inv.x, -oinv.x);
+    float t1y = __builtin_fmaf(loy, inv.y, -oinv.y), t2y = __builtin_fmaf(hiy, inv.y, -oinv.y);
+    float t1z = __builtin_fmaf(loz, inv.z, -oinv.z), t2z = __builtin_fmaf(hiz, inv.z, -oinv.z);
+    float tn = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
+    float tf = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tmax));
+    *tnear = tn;
+    return tn <= tf;
+}
+
+// Same hit set as lbvh.py:314-347 (every triangle whose own and ancestors' boxes the ray enters
+// before the best depth is tested); the order differs: near child first, far child pushed,
+// subtrees beyond the best depth skipped.  ANY = stop at the first hit with depth <= tmax
+// (path.py:51: occluded iff the closest hit is within li.dis).
+template <bool ANY, bool COUNT>
+DEV Hit bvh_walk(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, float tmax, Cnt &cnt) {
+    Hit ret; ret.hit = 0; ret.depth = tmax; ret.index = -1; ret.u = 0.0f; ret.v = 0.0f;
+    if (COUNT) cnt.rays++;
+    if (p.n < 2) return ret;   // lbvh.py:218,319: with one face the root box is never written
+    V3 inv = v3(m_rcp(rd.x), m_rcp(rd.y), m_rcp(rd.z));
+    V3 oinv = ro * inv;
+    Stack st; st.base = lds; st.sp = 0;
+    int curr = 0;
+    for (;;) {
+        const MptVec4 *nd = p.fnode + (size_t)curr * 4;
+        MptVec4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+        int id0 = __float_as_int(d.x), id1 = __float_as_int(d.y);
+        if (COUNT) { cnt.n_node++; cnt.n_box += 2; }
+        float tn0, tn1;
+        bool h0 = box_fast(a.x, a.y, a.z, a.w, b.x, b.y, inv, oinv, ret.depth, &tn0);
+        bool h1 = box_fast(b.z, b.w, c.x, c.y, c.z, c.w, inv, oinv, ret.depth, &tn1);
+        if (h0 && id0 < 0) {
+            h0 = false;
+            int slot = ~id0;
+            if (slot != avoid) {
+                if (COUNT) cnt.n_tri++;
+                float dd, s, t;
+                if (tri_test(p.tgeo, slot, ro, rd, &dd, &s, &t) && (ANY ? dd <= ret.depth : dd < ret.depth)) {
+                    ret.depth = dd; ret.index = slot; ret.u = s; ret.v = t; ret.hit = 1;
+                    if (ANY) return ret;
+                }
+            }
+        }
+        if (h1 && id1 < 0) {
+            h1 = false;
+            int slot = ~id1;
+            if (slot != avoid) {
+                if (COUNT) cnt.n_tri++;
+                float dd, s, t;
+                if (tri_test(p.tgeo, slot, ro, rd, &dd, &s, &t) && (ANY ? dd <= ret.depth : dd < ret.depth)) {
+                    ret.depth = dd; ret.index = slot; ret.u = s; ret.v = t; ret.hit = 1;
+                    if (ANY) return ret;
+                }
+            }
+        }
+        if (h0 && h1) {
+            bool swap = tn1 < tn0;
+            st.push(swap ? id0 : id1);
+            curr = swap ? id1 : id0;
+        } else if (h0) {
+            curr = id0;
+        } else if (h1) {
+            curr = id1;
+        } else {
+            if (st.sp == 0) break;
+            curr = st.pop();
+        }
+    }
+    return ret;
+}
+
+template <bool COUNT>
+DEV Hit bvh_closest(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, Cnt &cnt) {
+    Hit h = bvh_walk<false, COUNT>(p, lds, ro, rd, avoid, MPT_INF, cnt);
+    if (!h.hit) h.depth = MPT_INF;
+    return h;
+}
+
+template <bool COUNT>
+DEV bool bvh_occluded(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, float dis, Cnt &cnt) {
+    return bvh_walk<true, COUNT>(p, lds, ro, rd, avoid, dis, cnt).hit != 0;
+}
+#endif
+
+DEV float sphere_intersect(V3 pos, float rad2, V3 ro, V3 rd) {               // geometries.py:159-177
+    float ret = 0.0f;
+    V3 op = pos - ro;
+    float b = dot(op, rd);
+    float det = b * b + rad2 - norm_sqr(op);
+    if (det >= 0.0f) {
+        det = m_sqrt(det);
+        float t = b - det;
+        if (t > MPT_EPS) {
+            ret = t;
+        } else {
+            t = b + det;
+            if (t > MPT_EPS) ret = t;
+        }
+    }
+    return ret;
+}
+
+DEV bool area_intersect(V3 pos, V3 dirx, V3 diry, V3 ro, V3 rd, float *depth) {   // geometries.py:58-74
+    bool hit = false;
+    V3 nrm = normalized(cross(dirx, diry));
+    float NoD = dot(nrm, rd);
+    if (NoD > MPT_EPS) {
+        float t = m_div(dot(nrm, pos - ro), NoD);
+        V3 hitdisp = ro + rd * t - pos;
+        float u = m_div(dot(hitdisp, dirx), norm_sqr(dirx));
+        float v = m_div(dot(hitdisp, diry), norm_sqr(diry));
+        *depth = t;
+        if (-1.0f < u && u < 1.0f && -1.0f < v && v < 1.0f) hit = true;
+    }
+    return hit;
+}
+
+// ---------------------------------------------------------------- textures (image.py:137-148, common.py:183-192)
+DEV int pymod(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }
+
+DEV MptVec4 image_texel(const MptRenderParams &p, MptImage im, int x, int y) {
+    x = pymod(x, im.nx);
+    y = pymod(y, im.ny);
+    return p.texels[(size_t)im.base + (size_t)x * im.ny + y];
+}
+
+DEV MptVec4 image_sample(const MptRenderParams &p, int id, float x, float y) {
+    MptImage im = p.images[id];
+    float px = x * (float)(im.nx - 1), py = y * (float)(im.ny - 1);
+    float fx = floorf(px), fy = floorf(py);
+    int Ix = (int)fx, Iy = (int)fy;
+    float x0 = px - fx, x1 = py - fy;
+    float y0 = 1.0f - x0, y1 = 1.0f - x1;
+    MptVec4 t11 = image_texel(p, im, Ix + 1, Iy + 1), t10 = image_texel(p, im, Ix + 1, Iy);
+    MptVec4 t00 = image_texel(p, im, Ix, Iy), t01 = image_texel(p, im, Ix, Iy + 1);
+    MptVec4 r;
+    r.x = t11.x * x0 * x1 + t10.x * x0 * y1 + t00.x * y0 * y1 + t01.x * y0 * x1;
+    r.y = t11.y * x0 * x1 + t10.y * x0 * y1 + t00.y * y0 * y1 + t01.y * y0 * x1;
+    r.z = t11.z * x0 * x1 + t10.z * x0 * y1 + t00.z * y0 * y1 + t01.z * y0 * x1;
+    r.w = t11.w * x0 * x1 + t10.w * x0 * y1 + t00.w * y0 * y1 + t01.w * y0 * x1;
+    return r;
+}
+
+// ---------------------------------------------------------------- microfacet.py
+DEV float schlickFresnel(float cost) { return m_pow5(clampf(1.0f - cost, 0.0f, 1.0f)); }   // :9-10
+
+DEV float dielectricFresnel(float etai, float etao, float cosi) {            // :14-27
+    float sini = m_sqrt(fmaxf(0.0f, 1.0f - cosi * cosi));
+    float sint = m_div(etao, etai) * sini;
+    float ret = 1.0f;
+    if (sint < 1.0f) {
+        float cost = m_sqrt(fmaxf(0.0f, 1.0f - sint * sint));
+        float a1 = etai * cosi, a2 = etao * cost;
+        float b1 = etao * cosi, b2 = etai * cost;
+        float para = m_div(a1 - a2, a1 + a2);
+        float perp = m_div(b1 - b2, b1 + b2);
+        ret = 0.5f * (para * para + perp * perp);
+    }
+    return ret;
+}
+
+DEV float GTR1(float cosh_, float alpha) {                                   // :31-34
+    float alpha2 = alpha * alpha;
+    float t = 1.0f + (alpha2 - 1.0f) * (cosh_ * cosh_);
+    return m_div(alpha2 - 1.0f, MPT_PI * m_log(alpha2) * t);
+}
+DEV float GTR2(float cosh_, float alpha) {                                   // :38-41
+    float alpha2 = alpha * alpha;
+    float t = 1.0f + (alpha2 - 1.0f) * (cosh_ * cosh_);
+    return m_div(alpha2, MPT_PI * (t * t));
+}
+DEV float smithGGX(float cosi, float alpha) {                                // :45-48
+    float a = alpha * alpha;
+    float b = cosi * cosi;
+    return m_rcp(cosi + m_sqrt(a + b - a * b));
+}
+DEV V3 sample_GTR1(float u, float v, float alpha) {                          // :69-71 (NaN for alpha < 1, like the reference)
+    u = m_div(m_sqrt(m_pow(alpha, 2.0f - 2.0f * u) - 1.0f), alpha * alpha - 1.0f);
+    return spherical(u, v);
+}
+DEV V3 sample_GTR2(float u, float v, float alpha) {                          // :75-77
+    u = m_sqrt(m_div(1.0f - u, 1.0f - u * (1.0f - alpha * alpha)));
+    return spherical(u, v);
+}
+
+// ---------------------------------------------------------------- materials/disney.py
+struct Disney {
+    V3 basecolor;
+    float metallic, roughness, specular, specularTint, subsurface, sheen, sheenTint, clearcoat,
+        clearcoatGloss, transmission, ior;
+    V3 speccolor, sheencolor;
+    float alpha, clearcoatAlpha;
+};
+
+DEV void disney_init(Disney &m) {                                            // disney.py:14-50
+    V3 tint = v3s(1.0f);
+    float lum = dot(m.basecolor, v3(0.3f, 0.6f, 0.1f));
+    if (lum > MPT_EPS) tint = vdivs(m.basecolor, lum);
+    m.speccolor = lerpv(m.metallic, lerpv(m.specularTint, v3s(1.0f), tint) * (m.specular * 0.08f), m.basecolor);
+    m.sheencolor = lerpv(m.sheenTint, v3s(1.0f), tint);
+    m.alpha = fmaxf(0.001f, m.roughness * m.roughness);
+    m.clearcoatAlpha = lerpf(m.clearcoatGloss, 0.1f, 0.001f);
+}
+
+// MaterialPool.get + ParameterPair.get, mtllib.py:30-38,79-95
+DEV void material_get(const MptRenderParams &p, int mtlid, float tu, float tv, Disney &m) {
+    if (mtlid == -1) {
+        m.basecolor = v3s(0.8f);
+        m.metallic = 0.0f; m.roughness = 0.4f; m.specular = 0.5f; m.specularTint = 0.4f;
+        m.subsurface = 0.0f; m.sheen = 0.0f; m.sheenTint = 0.4f; m.clearcoat = 0.0f;
+        m.clearcoatGloss = 0.5f; m.transmission = 0.0f; m.ior = 1.45f;
+    } else {
+        const MptVec4 *q = (const MptVec4 *)(p.mats + mtlid);
+        MptVec4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        float v[14] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y };
+        const MptMaterial *mt = p.mats + mtlid;
+        if (mt->any_tex) {
+#pragma unroll 1
+            for (int k = 0; k < 12; k++) {
+                int texid = mt->tex[k];
+                if (texid != -1) {
+                    MptVec4 t = image_sample(p, texid, tu, tv);
+                    if (k == 0) { v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; }
+                    else {
+                        // scalar parameters take .x of fac * texel (mtllib.py:83-93)
+                        switch (k) {
+                        case 1: v[3] *= t.x; break; case 2: v[4] *= t.x; break; case 3: v[5] *= t.x; break;
+                        case 4: v[6] *= t.x; break; case 5: v[7] *= t.x; break; case 6: v[8] *= t.x; break;
+                        case 7: v[9] *= t.x; break; case 8: v[10] *= t.x; break; case 9: v[11] *= t.x; break;
+                        case 10: v[12] *= t.x; break; default: v[13] *= t.x; break;
+                        }
+                    }
+                }
+            }
+        }
+        m.basecolor = v3(v[0], v[1], v[2]);
+        m.metallic = v[3]; m.roughness = v[4]; m.specular = v[5]; m.specularTint = v[6];
+        m.subsurface = v[7]; m.sheen = v[8]; m.sheenTint = v[9]; m.clearcoat = v[10];
+        m.clearcoatGloss = v[11]; m.transmission = v[12]; m.ior = v[13];
+    }
+    disney_init(m);
+}
+
+DEV V3 disney_brdf(const Disney &m, V3 normal, float sign, V3 indir, V3 outdir) {   // disney.py:53-106
+    float etai = 1.0f, etao = m.ior;
+    if (sign < 0.0f) { etai = m.ior; etao = 1.0f; }
+
+    V3 halfdir = normalized(indir + outdir);
+    float cosi = dot(indir, normal);
+    float coso = dot(outdir, normal);
+    float cosh_ = dot_or_zero(halfdir, normal);
+    float cosoh = dot_or_zero(halfdir, outdir);
+
+    V3 result = v3s(0.0f);
+    if (coso < 0.0f) {
+        if (cosi >= 0.0f) {
+            float Ds = GTR2(cosh_, m.alpha);
+            float fdf = dielectricFresnel(etao, etai, cosoh);
+            V3 transmit = m.basecolor * MPT_INV_PI * (1.0f - fdf) * Ds;
+            result = transmit * (1.0f - m.metallic) * m.transmission;
+        }
+    } else {
+        float Fi = schlickFresnel(cosi);
+        float Fo = schlickFresnel(coso);
+        float Fd90 = 0.5f + 2.0f * (cosoh * cosoh) * m.roughness;
+        float Fd = lerpf(Fi, 1.0f, Fd90) * lerpf(Fo, 1.0f, Fd90);
+
+        float Fss90 = (cosoh * cosoh) * m.roughness;
+        float Fss = lerpf(Fi, 1.0f, Fss90) * lerpf(Fo, 1.0f, Fss90);
+        float ss = 1.25f * (Fss * (m_rcp(cosi + coso) - 0.5f) + 0.5f);
+
+        float Foh = schlickFresnel(cosoh);
+        V3 Fsheen = m.sheencolor * (Foh * m.sheen);
+
+        float fdf = dielectricFresnel(etao, etai, cosoh);
+
+        float Ds = GTR2(cosh_, m.alpha);
+        V3 Fs = lerpv(Foh, m.speccolor, v3s(1.0f));
+        float Gs = smithGGX(cosi, m.alpha) * smithGGX(coso, m.alpha);
+
+        float Dr = GTR1(cosh_, m.clearcoatAlpha);
+        float Gr = smithGGX(cosi, 0.25f) * smithGGX(coso, 0.25f);
+        float Fr = lerpf(Foh, 0.04f, 1.0f);
+
+        V3 diffuse = m.basecolor * (MPT_INV_PI * lerpf(m.subsurface, Fd, ss)) + Fsheen;
+        V3 specular = Fs * Gs * Ds + v3s(0.25f * m.clearcoat * Gr * Fr * Dr);
+        V3 transmit = m.basecolor * (MPT_INV_PI * fdf * Ds);
+
+        result = diffuse * (1.0f - m.metallic) * (1.0f - m.transmission);
+        result = result + transmit * (1.0f - m.metallic) * m.transmission;
+        result = result + specular * (1.0f - m.transmission);
+    }
+    return result;
+}
+
+struct BsdfSample { V3 outdir; float pdf; V3 color; };
+
+struct Choice {                                                               // materials/__init__.py:22-48
+    float pdf, w;
+    DEV bool operator()(float r) {
+        bool ret;
+        if (w < r) {
+            w = m_div(w, r);
+            pdf *= r;
+            ret = true;
+        } else {
+            w = m_div(w - r, 1.0f - r);
+            pdf *= 1.0f - r;
+            ret = false;
+        }
+        return ret;
+    }
+};
+
+DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V3 samp) {   // disney.py:115-233
+    BsdfSample result;
+    result.outdir = v3s(0.0f); result.pdf = 0.0f; result.color = v3s(0.0f);
+
+    float etai = 1.0f, etao = m.ior;
+    if (sign < 0.0f) { etai = m.ior; etao = 1.0f; }
+    float eta = m_div(etai, etao);
+
+    float cosi = dot(indir, normal);
+    float Fi = schlickFresnel(cosi);
+    V3 Fs = lerpv(Fi, m.speccolor, v3s(1.0f));
+
+    Choice choice; choice.pdf = 1.0f; choice.w = samp.z;
+    float specrate = lerpf(m.transmission, lerpf(m.metallic, vavg(Fs), 1.0f), 1.0f);
+    float coatrate = 0.04f * m.clearcoat;
+
+    specrate = lerpf(specrate, 0.1f, 1.0f);
+    if (coatrate != 0.0f) coatrate = lerpf(coatrate, 0.1f, 1.0f);
+
+    if (choice(coatrate)) {
+        float alpha = m.clearcoatAlpha;
+        V3 halfdir = tanspace_mul(normal, sample_GTR1(samp.x, samp.y, alpha));
+        V3 outdir = reflectv(-indir, halfdir);
+
+        float coso = dot(outdir, normal);
+        float cosh_ = dot_or_zero(halfdir, normal);
+        float cosoh = dot_or_zero(halfdir, outdir);
+        if (cosoh > 0.0f) {
+            float Dr = GTR1(cosh_, alpha);
+            float Foh = schlickFresnel(cosoh);
+            float Fr = lerpf(Foh, 0.04f, 1.0f);
+
+            result.outdir = outdir;
+            float partial = m_div(m.clearcoat * Fr * coso, cosoh);
+            result.pdf = Dr * partial;
+            result.color = v3s(m_div(partial, choice.pdf));
+        }
+    } else if (choice(specrate)) {
+        float alpha = m.alpha;
+        V3 halfdir = tanspace_mul(normal, sample_GTR2(samp.x, samp.y, alpha));
+        V3 outdir = reflectv(-indir, halfdir);
+
+        float coso = dot_or_zero(outdir, normal);
+        float cosh_ = dot_or_zero(halfdir, normal);
+        float cosoh = dot_or_zero(halfdir, outdir);
+        if (cosoh > 0.0f && coso > 0.0f && cosh_ > 0.0f) {
+            float Ds = GTR2(cosh_, alpha);
+
+            if (choice(m.transmission)) {
+                float fdf = dielectricFresnel(etao, etai, cosoh);
+                float reflrate = lerpf(fdf, 0.2f, 1.0f);
+
+                if (choice(reflrate)) {
+                    result.outdir = outdir;
+                    result.pdf = Ds * fdf;
+                    result.color = vdivs(m.basecolor * fdf * m.transmission, choice.pdf);
+                } else {
+                    V3 T;
+                    if (refractv(-indir, halfdir, eta, &T)) {
+                        result.outdir = T;
+                        result.pdf = Ds * (1.0f - fdf);
+                        result.color = vdivs(m.basecolor * (1.0f - fdf) * m.transmission, choice.pdf);
+                    }
+                }
+            } else {
+                float Foh = schlickFresnel(cosoh);
+                V3 Fs2 = lerpv(Foh, m.speccolor, v3s(1.0f));
+
+                result.outdir = outdir;
+                float partial = m_div(0.5f, cosoh * smithGGX(coso, alpha));
+                result.pdf = Ds * vavg(Fs2) * partial;
+                result.color = vdivs(Fs2 * partial * (1.0f - m.transmission), choice.pdf);
+            }
+        }
+    } else {
+        V3 outdir = tanspace_mul(normal, spherical(m_sqrt(samp.x), samp.y));
+
+        V3 halfdir = normalized(indir + outdir);
+        float cosi2 = dot(indir, normal);
+        float coso = dot(outdir, normal);
+        float cosoh = dot_or_zero(halfdir, outdir);
+
+        float Fi2 = schlickFresnel(cosi2);
+        float Fo = schlickFresnel(coso);
+        float Fd90 = 0.5f + 2.0f * (cosoh * cosoh) * m.roughness;
+        float Fd = lerpf(Fi2, 1.0f, Fd90) * lerpf(Fo, 1.0f, Fd90);
+
+        float Fss90 = (cosoh * cosoh) * m.roughness;
+        float Fss = lerpf(Fi2, 1.0f, Fss90) * lerpf(Fo, 1.0f, Fss90);
+        float ss = 1.25f * (Fss * (m_rcp(cosi2 + coso) - 0.5f) + 0.5f);
+
+        float Foh = schlickFresnel(cosoh);
+        V3 Fsheen = m.sheencolor * (Foh * m.sheen);
+
+        V3 diffuse = m.basecolor * (MPT_INV_PI * lerpf(m.subsurface, Fd, ss)) + Fsheen;
+
+        result.outdir = outdir;
+        result.pdf = MPT_INV_PI;
+        result.color = vdivs(diffuse * MPT_PI * (1.0f - m.metallic) * (1.0f - m.transmission), choice.pdf);
+    }
+    return result;
+}
+
+DEV float power_heuristic(float a, float b) {                                // path.py:11-15
+    a = clampf(a, MPT_EPS, MPT_INF); a = a * a;
+    b = clampf(b, MPT_EPS, MPT_INF); b = b * b;
+    return m_div(a, a + b);
+}
+
+// ---------------------------------------------------------------- lights
+DEV V3 axes_mul(const MptLight &L, V3 v) {
+    return v3(L.ax0.x * v.x + L.ax0.y * v.y + L.ax0.z * v.z,
+              L.ax1.x * v.x + L.ax1.y * v.y + L.ax1.z * v.z,
+              L.ax2.x * v.x + L.ax2.y * v.y + L.ax2.z * v.z);
+}
+
+struct LightHit { bool hit; float dis, pdf; V3 color; };
+
+DEV LightHit lights_hit(const MptRenderParams &p, V3 ro, V3 rd) {            // light/__init__.py:51-81
+    LightHit ret; ret.hit = false; ret.dis = MPT_INF; ret.pdf = 0.0f; ret.color = v3s(0.0f);
+    for (int i = 0; i < p.nlights; i++) {
+        MptLight L = p.lights[i];
+        int type = __float_as_int(L.pos_type.w);
+        V3 pos = ld3(L.pos_type);
+        float size = L.color_size.w;
+        float t = 0.0f, area = 0.0f;
+        if (type == 1) {
+            t = sphere_intersect(pos, size * size, ro, rd);
+            area = MPT_PI * (size * size);
+        } else if (type == 2) {
+            V3 dirx = axes_mul(L, v3(size, 0.0f, 0.0f));
+            V3 diry = axes_mul(L, v3(0.0f, size, 0.0f));
+            float d;
+            if (area_intersect(pos, dirx, diry, ro, rd, &d)) {
+                t = d;
+                area = 4.0f * (size * size);
+            }
+        }
+        if (0.0f < t && t < ret.dis) {
+            ret.dis = t;
+            ret.pdf = m_div(ret.dis * ret.dis, area);
+            ret.color = ld3(L.color_size);
+            ret.hit = true;
+            break;
+        }
+    }
+    return ret;
+}
+
+struct LightSample { float dis; V3 dir; float pdf; V3 color; };
+
+DEV LightSample lights_sample(const MptRenderParams &p, V3 hitpos, V3 samp) {   // light/__init__.py:83-121
+    LightSample ret; ret.dis = MPT_INF; ret.dir = v3s(0.0f); ret.pdf = 0.0f; ret.color = v3s(0.0f);
+    if (p.nlights != 0) {
+        int i = (int)floorf(samp.z * (float)p.nlights);
+        i = min(max(i, 0), min(p.nlights, MPT_MAX_LIGHTS - 1));
+        MptLight L = p.lights[i];
+        int type = __float_as_int(L.pos_type.w);
+        V3 color = ld3(L.color_size);
+        V3 pos = ld3(L.pos_type);
+        float size = L.color_size.w;
+
+        V3 litpos = v3s(MPT_INF);
+        V3 norm = v3s(0.0f);
+        float area = 0.0f;
+        if (type == 1) {
+            V3 disp = spherical(samp.x, samp.y);
+            litpos = pos + disp * size;
+            area = MPT_PI * (size * size);
+        } else if (type == 2) {
+            V3 disp = axes_mul(L, v3(samp.x * 2.0f - 1.0f, samp.y * 2.0f - 1.0f, 0.0f));
+            norm = axes_mul(L, v3(0.0f, 0.0f, 1.0f));
+            litpos = pos + disp * size;
+            area = 4.0f * (size * size);
+        }
+        V3 toli = litpos - hitpos;
+        float d2 = norm_sqr(toli);
+#if MPT_STRICT
+        float dis = sqrtf(d2);
+        V3 dir = vdivs(toli, dis);
+        float pdf = dis * dis / area;
+#else
+        float rdis = __builtin_amdgcn_rsqf(d2);
+        float dis = d2 * rdis;
+        V3 dir = toli * rdis;
+        float pdf = dis * dis * __builtin_amdgcn_rcpf(area);
+#endif
+        color = vdivs(color, pdf);
+        if (any_ne0(norm)) color = color * dot_or_zero(norm, dir);
+        ret.dis = dis; ret.dir = dir; ret.pdf = pdf; ret.color = color;
+    }
+    return ret;
+}
+
+DEV V3 world_at(const MptRenderParams &p, V3 dir) {                          // light/world.py:22-29
+    V3 fac = v3(p.world_fac[0], p.world_fac[1], p.world_fac[2]);
+    if (p.world_tex != -1) {
+        V3 d2 = v3(dir.x, dir.z, -dir.y);                                    // dir.y, dir.z = dir.z, -dir.y
+        V3 dn = normalized(d2);                                              // dir2tex, common.py:234-239
+        float s = atan2f(dn.z, dn.x) / MPT_PI * 0.5f + 0.5f;
+        float t = atan2f(dn.y, sqrtf(dn.x * dn.x + dn.z * dn.z)) / MPT_PI + 0.5f;
+        MptVec4 tx = image_sample(p, p.world_tex, s, t);
+        fac = fac * v3(tx.x, tx.y, tx.z);
+    }
+    return fac;
+}
+
+// ---------------------------------------------------------------- camera (camera.py:34-39)
+DEV void camera_generate(const MptRenderParams &p, float x, float y, V3 *ro, V3 *rd) {
+    const float *M = p.v2w;
+    float a0 = M[0] * x + M[1] * y + M[2] * -1.0f + M[3] * 1.0f;
+    float a1 = M[4] * x + M[5] * y + M[6] * -1.0f + M[7] * 1.0f;
+    float a2 = M[8] * x + M[9] * y + M[10] * -1.0f + M[11] * 1.0f;
+    float a3 = M[12] * x + M[13] * y + M[14] * -1.0f + M[15] * 1.0f;
+    float b0 = M[0] * x + M[1] * y + M[2] * 1.0f + M[3] * 1.0f;
+    float b1 = M[4] * x + M[5] * y + M[6] * 1.0f + M[7] * 1.0f;
+    float b2 = M[8] * x + M[9] * y + M[10] * 1.0f + M[11] * 1.0f;
+    float b3 = M[12] * x + M[13] * y + M[14] * 1.0f + M[15] * 1.0f;
+    V3 o = v3(m_div(a0, a3), m_div(a1, a3), m_div(a2, a3));
+    V3 o1 = v3(m_div(b0, b3), m_div(b1, b3), m_div(b2, b3));
+    *ro = o;
+    *rd = normalized(o1 - o);
+}
+
+// ---------------------------------------------------------------- shading geometry (model.py:88-101, geometries.py:96-108)
+DEV void get_geometries(const MptRenderParams &p, const Hit &hit, V3 ro, V3 rd, V3 *hitpos, V3 *normal, Disney &mat) {
+    const MptVec4 *s = p.tshade + (size_t)hit.index * 4;
+    MptVec4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
+    float u = hit.u, v = hit.v;
+    float wx = 1.0f - u - v, wy = u, wz = v;
+    V3 vn0 = v3(s0.x, s0.y, s0.z), vn1 = v3(s0.w, s1.x, s1.y), vn2 = v3(s1.z, s1.w, s2.x);
+    V3 nrm = normalized(vn0 * wx + vn1 * wy + vn2 * wz);
+    float tu = wx * s2.y + wy * s2.w + wz * s3.y;
+    float tv = wx * s2.z + wy * s3.x + wz * s3.z;
+    *hitpos = ro + rd * hit.depth;
+    float sign = -dot(rd, nrm);
+    if (sign < 0.0f) nrm = -nrm;
+    *normal = nrm;
+    material_get(p, __float_as_int(s3.w), tu, tv, mat);
+}

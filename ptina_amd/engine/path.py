@@ -1,0 +1,21 @@
+'''
+unidirectional path integrator (reference engine/path.py).  path_trace / do_render
+(path.py:18-93) are the render megakernel in csrc/render_kernel.hip.
+'''
+
+from . import *                       # noqa: F401,F403
+from ..common import Singleton, register, ctx, np
+from ..sampling import *              # noqa: F401,F403
+from ..sampling.sobol import *        # noqa: F401,F403
+from ..sampling.sobol import SobolSampler
+
+
+@register
+class PathEngine(metaclass=Singleton):
+    def __init__(self):
+        SobolSampler()
+
+    def render(self, nframes=1):
+        '''reference path.py:75-77: one Sobol update + one sample per pixel, asynchronously.
+        Consecutive calls are fused into one launch at the next read-back.'''
+        ctx().call('mpt_render', int(nframes))

@@ -1,0 +1,124 @@
+'''
+CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol the header
+declares, fails loudly without a GPU, and the Python host layer packs inputs the way the
+reference's pools do.  No compute calls.
+'''
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'miptina.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(mpt_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ptina_amd import _lib
+    lib = _lib.load_library()
+    syms = header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(lib, s), f'libmiptina.so lacks {s}'
+    assert sorted(_lib.SIGNATURES) == syms, 'ctypes table and header disagree'
+    assert lib.mpt_version() >= 100
+
+
+def test_no_cpu_fallback():
+    from ptina_amd import _lib
+    lib = _lib.load_library()
+    if lib.mpt_device_count() > 0:
+        pytest.skip('a GPU is visible')
+    with pytest.raises(RuntimeError, match='no HIP device'):
+        _lib.Context()
+    from ptina_amd import common
+    common.reset_all()
+    from ptina_amd.things import init_things
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        init_things()
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dp, dn, fn in os.walk(os.path.join(ROOT, 'ptina_amd')):
+        for f in fn:
+            if f.endswith(('.py', '.cpp', '.hip', '.h')):
+                s = open(os.path.join(dp, f), errors='replace').read()
+                if re.search(r'^\s*(import|from)\s+oracle\b', s, flags=re.M) or 'ptina_oracle' in s:
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_sobol_vgrid_numpy_matches_golden_points():
+    '''host-side calc_sobol_vgrid (numpy) -> Gray-code recurrence -> scipy's points'''
+    from ptina_amd.sampling.sobol import calc_sobol_vgrid
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'sobol_points.npz'))
+    V = calc_sobol_vgrid(2**20, 21201)
+    assert V.shape == (21, 21201) and V.dtype == np.int64
+    X = np.zeros(21201, np.int64)
+    want = {int(k): p for k, p in zip(g['k'], g['P'])}
+    for t in range(0, max(want)):
+        c = 1
+        v = t
+        while v & 1:
+            v >>= 1
+            c += 1
+        X ^= V[c]
+        if t + 1 in want:
+            assert np.array_equal((X / 2.0**32).astype(np.float32), want[t + 1])
+
+
+def test_material_packing_follows_parameterpair_load():
+    from ptina_amd.mtllib import MaterialPool, PARAMS
+    pool = MaterialPool.__new__(MaterialPool)
+    MaterialPool.__init__(pool, 4)
+    assert PARAMS[0] == 'basecolor' and PARAMS[-1] == 'ior' and len(PARAMS) == 12
+    pool.basecolor.load(1, [0.1, 0.2, 0.3], -1)           # 3-vector -> + [1.0]
+    pool.metallic.load(1, None, 2)                        # None -> 1.0, broadcast to 4
+    pool.roughness.load(1, np.float32(0.25), -1)          # 0-d array -> scalar
+    pool.ior.load(1, np.array([1, 2, 3, 4.0]), 5)
+    assert np.allclose(pool._fac[1, 0], [0.1, 0.2, 0.3, 1.0])
+    assert np.allclose(pool._fac[1, 1], [1, 1, 1, 1]) and pool._tex[1, 1] == 2
+    assert np.allclose(pool._fac[1, 2], [0.25] * 4)
+    assert np.allclose(pool._fac[1, 11], [1, 2, 3, 4]) and pool._tex[1, 11] == 5
+    assert np.all(pool._fac[0] == 0) and np.all(pool._tex[0] == -1)   # untouched: zero / none
+
+
+def test_singleton_semantics():
+    from ptina_amd.common import Singleton
+
+    class Foo(metaclass=Singleton):
+        def __init__(self, a=1):
+            self.a = a
+    assert Foo(5) is Foo(7) and Foo().a == 5
+
+
+def test_matrix_helpers_reproduce_the_benchmark_camera():
+    '''exams/benchmark.py:18-23 is perspective(fov=60) @ a view from ~(0,1.95,5.37)'''
+    from ptina_amd.tools.matrix import perspective, lookat, ortho, frustum
+    from ptina_amd.scenes import BENCH_CAMERA
+    p = perspective(fov=60, aspect=1, near=0.05, far=500)
+    assert abs(p[0, 0] - 1.73205081) < 1e-6 and abs(p[2, 2] + 1.00020002) < 1e-6
+    view = np.linalg.inv(p) @ BENCH_CAMERA
+    assert np.allclose(view[3], [0, 0, 0, 1], atol=1e-6)
+    eye = np.linalg.inv(view)[:3, 3]
+    assert np.allclose(eye, [-0.00585, 1.9449, 5.3724], atol=2e-3)
+    assert np.allclose(lookat() @ np.array([0, 0, 3, 1.0]), [0, 0, 0, 1])
+    assert np.allclose((ortho() @ np.array([1, -1, 0, 1.0]))[:2], [1, -1])
+    assert frustum()[3, 2] == -1
+
+
+def test_scenes_have_the_quoted_triangle_counts():
+    from ptina_amd import scenes
+    for name, n in (('s34', 34), ('s978', 978)):
+        v, m, mats, imgs = scenes.get_scene(name)
+        assert v.shape == (3 * n, 8) and v.dtype == np.float32 and m.shape == (n,)
+        assert m.max() < len(mats) and all(len(x) == 12 for x in mats)
+        nrm = np.linalg.norm(v[:, 3:6], axis=1)
+        assert np.allclose(nrm, 1, atol=1e-5)

@@ -1,0 +1,308 @@
+'''
+GPU parity tests (-m gpu): the HIP path, driven through the C ABI by the PTina-named Python
+classes, against the CPU oracle on the same seeded inputs.
+
+Tolerances (resolved image, per-pixel L2 over rgb), calibrated on MI355X and against the
+oracle's own f32-vs-f64 spread (test_oracle_cpu.py::test_f32_oracle_agrees_with_f64_build):
+  strict build : >= 99 % of pixels within 1e-4 * (1 + |ref|), relative RMSE <= 1e-2
+  fast build   : >= 99.5 % of pixels within 1e-3 * (1 + |ref|) needs many spp to hold, because one
+                 flipped discrete decision (lobe choice, edge hit) moves a pixel by O(sample/spp);
+                 stated per test below.
+Integer / index work (Sobol state, tree arrays, sample counts) is bit-exact.
+'''
+
+import os
+
+import numpy as np
+import pytest
+
+from ptina_amd import scenes
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _engine(fresh, *a, **kw):
+    from helpers import setup_engine
+    return setup_engine(*a, **kw)
+
+
+def test_sobol_state_on_device_is_bit_exact(fresh):
+    from ptina_amd.things import init_things
+    from ptina_amd.sampling.sobol import SobolSampler
+    g = np.load(os.path.join(GOLD, 'sobol_points.npz'))
+    want = {int(k): p for k, p in zip(g['k'], g['P'])}
+    init_things()
+    s = SobolSampler()
+    t, X, P = s.state()
+    assert t == 64 and np.array_equal(P, want[64])
+    s.update()
+    t, X, P = s.state()
+    assert t == 65 and np.array_equal(P, want[65])
+    s.skip = 0
+    s.reset()
+    for k in (1, 2, 3):
+        s.update()
+        assert np.array_equal(s.state()[2], want[k])
+
+
+@pytest.mark.parametrize('name', ['s34', 's978'])
+def test_tree_is_node_for_node_the_reference_lbvh(fresh, oracle_mod, name):
+    from ptina_amd.things import BVHTree
+    scene = scenes.get_scene(name)
+    n = scene[1].shape[0]
+    _engine(fresh, scene, 16, 16)
+    t = BVHTree().to_numpy()
+    o = oracle_mod.Oracle(sobol=False)
+    o.load_model(scene[0], scene[1])
+    o.build_tree()
+    r = o.get_tree(n)
+    for k in ('mc', 'leaf', 'child', 'bmin', 'bmax'):
+        assert np.array_equal(t[k], r[k]), k
+    assert t['depth'] + 1 <= 32
+
+
+def _bench_sequence(eng, film, spp):
+    eng.render()                     # exams/benchmark.py:25-27
+    film.get_image()
+    film.clear()
+    for _ in range(spp):             # :31-33, one call per sample like the reference
+        eng.render()
+    return film.get_image()
+
+
+@pytest.mark.parametrize('name,nx,ny,spp', [('s34', 64, 64, 8), ('s978', 96, 80, 8)])
+def test_strict_build_matches_oracle(fresh, oracle_mod, name, nx, ny, spp):
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    scene = scenes.get_scene(name)
+    ref = setup_oracle(oracle_mod, scene, nx, ny)
+    ref.render(1)
+    ref.clear()
+    ref.render(spp)
+    want = ref.get_image()
+    eng = _engine(fresh, scene, nx, ny, mode='strict')
+    img = _bench_sequence(eng, FilmTable(), spp)
+    assert np.all(img[..., 3] == 1.0)
+    assert_parity(img, want, 1e-4, 0.01, 1e-2, what=f'strict {name} {nx}x{ny}x{spp}')
+
+
+@pytest.mark.parametrize('name,nx,ny,spp', [('s34', 96, 96, 32), ('s978', 128, 128, 32)])
+def test_fast_build_matches_oracle(fresh, oracle_mod, name, nx, ny, spp):
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    scene = scenes.get_scene(name)
+    ref = setup_oracle(oracle_mod, scene, nx, ny)
+    ref.render(1)
+    ref.clear()
+    ref.render(spp)
+    want = ref.get_image()
+    eng = _engine(fresh, scene, nx, ny, mode='fast')
+    img = _bench_sequence(eng, FilmTable(), spp)
+    assert np.all(img[..., 3] == 1.0)
+    assert_parity(img, want, 1e-3, 0.02, 1e-2, what=f'fast {name} {nx}x{ny}x{spp}')
+
+
+def test_golden_fixture_film(fresh):
+    '''the committed oracle film (tests/golden/oracle_s34_24x24x4.npz) vs the strict build'''
+    from helpers import assert_parity
+    from ptina_amd.things import FilmTable
+    g = np.load(os.path.join(GOLD, 'oracle_s34_24x24x4.npz'))
+    eng = _engine(fresh, scenes.scene_s34(), 24, 24, mode='strict')
+    img = _bench_sequence(eng, FilmTable(), 4)
+    raw = FilmTable().get_raw()
+    assert np.all(raw[:, 3] == 4.0)
+    assert_parity(img, g['image'], 1e-4, 0.02, 2e-2, what='golden s34 24x24x4')
+
+
+def test_film_api_semantics(fresh):
+    from ptina_amd.things import FilmTable
+    eng = _engine(fresh, scenes.scene_s34(), 20, 12)
+    film = FilmTable()
+    assert (film.nx, film.ny) == (20, 12)
+    img = film.get_image()
+    assert img.shape == (20, 12, 4) and np.allclose(img, [0.9, 0.4, 0.9, 0.0])   # filmtable.py:60-61
+    eng.render()
+    eng.render()
+    raw = film.get_raw().reshape(20, 12, 4)
+    img = film.get_image()
+    assert np.all(raw[..., 3] == 2.0)
+    assert np.array_equal(img[..., :3], raw[..., :3] / raw[..., 3:4]) and np.all(img[..., 3] == 1)
+    flat = np.zeros(20 * 12 * 3, np.float32)
+    film.fast_export_image(flat)
+    assert np.array_equal(flat.reshape(12, 20, 3), np.swapaxes(img[..., :3], 0, 1))   # (y*nx + x)*3
+    film.clear(1)                             # clears every pass, filmtable.py:44-45
+    assert np.all(film.get_raw(0) == 0)
+
+
+@pytest.mark.parametrize('mode', ['strict', 'fast'])
+def test_batching_does_not_change_the_film(fresh, mode):
+    '''32 x render() fused into one launch == 32 single-frame launches (strict: bit for bit;
+    fast: bit for bit at equal chunking)'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    films = []
+    for batch in (1, 16):
+        reset_all()
+        eng = _engine(None, scenes.scene_s34(), 40, 24, mode=mode)
+        ctx().set_option('batch', batch)
+        ctx().set_option('chunk', 1)
+        for _ in range(16):
+            eng.render()
+        films.append(FilmTable().get_raw())
+    assert np.array_equal(films[0], films[1])
+    assert np.all(films[0][:, 3] == 16)
+
+
+def test_slabs_reassemble_bit_identically(fresh):
+    '''two column slabs rendered separately == the full film (what the multi-GPU path relies on)'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    nx, ny, spp = 50, 37, 4                   # ragged: not multiples of the 16x16 tile
+    eng = _engine(None, scenes.scene_s34(), nx, ny, mode='fast')
+    eng.render(spp)
+    full = FilmTable().get_raw().reshape(nx, ny, 4)
+    parts = np.zeros_like(full)
+    for x0, x1 in ((0, 23), (23, 50)):
+        reset_all()
+        eng = _engine(None, scenes.scene_s34(), nx, ny, mode='fast', slab=(x0, x1))
+        eng.render(spp)
+        got = FilmTable().get_raw().reshape(nx, ny, 4)
+        assert np.all(got[:x0] == 0) and np.all(got[x1:] == 0)
+        parts[x0:x1] = got[x0:x1]
+    reset_all()
+    assert np.array_equal(parts, full)
+    assert np.all(full[..., 3] == spp)
+
+
+def test_lights_and_area_light_parity(fresh, oracle_mod):
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.tools.matrix import translate
+    rot = np.eye(4)
+    rot[:3, :3] = [[1, 0, 0], [0, 0, 1], [0, -1, 0]]        # area light facing down (+z -> -y)
+    lights = [(translate([0, 3.9, 0]) @ rot, np.array([18.0, 16.0, 12.0]), 0.6, 'AREA'),
+              (translate([-1.2, 3.0, 1.0]), np.array([6.0, 6.0, 9.0]), 0.2, 'POINT')]
+    scene = scenes.scene_s34()
+    ref = setup_oracle(oracle_mod, scene, 64, 64, lights=lights, world=([0.3, 0.3, 0.4, 1.0], -1))
+    ref.render(16)
+    for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
+        from ptina_amd.common import reset_all
+        reset_all()
+        eng = _engine(None, scene, 64, 64, mode=mode, lights=lights, world=([0.3, 0.3, 0.4, 1.0], -1))
+        eng.render(16)
+        assert_parity(FilmTable().get_image(), ref.get_image(), tol, 0.02, 2e-2, what=f'lights {mode}')
+
+
+def test_textures_and_environment_parity(fresh, oracle_mod):
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
+    v, m, mats, _ = scenes.scene_s978()
+    rng = np.random.default_rng(5)
+    checker = np.ones((8, 8, 3), np.float32)
+    checker[::2, 1::2] = 0.2
+    checker[1::2, ::2] = 0.2
+    mats = [list(x) for x in mats]
+    mats[3][0] = ([1.0, 0.9, 0.8], 1)                      # basecolor textured by image 1
+    mats[3][2] = (0.9, 2)                                   # roughness textured by image 2 (grey)
+    images = [scenes.env_image(64, 32), checker, rng.uniform(0.3, 1.0, (5, 7)).astype(np.float32)]
+    scene = (v, m, mats, images)
+    world = ([1.0, 1.0, 1.0, 1.0], 0)
+    ref = setup_oracle(oracle_mod, scene, 64, 64, world=world)
+    ref.render(16)
+    for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
+        reset_all()
+        eng = _engine(None, scene, 64, 64, mode=mode, world=world)
+        eng.render(16)
+        assert_parity(FilmTable().get_image(), ref.get_image(), tol, 0.03, 3e-2, what=f'textures {mode}')
+
+
+def test_preview_aov_parity(fresh, oracle_mod):
+    from helpers import setup_oracle
+    from ptina_amd.things import FilmTable
+    from ptina_amd.engine.preview import PreviewEngine
+    scene = scenes.scene_s978()
+    ref = setup_oracle(oracle_mod, scene, 48, 48)
+    ref.render_preview()
+    ref.render_preview()
+    _engine(fresh, scene, 48, 48, mode='strict')
+    PreviewEngine().render()
+    PreviewEngine().render()
+    for p in (1, 2):
+        a, b = FilmTable().get_image(p), ref.get_image(p)
+        close = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(axis=-1)
+        assert close.mean() > 0.99, (p, close.mean())
+    assert np.all(FilmTable().get_raw(0) == 0)             # path pass untouched
+
+
+def test_edge_cases_empty_and_single_triangle(fresh, oracle_mod):
+    from helpers import setup_oracle
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
+    tri = np.zeros((3, 8), np.float32)
+    tri[:, :3] = [[-1, 0, 0], [1, 0, 0], [0, 2, 0]]
+    tri[:, 5] = 1
+    for verts, ids in ((np.zeros((0, 8), np.float32), np.zeros(0, np.int32)), (tri, np.array([-1], np.int32))):
+        scene = (verts, ids, [], [])
+        ref = setup_oracle(oracle_mod, scene, 32, 32)
+        ref.render(2)
+        for mode in ('strict', 'fast'):
+            reset_all()
+            eng = _engine(None, scene, 32, 32, mode=mode)
+            eng.render(2)
+            a, b = FilmTable().get_image(), ref.get_image()
+            # every ray misses (one face: the reference never writes the root box)
+            assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
+    reset_all()
+
+
+def test_errors_are_loud(fresh):
+    from ptina_amd.things import init_things, FilmTable, ModelPool, BVHTree
+    from ptina_amd.engine.path import PathEngine
+    init_things(max_filmsize=64 * 64)
+    eng = PathEngine()
+    with pytest.raises(RuntimeError, match='film size'):
+        eng.render()
+    with pytest.raises(RuntimeError, match='max_filmsize'):
+        FilmTable().set_size(128, 128)
+    FilmTable().set_size(32, 32)
+    with pytest.raises(RuntimeError, match='BVH not built'):
+        eng.render()
+    ModelPool().load(scenes.scene_s34()[0], scenes.scene_s34()[1])
+    with pytest.raises(RuntimeError, match='BVH not built'):
+        eng.render()
+    BVHTree().build()
+    eng.render()
+    assert np.all(FilmTable().get_raw()[:, 3] == 1)
+
+
+def test_full_size_properties_and_window_parity(fresh, oracle_mod):
+    '''BASELINE configs[1] at full size (512x512x32, S978): size-independent properties, run-to-run
+    bit reproducibility, fast-vs-strict agreement, and oracle parity on a window of columns'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
+    scene = scenes.scene_s978()
+    nx = ny = 512
+    spp = 32
+    imgs = {}
+    for key, mode in (('fast', 'fast'), ('fast2', 'fast'), ('strict', 'strict')):
+        reset_all()
+        eng = _engine(None, scene, nx, ny, mode=mode)
+        img = _bench_sequence(eng, FilmTable(), spp)
+        raw = FilmTable().get_raw()
+        assert np.all(raw[:, 3] == spp) and np.isfinite(raw).all() and raw[:, :3].min() >= 0
+        imgs[key] = img
+    reset_all()
+    assert np.array_equal(imgs['fast'], imgs['fast2']), 'render is not run-to-run deterministic'
+    assert_parity(imgs['fast'], imgs['strict'], 1e-3, 0.01, 5e-3, what='full-size fast vs strict')
+    x0, x1 = 250, 258
+    ref = setup_oracle(oracle_mod, scene, nx, ny)
+    ref.set_window(x0, x1)
+    ref.render(1)
+    ref.clear()
+    ref.render(spp)
+    want = ref.get_image()[x0:x1]
+    assert_parity(imgs['strict'][x0:x1], want, 1e-4, 0.01, 1e-2, what='full-size strict window')
+    assert_parity(imgs['fast'][x0:x1], want, 1e-3, 0.02, 1e-2, what='full-size fast window')

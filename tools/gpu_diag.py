@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+'''GPU-box diagnostics: parity statistics (strict / fast vs oracle) and a timing sweep.
+Writes gpurun_out/diag.json.  Not part of the product or the tests.'''
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np  # noqa: E402
+import oracle  # noqa: E402
+from ptina_amd import scenes, common, _lib  # noqa: E402
+from ptina_amd.common import ctx  # noqa: E402
+from ptina_amd.things import FilmTable  # noqa: E402
+from helpers import setup_engine, setup_oracle, image_stats  # noqa: E402
+
+out = {}
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+
+
+def save():
+    with open(os.path.join(ROOT, 'gpurun_out', 'diag.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+
+
+def parity(name, nx, ny, spp):
+    scene = scenes.get_scene(name)
+    ref = setup_oracle(oracle, scene, nx, ny)
+    t0 = time.time()
+    ref.render(spp)
+    tor = time.time() - t0
+    want = ref.get_image()
+    res = {'oracle_s': tor, 'oracle_counters': ref.counters()}
+    for mode in ('strict', 'fast'):
+        common.reset_all()
+        eng = setup_engine(scene, nx, ny, mode=mode)
+        ctx().set_option('count', 1)
+        eng.render(spp)
+        img = FilmTable().get_image()
+        d, refn, rel = image_stats(img, want)
+        res[mode] = {'rel_rmse': rel, 'exact_frac': float((d == 0).mean()),
+                     'frac_gt_1e-5': float((d > 1e-5 * (1 + refn)).mean()),
+                     'frac_gt_1e-4': float((d > 1e-4 * (1 + refn)).mean()),
+                     'frac_gt_1e-3': float((d > 1e-3 * (1 + refn)).mean()),
+                     'frac_gt_1e-2': float((d > 1e-2 * (1 + refn)).mean()),
+                     'max': float(d.max()), 'mean_img': float(img[..., :3].mean()),
+                     'mean_ref': float(want[..., :3].mean()), 'counters': ctx().counters()}
+    common.reset_all()
+    return res
+
+
+def timing(name, mode, chunk, steps=5, spp=32, n=512):
+    common.reset_all()
+    eng = setup_engine(scenes.get_scene(name), n, n, mode=mode)
+    c = ctx()
+    c.set_option('batch', spp)
+    c.set_option('chunk', chunk)
+    eng.render(spp)
+    c.call('mpt_synchronize')
+    c.kernel_time()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.render(spp)
+        c.call('mpt_resolve', 0)
+    c.call('mpt_synchronize')
+    dt = time.perf_counter() - t0
+    kms, nl = c.kernel_time()
+    common.reset_all()
+    return {'wall_ms_per_step': dt / steps * 1e3, 'kernel_ms': kms / nl, 'msamples_s': n * n * spp * steps / dt / 1e6}
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['parity', 'timing']
+    if 'parity' in what:
+        for name, nx, ny, spp in (('s34', 64, 64, 8), ('s978', 96, 96, 8), ('s978', 128, 128, 32)):
+            out[f'parity_{name}_{nx}x{ny}x{spp}'] = parity(name, nx, ny, spp)
+            print(name, nx, ny, spp, json.dumps(out[f'parity_{name}_{nx}x{ny}x{spp}'])[:600], flush=True)
+            save()
+    if 'timing' in what:
+        for name in ('s978', 's34'):
+            for mode, chunks in (('fast', (0, 1, 2, 4, 8, 16, 32)), ('strict', (32,))):
+                for ch in chunks:
+                    r = timing(name, mode, ch)
+                    out[f'timing_{name}_{mode}_chunk{ch}'] = r
+                    print(name, mode, ch, r, flush=True)
+                    save()
+    save()

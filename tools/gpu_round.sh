@@ -1,0 +1,32 @@
+#!/bin/bash
+# Runs a sequence of GPU steps on the gpurun box, each under its own timeout; a step that fails
+# an assertion does not stop the sequence, a step that TIMES OUT does (no GPU work after a hang).
+# usage: tools/gpu_round.sh step1 step2 ...   (steps: diag diag_parity diag_timing tests bench prof smoke)
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+run() {  # name seconds command...
+  local name=$1 secs=$2; shift 2
+  echo "=== $name ===" | tee -a gpurun_out/round.log
+  timeout -k 10 "$secs" "$@" > "gpurun_out/$name.log" 2>&1
+  local rc=$?
+  echo "$name rc=$rc" | tee -a gpurun_out/round.log
+  tail -n 25 "gpurun_out/$name.log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a gpurun_out/round.log; exit 1; fi
+}
+: > gpurun_out/round.log
+for step in "$@"; do
+  case $step in
+    smoke)       run smoke 300 python __graft_entry__.py smoke ;;
+    diag)        run diag 600 python tools/gpu_diag.py parity timing ;;
+    diag_parity) run diag_parity 400 python tools/gpu_diag.py parity ;;
+    diag_timing) run diag_timing 400 python tools/gpu_diag.py timing ;;
+    tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
+    tests_all)   run tests_all 900 python -m pytest tests -m gpu -q ;;
+    bench)       run bench 600 python bench.py ;;
+    prof)        (cd /tmp; run_dir=$GRAFT_REPO_ROOT/gpurun_out/prof; rm -rf $run_dir; mkdir -p $run_dir;
+                  cd $GRAFT_REPO_ROOT;
+                  run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline) ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
+exit 0
