@@ -68,7 +68,9 @@ mpt_ctx *mpt_create(const mpt_caps *caps, int device);
 void mpt_destroy(mpt_ctx *ctx);
 
 /* "mode" (MPT_MODE_*), "batch" (max frames per launch, 1..64), "chunk" (frames per work item,
- * 0 = auto), "count" (1 = accumulate mpt_counters, slower) */
+ * 0 = auto), "count" (1 = accumulate mpt_counters, slower), "lds" (1 = use the LDS-resident
+ * persistent kernel when the scene fits a CU's 160 KiB LDS, default; 0 = always gather from HBM/L2).
+ * read-only: "tree_depth", "pending", "last_kernel" (1 = LDS-resident), "num_cus" */
 int mpt_set_option(mpt_ctx *ctx, const char *key, int value);
 int mpt_get_option(mpt_ctx *ctx, const char *key, int *value);
 

@@ -22,6 +22,7 @@
 // kernel launchers (render_kernel.hip x2, aux_kernels.hip)
 extern "C" hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
 extern "C" hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
+extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, size_t lds_bytes, int count, hipStream_t);
 extern "C" hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
 extern "C" hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
 extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
@@ -113,7 +114,9 @@ struct mpt_ctx {
     mpt_caps caps{};
 
     // options
-    int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0;
+    int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1;
+    int num_cus = 256;
+    int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
 
     // film
     int nx = 0, ny = 0, x0 = 0, x1 = 0;
@@ -158,6 +161,7 @@ struct mpt_ctx {
 
     // measurement
     unsigned long long *d_counters = nullptr;
+    unsigned int *d_work = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
 
@@ -225,6 +229,12 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (dev_alloc(&c->lights, MPT_MAX_LIGHTS)) return bail("lights");
     if (dev_alloc(&c->d_counters, 8)) return bail("counters");
     if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
+    if (dev_alloc(&c->d_work, 4)) return bail("work counter");
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            c->num_cus = prop.multiProcessorCount;
+    }
     hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream);
     {   // unset materials: factor 0 (field-zero, mtllib.py:12-13), texture -1 (deviation Q6)
         std::vector<MptMaterial> z(c->caps.max_materials);
@@ -250,7 +260,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade);
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
-    hipFree(c->d_counters); hipFree(c->d_scratch);
+    hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -271,6 +281,8 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->chunk = value;
     } else if (k == "count") {
         c->count = value ? 1 : 0;
+    } else if (k == "lds") {
+        c->use_lds = value ? 1 : 0;
     } else {
         return fail("unknown option '%s'", k.c_str());
     }
@@ -286,6 +298,9 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "count") *value = c->count;
     else if (k == "tree_depth") *value = c->tree_depth;
     else if (k == "pending") *value = c->pending;
+    else if (k == "lds") *value = c->use_lds;
+    else if (k == "last_kernel") *value = c->last_kernel;
+    else if (k == "num_cus") *value = c->num_cus;
     else return fail("unknown option '%s'", k.c_str());
     return 0;
 }
@@ -757,20 +772,35 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     if (sobol_advance(c, B, B)) return 1;
 
     const int stack = (c->tree_depth + 2 <= 32) ? 32 : 64;
+    // LDS-resident kernel: node + triangle records + a 16-bit stack of (depth-1) levels x 1024
+    // lanes must fit the CU's 160 KiB; ids must fit int16
+    const int lds_stack = std::max(c->tree_depth - 1, 1);
+    const size_t lds_bytes = ((size_t)(c->nfaces - 1) * 4 + (size_t)c->nfaces * 4) * sizeof(MptVec4) +
+                             (size_t)lds_stack * 1024 * sizeof(short);
+    const bool lds_kernel = c->mode == MPT_MODE_FAST && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 &&
+                            lds_bytes <= 160 * 1024;
     int chunk = B, nchunks = 1;
     if (c->mode == MPT_MODE_FAST) {
         chunk = c->chunk;
         if (chunk <= 0) {
-            // aim for >= ~6000 work items so the dispatcher can balance them over 256 CUs
-            int want = (6144 + p.ntiles - 1) / p.ntiles;
+            int items_per_chunk, want_items;
+            if (lds_kernel) {   // 8x8 tiles pulled by 16 waves x CUs persistent waves: ~4 items per wave
+                items_per_chunk = ((c->x1 - c->x0 + 7) / 8) * ((c->ny + 7) / 8);
+                want_items = 4 * 16 * c->num_cus;
+            } else {            // 16x16 tiles dispatched as workgroups: thousands of blocks to balance
+                items_per_chunk = p.ntiles;
+                want_items = 6144;
+            }
+            int want = (want_items + items_per_chunk - 1) / items_per_chunk;
             want = std::max(1, std::min(want, B));
             chunk = (B + want - 1) / want;
-            chunk = std::max(chunk, std::min(B, 4));
         }
         chunk = std::min(chunk, B);
         nchunks = (B + chunk - 1) / chunk;
     }
     p.chunk = chunk; p.nchunks = nchunks;
+    p.lds_stack = lds_stack;
+    p.work_counter = c->d_work;
     if (nchunks > 1) {
         size_t need = (size_t)nchunks * c->nx * c->ny;
         if (need > c->partial_cap) {
@@ -781,11 +811,14 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         }
         p.partial = c->partial;
     }
+    if (lds_kernel) HIP_TRY(hipMemsetAsync(c->d_work, 0, sizeof(unsigned int), c->stream));
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(hipEventRecord(e0, c->stream));
     int grid = p.ntiles * nchunks;
     if (c->mode == MPT_MODE_STRICT) HIP_TRY(mpt_launch_render_strict(&p, grid, stack, c->count, c->stream));
+    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, c->num_cus, lds_bytes, c->count, c->stream));
     else HIP_TRY(mpt_launch_render_fast(&p, grid, stack, c->count, c->stream));
+    c->last_kernel = lds_kernel ? 1 : 0;
     HIP_TRY(hipEventRecord(e1, c->stream));
     c->events.push_back({ e0, e1 });
     if (nchunks > 1) HIP_TRY(mpt_launch_combine(c->film[0], c->partial, c->nx, c->ny, c->x0, c->x1, nchunks, c->stream));

@@ -45,7 +45,7 @@ struct MptRenderParams {
     int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders
     int32_t nframes, chunk, nchunks, n;     // batch frames; frames per work item; items per tile; #triangles
     int32_t sobol_dim, nlights, world_tex, tiles_x;
-    int32_t tiles_y, ntiles, pad0, pad1;
+    int32_t tiles_y, ntiles, lds_stack, pad1;  // lds_stack: 16-bit stack levels of the LDS-resident kernel
     float world_fac[4];
     float v2w[16];
     const MptVec4 *snode;
@@ -62,4 +62,5 @@ struct MptRenderParams {
     MptVec4 *film2;                          // pass 2 (normal)
     MptVec4 *partial;                        // [nchunks][nx*ny] when nchunks > 1
     unsigned long long *counters;            // mpt_counters when counting, else unused
+    unsigned int *work_counter;              // persistent (LDS-resident) kernel: next work item
 };

@@ -130,9 +130,7 @@ struct Hit { int hit; float depth; int index; float u, v; };
 DEV V3 ld3(const MptVec4 &a) { return v3(a.x, a.y, a.z); }
 
 // Face.intersect, geometries.py:118-148, with the ray-independent terms hoisted into tgeo
-DEV bool tri_test(const MptVec4 *__restrict__ tgeo, int slot, V3 ro, V3 rd, float *depth, float *s_, float *t_) {
-    const MptVec4 *g = tgeo + (size_t)slot * 4;
-    MptVec4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+DEV bool tri_test(MptVec4 g0, MptVec4 g1, MptVec4 g2, MptVec4 g3, V3 ro, V3 rd, float *depth, float *s_, float *t_) {
     V3 v0 = ld3(g0), u = ld3(g1), v = ld3(g2), norm = ld3(g3);
     float D = g0.w, uu = g1.w, uv = g2.w, vv = g3.w;
     float b = dot(norm, rd);
@@ -188,6 +186,48 @@ struct Stack {
     DEV int pop() { sp--; return base[sp * MPT_BLOCK]; }
 };
 
+// scene records served from HBM/L2 through the vector L1 (any scene size)
+struct GlobalScene {
+    const MptVec4 *fnode, *tgeo;
+    DEV void node(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &d) const {
+        const MptVec4 *nd = fnode + (size_t)i * 4;
+        a = nd[0]; b = nd[1]; c = nd[2]; d = nd[3];
+    }
+    DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2, MptVec4 &g3) const {
+        const MptVec4 *g = tgeo + (size_t)slot * 4;
+        g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3];
+    }
+};
+
+// scene records resident in the CU's LDS (small scenes): ds_read_b128 instead of divergent
+// global gathers -- one copy per CU, shared by the 16 waves of a 1024-lane workgroup
+typedef float mpt_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const mpt_f4 *LdsVec4Ptr;
+typedef __attribute__((address_space(3))) short *LdsShortPtr;
+
+DEV MptVec4 lds_ld(LdsVec4Ptr q) { mpt_f4 v = *q; MptVec4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+
+struct LdsScene {
+    LdsVec4Ptr fnode, tgeo;
+    DEV void node(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &d) const {
+        LdsVec4Ptr nd = fnode + i * 4;
+        a = lds_ld(nd); b = lds_ld(nd + 1); c = lds_ld(nd + 2); d = lds_ld(nd + 3);
+    }
+    DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2, MptVec4 &g3) const {
+        LdsVec4Ptr g = tgeo + slot * 4;
+        g0 = lds_ld(g); g1 = lds_ld(g + 1); g2 = lds_ld(g + 2); g3 = lds_ld(g + 3);
+    }
+};
+
+// 16-bit LIFO for the LDS-resident kernel (node ids fit in int16 there), [level][lane of 1024]
+#define MPT_LDS_BLOCK 1024
+struct Stack16 {
+    LdsShortPtr base;          // &lds16[threadIdx.x]
+    int sp;
+    DEV void push(int v) { base[sp * MPT_LDS_BLOCK] = (short)v; sp++; }
+    DEV int pop() { sp--; return (int)base[sp * MPT_LDS_BLOCK]; }
+};
+
 #if MPT_STRICT
 // LinearBVH.intersect, tree/lbvh.py:314-347, operation for operation.  `avoid`/index are leaf slots.
 template <bool COUNT>
@@ -204,7 +244,8 @@ DEV Hit bvh_closest(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid,
             if (curr != avoid) {
                 if (COUNT) cnt.n_tri++;
                 float d, s, t;
-                if (tri_test(p.tgeo, curr, ro, rd, &d, &s, &t) && d < ret.depth) {
+                const MptVec4 *g = p.tgeo + (size_t)curr * 4;
+                if (tri_test(g[0], g[1], g[2], g[3], ro, rd, &d, &s, &t) && d < ret.depth) {
                     ret.depth = d; ret.index = curr; ret.u = s; ret.v = t; ret.hit = 1;
                 }
             }
@@ -246,18 +287,18 @@ DEV bool box_fast(float lox, float loy, float loz, float hix, float hiy, float h
 // before the best depth is tested); the order differs: near child first, far child pushed,
 // subtrees beyond the best depth skipped.  ANY = stop at the first hit with depth <= tmax
 // (path.py:51: occluded iff the closest hit is within li.dis).
-template <bool ANY, bool COUNT>
-DEV Hit bvh_walk(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, float tmax, Cnt &cnt) {
+template <bool ANY, bool COUNT, class SCENE, class STACK>
+DEV Hit bvh_walk(const SCENE &sc, int n, STACK st, V3 ro, V3 rd, int avoid, float tmax, Cnt &cnt) {
     Hit ret; ret.hit = 0; ret.depth = tmax; ret.index = -1; ret.u = 0.0f; ret.v = 0.0f;
     if (COUNT) cnt.rays++;
-    if (p.n < 2) return ret;   // lbvh.py:218,319: with one face the root box is never written
+    if (n < 2) return ret;     // lbvh.py:218,319: with one face the root box is never written
     V3 inv = v3(m_rcp(rd.x), m_rcp(rd.y), m_rcp(rd.z));
     V3 oinv = ro * inv;
-    Stack st; st.base = lds; st.sp = 0;
+    st.sp = 0;
     int curr = 0;
     for (;;) {
-        const MptVec4 *nd = p.fnode + (size_t)curr * 4;
-        MptVec4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+        MptVec4 a, b, c, d;
+        sc.node(curr, a, b, c, d);
         int id0 = __float_as_int(d.x), id1 = __float_as_int(d.y);
         if (COUNT) { cnt.n_node++; cnt.n_box += 2; }
         float tn0, tn1;
@@ -269,7 +310,9 @@ DEV Hit bvh_walk(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, fl
             if (slot != avoid) {
                 if (COUNT) cnt.n_tri++;
                 float dd, s, t;
-                if (tri_test(p.tgeo, slot, ro, rd, &dd, &s, &t) && (ANY ? dd <= ret.depth : dd < ret.depth)) {
+                MptVec4 g0, g1, g2, g3;
+                sc.tri(slot, g0, g1, g2, g3);
+                if (tri_test(g0, g1, g2, g3, ro, rd, &dd, &s, &t) && (ANY ? dd <= ret.depth : dd < ret.depth)) {
                     ret.depth = dd; ret.index = slot; ret.u = s; ret.v = t; ret.hit = 1;
                     if (ANY) return ret;
                 }
@@ -281,7 +324,9 @@ DEV Hit bvh_walk(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, fl
             if (slot != avoid) {
                 if (COUNT) cnt.n_tri++;
                 float dd, s, t;
-                if (tri_test(p.tgeo, slot, ro, rd, &dd, &s, &t) && (ANY ? dd <= ret.depth : dd < ret.depth)) {
+                MptVec4 g0, g1, g2, g3;
+                sc.tri(slot, g0, g1, g2, g3);
+                if (tri_test(g0, g1, g2, g3, ro, rd, &dd, &s, &t) && (ANY ? dd <= ret.depth : dd < ret.depth)) {
                     ret.depth = dd; ret.index = slot; ret.u = s; ret.v = t; ret.hit = 1;
                     if (ANY) return ret;
                 }
@@ -303,17 +348,23 @@ DEV Hit bvh_walk(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, fl
     return ret;
 }
 
-template <bool COUNT>
-DEV Hit bvh_closest(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, Cnt &cnt) {
-    Hit h = bvh_walk<false, COUNT>(p, lds, ro, rd, avoid, MPT_INF, cnt);
-    if (!h.hit) h.depth = MPT_INF;
-    return h;
-}
-
-template <bool COUNT>
-DEV bool bvh_occluded(const MptRenderParams &p, int *lds, V3 ro, V3 rd, int avoid, float dis, Cnt &cnt) {
-    return bvh_walk<true, COUNT>(p, lds, ro, rd, avoid, dis, cnt).hit != 0;
-}
+// what a traversal needs besides the ray: where the scene records and this lane's stack live
+template <class SCENE, class STACK>
+struct Tracer {
+    SCENE sc;
+    STACK st;
+    int n;
+    template <bool COUNT>
+    DEV Hit closest(V3 ro, V3 rd, int avoid, Cnt &cnt) const {
+        Hit h = bvh_walk<false, COUNT>(sc, n, st, ro, rd, avoid, MPT_INF, cnt);
+        if (!h.hit) h.depth = MPT_INF;
+        return h;
+    }
+    template <bool COUNT>
+    DEV bool occluded(V3 ro, V3 rd, int avoid, float dis, Cnt &cnt) const {
+        return bvh_walk<true, COUNT>(sc, n, st, ro, rd, avoid, dis, cnt).hit != 0;
+    }
+};
 #endif
 
 DEV float sphere_intersect(V3 pos, float rad2, V3 ro, V3 rd) {               // geometries.py:159-177

@@ -52,12 +52,13 @@ def parity(name, nx, ny, spp):
     return res
 
 
-def timing(name, mode, chunk, steps=5, spp=32, n=512):
+def timing(name, mode, chunk, steps=5, spp=32, n=512, lds=1):
     common.reset_all()
     eng = setup_engine(scenes.get_scene(name), n, n, mode=mode)
     c = ctx()
     c.set_option('batch', spp)
     c.set_option('chunk', chunk)
+    c.set_option('lds', lds)
     eng.render(spp)
     c.call('mpt_synchronize')
     c.kernel_time()
@@ -68,8 +69,10 @@ def timing(name, mode, chunk, steps=5, spp=32, n=512):
     c.call('mpt_synchronize')
     dt = time.perf_counter() - t0
     kms, nl = c.kernel_time()
+    lk = c.get_option('last_kernel')
     common.reset_all()
-    return {'wall_ms_per_step': dt / steps * 1e3, 'kernel_ms': kms / nl, 'msamples_s': n * n * spp * steps / dt / 1e6}
+    return {'wall_ms_per_step': dt / steps * 1e3, 'kernel_ms': kms / nl, 'msamples_s': n * n * spp * steps / dt / 1e6,
+            'lds_kernel': lk}
 
 
 if __name__ == '__main__':
@@ -81,10 +84,14 @@ if __name__ == '__main__':
             save()
     if 'timing' in what:
         for name in ('s978', 's34'):
-            for mode, chunks in (('fast', (0, 1, 2, 4, 8, 16, 32)), ('strict', (32,))):
-                for ch in chunks:
-                    r = timing(name, mode, ch)
-                    out[f'timing_{name}_{mode}_chunk{ch}'] = r
-                    print(name, mode, ch, r, flush=True)
+            for lds in (1, 0):
+                for ch in (0, 1, 2, 4, 8, 16, 32):
+                    r = timing(name, 'fast', ch, lds=lds)
+                    out[f'timing_{name}_fast_lds{lds}_chunk{ch}'] = r
+                    print(name, 'fast lds', lds, 'chunk', ch, r, flush=True)
                     save()
+            r = timing(name, 'strict', 32)
+            out[f'timing_{name}_strict'] = r
+            print(name, 'strict', r, flush=True)
+            save()
     save()

@@ -19,13 +19,18 @@ for step in "$@"; do
     smoke)       run smoke 300 python __graft_entry__.py smoke ;;
     diag)        run diag 600 python tools/gpu_diag.py parity timing ;;
     diag_parity) run diag_parity 400 python tools/gpu_diag.py parity ;;
-    diag_timing) run diag_timing 400 python tools/gpu_diag.py timing ;;
+    diag_timing) run diag_timing 500 python tools/gpu_diag.py timing ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
     tests_all)   run tests_all 900 python -m pytest tests -m gpu -q ;;
     bench)       run bench 600 python bench.py ;;
     prof)        (cd /tmp; run_dir=$GRAFT_REPO_ROOT/gpurun_out/prof; rm -rf $run_dir; mkdir -p $run_dir;
                   cd $GRAFT_REPO_ROOT;
                   run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline) ;;
+    counters)    rocprofv3 -L > gpurun_out/counters_list.txt 2>&1; echo "counters listed" ;;
+    pmc1)        run pmc1 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
+    pmc2)        run pmc2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
+    pmc3)        run pmc3 400 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
+    pmc4)        run pmc4 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc4 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     *) echo "unknown step $step" ;;
   esac
 done
