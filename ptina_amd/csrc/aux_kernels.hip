@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void sobol_update_kernel(int *__restrict__ X, 
     X[j] = x;
 }
 
-// film[pix] += partial[0][pix] + partial[1][pix] + ... in chunk order (deterministic)
+// film[pix] += sample[0][pix], then sample[1][pix], ... : the reference's frame-by-frame
+// accumulation order (filmtable.py:37-39, path.py:93), one sample slab per frame of the batch
 __global__ __launch_bounds__(256) void combine_kernel(MptVec4 *__restrict__ film, const MptVec4 *__restrict__ partial,
                                                       int nx, int ny, int x0, int x1, int nchunks) {
     size_t npix = (size_t)nx * ny;

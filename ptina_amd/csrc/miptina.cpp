@@ -116,6 +116,7 @@ struct mpt_ctx {
     // options
     int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1;
     int num_cus = 256;
+    int sched_num = 2, sched_den = 1;    // scheduler: stay in traversal mode while traversing*num >= waiting*den (tuned on MI355X)
     int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
 
     // film
@@ -283,6 +284,12 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->count = value ? 1 : 0;
     } else if (k == "lds") {
         c->use_lds = value ? 1 : 0;
+    } else if (k == "sched_num") {
+        if (value < 1) return fail("sched_num must be >= 1");
+        c->sched_num = value;
+    } else if (k == "sched_den") {
+        if (value < 0) return fail("sched_den must be >= 0");
+        c->sched_den = value;
     } else {
         return fail("unknown option '%s'", k.c_str());
     }
@@ -774,7 +781,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     const int stack = (c->tree_depth + 2 <= 32) ? 32 : 64;
     // LDS-resident kernel: node + triangle records + a 16-bit stack of (depth-1) levels x 1024
     // lanes must fit the CU's 160 KiB; ids must fit int16
-    const int lds_stack = std::max(c->tree_depth - 1, 1);
+    const int lds_stack = std::max(c->tree_depth, 1);   // one pending sibling (node or leaf) per level
     const size_t lds_bytes = ((size_t)(c->nfaces - 1) * 4 + (size_t)c->nfaces * 4) * sizeof(MptVec4) +
                              (size_t)lds_stack * 1024 * sizeof(short);
     const bool lds_kernel = c->mode == MPT_MODE_FAST && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 &&
@@ -799,10 +806,11 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         nchunks = (B + chunk - 1) / chunk;
     }
     p.chunk = chunk; p.nchunks = nchunks;
-    p.lds_stack = lds_stack;
+    p.sched_num = c->sched_num; p.sched_den = c->sched_den;
     p.work_counter = c->d_work;
-    if (nchunks > 1) {
-        size_t need = (size_t)nchunks * c->nx * c->ny;
+    if (c->mode == MPT_MODE_FAST) {
+        // one float4 per sample: [frame][pixel]; the combine pass sums frames in order
+        size_t need = (size_t)B * c->nx * c->ny;
         if (need > c->partial_cap) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             hipFree(c->partial); c->partial = nullptr;
@@ -821,7 +829,8 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     c->last_kernel = lds_kernel ? 1 : 0;
     HIP_TRY(hipEventRecord(e1, c->stream));
     c->events.push_back({ e0, e1 });
-    if (nchunks > 1) HIP_TRY(mpt_launch_combine(c->film[0], c->partial, c->nx, c->ny, c->x0, c->x1, nchunks, c->stream));
+    if (c->mode == MPT_MODE_FAST)
+        HIP_TRY(mpt_launch_combine(c->film[0], c->partial, c->nx, c->ny, c->x0, c->x1, B, c->stream));
     return 0;
 }
 

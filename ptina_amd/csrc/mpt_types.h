@@ -45,7 +45,7 @@ struct MptRenderParams {
     int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders
     int32_t nframes, chunk, nchunks, n;     // batch frames; frames per work item; items per tile; #triangles
     int32_t sobol_dim, nlights, world_tex, tiles_x;
-    int32_t tiles_y, ntiles, lds_stack, pad1;  // lds_stack: 16-bit stack levels of the LDS-resident kernel
+    int32_t tiles_y, ntiles, sched_num, sched_den;  // leave traversal mode when traversing*num < waiting*den
     float world_fac[4];
     float v2w[16];
     const MptVec4 *snode;
@@ -60,7 +60,7 @@ struct MptRenderParams {
     MptVec4 *film0;                          // pass 0 (path) / unused by preview
     MptVec4 *film1;                          // pass 1 (albedo)
     MptVec4 *film2;                          // pass 2 (normal)
-    MptVec4 *partial;                        // [nchunks][nx*ny] when nchunks > 1
+    MptVec4 *partial;                        // fast build: per-sample radiance [nframes][nx*ny]
     unsigned long long *counters;            // mpt_counters when counting, else unused
     unsigned int *work_counter;              // persistent (LDS-resident) kernel: next work item
 };

@@ -5,14 +5,14 @@
 // MPT_STRICT=0 -> mpt_launch_*_fast (see pt_device.h).
 //
 // Common to every kernel here (gfx950, wave64):
-//   * a lane owns ONE pixel and walks a chunk of consecutive frames (spp) in order, regenerating
-//     a new camera path the moment the previous one ends (no lane idles while its neighbours
-//     finish a 5-bounce path); the per-pixel sum is kept in registers in frame order;
-//   * a wave owns an 8x8 pixel tile so primary rays are coherent; within a row of 8 lanes
-//     consecutive lanes are consecutive y = consecutive film addresses (index x*ny + y);
-//   * chunk partial sums go to a scratch slab and a deterministic combine adds them in chunk
-//     order (no float atomics: results are bit-reproducible and identical for any slab split
-//     across GPUs).
+//   * a wave owns an 8x8 pixel tile x a chunk of consecutive frames (spp) = a pool of samples;
+//     lanes are NOT tied to pixels: idle lanes are compacted with ballot + mbcnt and handed the
+//     next samples of the pool the moment their path ends (trace_pool), so no lane idles while
+//     its neighbours finish a 5-bounce path;
+//   * every sample's radiance is stored to a [frame][pixel] slab and a combine pass adds the
+//     frames to the film in frame order: the reference's summation order, no float atomics,
+//     bit-reproducible and identical for any slab split across GPUs;
+//   * (strict build only) a lane owns one pixel and sums its frames in a register, in order.
 //
 // render_kernel (any scene size): scene records are gathered from HBM/L2; one 256-lane
 //   workgroup = a 16x16 tile x one chunk; grid = tiles x chunks so the hardware dispatcher
@@ -81,95 +81,357 @@ DEV void flush_counters(const MptRenderParams &p, const Cnt &c) {
     }
 }
 
-// One pixel, frames [f, fend): do_render + path_trace (path.py:18-93) with path regeneration.
+// ---------------------------------------------------------------- one path = do_render + path_trace (path.py:18-93)
+struct PathState {
+    Rng rng;
+    V3 ro, rd, result, throughput;
+    float last_brdf_pdf;
+    int avoid, depth;
+};
+
+// do_render up to the camera ray, path.py:82-90, for pixel (i, j) and batch frame f
+template <bool COUNT>
+DEV void path_begin(const MptRenderParams &p, PathState &s, int i, int j, int f, Cnt &cnt) {
+    s.rng.dim = p.sobol_dim;
+    s.rng.P = p.P + (size_t)f * p.sobol_dim;
+    s.rng.i = wanghash2(i, j);                                               // path.py:72-73
+    float dx = rng_random(s.rng), dy = rng_random(s.rng);
+    float x = m_div((float)i + dx, (float)p.nx) * 2.0f - 1.0f;
+    float y = m_div((float)j + dy, (float)p.ny) * 2.0f - 1.0f;
+    camera_generate(p, x, y, &s.ro, &s.rd);
+    s.avoid = -1; s.depth = 0;
+    s.result = v3s(0.0f); s.throughput = v3s(1.0f); s.last_brdf_pdf = 0.0f;
+    if (COUNT) { cnt.samples++; cnt.n_draws += 2; }
+}
+
+// one iteration of the path_trace loop, path.py:25-62; returns true when the path has ended
 template <bool COUNT, class TR>
-DEV void trace_pixel(const MptRenderParams &p, const TR &tr, int i, int j, int f, int fend, int chunk_id, Cnt &cnt) {
-    const int pix = i * p.ny + j;
-    const int h = wanghash2(i, j);                                           // path.py:72-73
+DEV bool path_step(const MptRenderParams &p, const TR &tr, PathState &s, Cnt &cnt) {
+    if (!(s.depth < 5 && any_gt0(s.throughput) && any_ne0(s.rd))) return true;   // loop head, path.py:25
+    s.depth += 1;
+    if (COUNT) cnt.bounces++;
 
-    MptVec4 acc;
-    if (p.nchunks == 1) acc = p.film0[pix];                                  // film += in frame order, filmtable.py:37-39
-    else { acc.x = acc.y = acc.z = acc.w = 0.0f; }
+    s.rd = normalized(s.rd);
+    Hit hit = tr.template closest<COUNT>(s.ro, s.rd, s.avoid, cnt);
 
-    bool alive = false;
-    Rng rng; rng.dim = p.sobol_dim; rng.P = p.P; rng.i = h;
-    V3 ro = v3s(0.0f), rd = v3s(0.0f), result = v3s(0.0f), throughput = v3s(0.0f);
-    float last_brdf_pdf = 0.0f;
-    int avoid = -1, depth = 0;
+    LightHit lit = lights_hit(p, s.ro, s.rd);
+    if (lit.hit && (hit.hit == 0 || lit.dis < hit.depth)) {
+        float mis = power_heuristic(s.last_brdf_pdf, lit.pdf);
+        s.result = s.result + s.throughput * (lit.color * mis);
+    }
 
-    while (true) {
-        if (!alive) {
-            if (f >= fend) break;
-            // do_render, path.py:86-92
-            rng.P = p.P + (size_t)f * p.sobol_dim;
-            rng.i = h;
-            float dx = rng_random(rng), dy = rng_random(rng);
-            float x = m_div((float)i + dx, (float)p.nx) * 2.0f - 1.0f;
-            float y = m_div((float)j + dy, (float)p.ny) * 2.0f - 1.0f;
-            camera_generate(p, x, y, &ro, &rd);
-            avoid = -1; depth = 0;
-            result = v3s(0.0f); throughput = v3s(1.0f); last_brdf_pdf = 0.0f;
-            alive = true;
-            if (COUNT) { cnt.samples++; cnt.n_draws += 2; }
-        }
+    if (hit.hit == 0) {
+        s.result = s.result + s.throughput * world_at(p, s.rd);
+        return true;                                                         // break, path.py:39
+    }
+    s.avoid = hit.index;
+    V3 hitpos, normal; Disney material;
+    get_geometries(p, hit, s.ro, s.rd, &hitpos, &normal, material);
+    if (COUNT) { cnt.n_shade++; cnt.n_draws += 6; }
 
-        bool done = true;
-        // path_trace loop head, path.py:25
-        if (depth < 5 && any_gt0(throughput) && any_ne0(rd)) {
-            done = false;
-            depth += 1;
-            if (COUNT) cnt.bounces++;
+    float sign = -dot(s.rd, normal);                                         // path.py:44-46 (never negative)
+    if (sign < 0.0f) normal = -normal;
 
-            rd = normalized(rd);
-            Hit hit = tr.template closest<COUNT>(ro, rd, avoid, cnt);
-
-            LightHit lit = lights_hit(p, ro, rd);
-            if (lit.hit && (hit.hit == 0 || lit.dis < hit.depth)) {
-                float mis = power_heuristic(last_brdf_pdf, lit.pdf);
-                result = result + throughput * (lit.color * mis);
-            }
-
-            if (hit.hit == 0) {
-                result = result + throughput * world_at(p, rd);
-                done = true;                                                 // break, path.py:39
-            } else {
-                avoid = hit.index;
-                V3 hitpos, normal; Disney material;
-                get_geometries(p, hit, ro, rd, &hitpos, &normal, material);
-                if (COUNT) { cnt.n_shade++; cnt.n_draws += 6; }
-
-                float sign = -dot(rd, normal);                               // path.py:44-46 (never negative)
-                if (sign < 0.0f) normal = -normal;
-
-                LightSample li = lights_sample(p, hitpos, random3(rng));
-                if (any_gt0(li.color)) {
-                    if (!tr.template occluded<COUNT>(hitpos, li.dir, avoid, li.dis, cnt)) {
-                        V3 brdf_clr = disney_brdf(material, normal, sign, -rd, li.dir);
-                        float brdf_pdf = vavg(brdf_clr);
-                        float mis = power_heuristic(li.pdf, brdf_pdf);
-                        V3 direct_li = li.color * mis * brdf_clr * dot_or_zero(normal, li.dir);
-                        result = result + throughput * direct_li;
-                    }
-                }
-
-                BsdfSample brdf = disney_bounce(material, normal, sign, -rd, random3(rng));
-                throughput = throughput * brdf.color;
-                ro = hitpos;
-                rd = brdf.outdir;
-                last_brdf_pdf = brdf.pdf;
-            }
-        }
-
-        if (done) {
-            acc.x += result.x; acc.y += result.y; acc.z += result.z; acc.w += 1.0f;   // path.py:93
-            f++;
-            alive = false;
+    LightSample li = lights_sample(p, hitpos, random3(s.rng));
+    if (any_gt0(li.color)) {
+        if (!tr.template occluded<COUNT>(hitpos, li.dir, s.avoid, li.dis, cnt)) {
+            V3 brdf_clr = disney_brdf(material, normal, sign, -s.rd, li.dir);
+            float brdf_pdf = vavg(brdf_clr);
+            float mis = power_heuristic(li.pdf, brdf_pdf);
+            V3 direct_li = li.color * mis * brdf_clr * dot_or_zero(normal, li.dir);
+            s.result = s.result + s.throughput * direct_li;
         }
     }
 
-    if (p.nchunks == 1) p.film0[pix] = acc;
-    else p.partial[(size_t)chunk_id * ((size_t)p.nx * p.ny) + pix] = acc;
+    BsdfSample brdf = disney_bounce(material, normal, sign, -s.rd, random3(s.rng));
+    s.throughput = s.throughput * brdf.color;
+    s.ro = hitpos;
+    s.rd = brdf.outdir;
+    s.last_brdf_pdf = brdf.pdf;
+    return false;
 }
+
+// Strict build: a lane owns ONE pixel and walks the batch's frames in order; the film sum is
+// kept in a register and grows in exactly the reference's order (filmtable.py:37-39, path.py:93).
+template <bool COUNT, class TR>
+DEV void trace_pixel(const MptRenderParams &p, const TR &tr, int i, int j, int f, int fend, Cnt &cnt) {
+    const int pix = i * p.ny + j;
+    MptVec4 acc = p.film0[pix];
+    PathState s;
+    for (; f < fend; f++) {
+        path_begin<COUNT>(p, s, i, j, f, cnt);
+        while (!path_step<COUNT>(p, tr, s, cnt)) {}
+        acc.x += s.result.x; acc.y += s.result.y; acc.z += s.result.z; acc.w += 1.0f;   // path.py:93
+    }
+    p.film0[pix] = acc;
+}
+
+#if !MPT_STRICT
+// Production build: a WAVE owns an 8x8 pixel tile x the frames [f0, f1) = a pool of 64*(f1-f0)
+// samples, and runs them as an in-wave state machine.  Measured on MI355X, the straightforward
+// "each lane loops over its own path" megakernel is VALU-issue bound at ~14 % lane utilisation
+// (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU): traversal trip counts, leaf tests and
+// shading all diverge.  Here every lane carries a small state and the wave alternates between
+//   traversal mode: a tight loop that runs ONE step per iteration for the lanes that are ready for
+//       it -- NODE (two child-box tests, near child next, far child pushed) or LEAF (one triangle
+//       test), whichever has more lanes -- for as long as most live lanes are traversing;
+//   shading mode: lanes whose shadow ray finished add their direct light and start the next bounce;
+//       lanes whose closest-hit query finished run SHADE (emitters, miss -> world, material, light
+//       sample + BSDF eval, BSDF sample: the whole bounce); then NEW hands the idle lanes the next
+//       samples of the pool (ballot + mbcnt compaction) and makes camera rays.
+// A bounce issues its shadow ray first and keeps the next ray's direction and the candidate direct
+// light C = throughput * mis * li * f * cos in registers; when the shadow traversal ends, C is
+// added iff nothing was hit and the closest-hit traversal of the next bounce starts at once, so
+// there is one shading stage per bounce and the order of additions into `result` is the
+// reference's (path.py:31-56).  Rays, samples and sums do not depend on the schedule: each sample's
+// radiance goes to p.partial[frame][pixel] and the combine pass adds frames in order.
+enum { ST_NODE = 0, ST_LEAF = 1, ST_DONE = 2, ST_NEW = 3, ST_DEAD = 4 };   // DONE: this lane's ray is finished
+
+// Per-lane state: live across the whole loop, so every word costs a VGPR for the kernel's lifetime.
+struct LaneState {
+    int st;
+    // path, path.py:19-23
+    V3 result, throughput;
+    float last_brdf_pdf;
+    int avoid, depth, rng_i;
+    int pix, frame;
+    V3 prd;                    // closest ray: the path direction r.d; shadow ray: the NEXT bounce direction
+    V3 direct;                 // shadow ray in flight: candidate direct light, added if unoccluded
+    // ray being traversed (closest: the path ray; shadow: hitpos -> light)
+    V3 to, td, inv, oinv;
+    float tbest;               // closest: best depth so far; shadow: li.dis
+    int curr, sp, hidx;
+    float hu, hv;
+    bool shadow, hit;
+};
+
+DEV Rng lane_rng(const MptRenderParams &p, const LaneState &L) {
+    Rng r; r.dim = p.sobol_dim; r.P = p.P + (size_t)L.frame * p.sobol_dim; r.i = L.rng_i; return r;
+}
+
+template <bool COUNT>
+DEV void lane_start_ray(LaneState &L, int n, V3 o, V3 d, float tmax, bool shadow, Cnt &cnt) {
+    L.to = o; L.td = d;
+    L.inv = v3(m_rcp(d.x), m_rcp(d.y), m_rcp(d.z));
+    L.oinv = o * L.inv;
+    L.tbest = tmax; L.shadow = shadow; L.hit = false; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f;
+    L.curr = 0; L.sp = 0;
+    if (COUNT) cnt.rays++;
+    L.st = ST_NODE;
+}
+
+// head of the path_trace loop, path.py:25-29: either the path is over or a closest-hit ray
+// starts from `ro` along L.prd
+template <bool COUNT>
+DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, V3 ro, Cnt &cnt) {
+    if (L.depth < 5 && any_gt0(L.throughput) && any_ne0(L.prd)) {
+        L.depth += 1;
+        if (COUNT) cnt.bounces++;
+        L.prd = normalized(L.prd);
+        lane_start_ray<COUNT>(L, p.n, ro, L.prd, MPT_INF, false, cnt);
+        // lbvh.py:218,319: with fewer than two faces the root box is never written: no hit
+        if (p.n < 2) L.st = ST_DONE;
+    } else {
+        MptVec4 o; o.x = L.result.x; o.y = L.result.y; o.z = L.result.z; o.w = 1.0f;
+        p.partial[(size_t)L.frame * ((size_t)p.nx * p.ny) + L.pix] = o;      // path.py:93, summed by combine
+        L.st = ST_NEW;
+    }
+}
+
+// Traversal steps touch only (curr, sp, st) and, for leaves, the hit record: everything a finished
+// ray triggers happens later, in shading mode, so the traversal loop carries no other live updates.
+template <class STACK>
+DEV void lane_pop(LaneState &L, STACK &stk) {
+    if (L.sp == 0) {
+        L.st = ST_DONE;
+    } else {
+        stk.sp = L.sp;
+        L.curr = stk.pop();
+        L.sp = stk.sp;
+        L.st = L.curr < 0 ? ST_LEAF : ST_NODE;
+    }
+}
+
+template <bool COUNT, class SCENE, class STACK>
+DEV void stage_node(const MptRenderParams &p, const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
+    MptVec4 a, b, c, d;
+    sc.node(L.curr, a, b, c, d);
+    int id0 = __float_as_int(d.x), id1 = __float_as_int(d.y);
+    if (COUNT) { cnt.n_node++; cnt.n_box += 2; }
+    float tn0, tn1;
+    bool h0 = box_fast(a.x, a.y, a.z, a.w, b.x, b.y, L.inv, L.oinv, L.tbest, &tn0);
+    bool h1 = box_fast(b.z, b.w, c.x, c.y, c.z, c.w, L.inv, L.oinv, L.tbest, &tn1);
+    // a leaf that is the triangle the ray left from is never tested (lbvh.py:329)
+    if (~id0 == L.avoid) h0 = false;
+    if (~id1 == L.avoid) h1 = false;
+    if (h0 && h1) {
+        bool swap = tn1 < tn0;
+        stk.sp = L.sp;
+        stk.push(swap ? id0 : id1);
+        L.sp = stk.sp;
+        L.curr = swap ? id1 : id0;
+        L.st = L.curr < 0 ? ST_LEAF : ST_NODE;
+    } else if (h0 || h1) {
+        L.curr = h0 ? id0 : id1;
+        L.st = L.curr < 0 ? ST_LEAF : ST_NODE;
+    } else {
+        lane_pop(L, stk);
+    }
+}
+
+template <bool COUNT, class SCENE, class STACK>
+DEV void stage_leaf(const MptRenderParams &p, const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
+    int slot = ~L.curr;
+    if (COUNT) cnt.n_tri++;
+    MptVec4 g0, g1, g2, g3;
+    sc.tri(slot, g0, g1, g2, g3);
+    float dd, su, sv;
+    bool stop = false;
+    if (tri_test(g0, g1, g2, g3, L.to, L.td, &dd, &su, &sv)) {
+        if (L.shadow) {
+            if (dd <= L.tbest) { L.hit = true; stop = true; }               // path.py:51: any occluder within li.dis
+        } else if (dd < L.tbest) {                                          // lbvh.py:331
+            L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv; L.hit = true;
+        }
+    }
+    if (stop) L.st = ST_DONE;
+    else lane_pop(L, stk);
+}
+
+// a shadow ray has finished: add the candidate direct light if nothing was hit (path.py:51,56),
+// then the next bounce starts from hitpos (= the shadow ray's origin), path.py:60
+template <bool COUNT>
+DEV void stage_shadow_done(const MptRenderParams &p, LaneState &L, Cnt &cnt) {
+    if (!L.hit) L.result = L.result + L.direct;
+    lane_next_bounce<COUNT>(p, L, L.to, cnt);
+}
+
+// path.py:31-62 for one bounce.  On entry L.to / L.prd are the path ray r.o / r.d and
+// (L.hit, L.tbest, L.hidx, L.hu, L.hv) the closest hit.
+template <bool COUNT>
+DEV void stage_shade(const MptRenderParams &p, LaneState &L, Cnt &cnt) {
+    V3 ro = L.to, rd = L.prd;
+    float hdepth = L.hit ? L.tbest : MPT_INF;
+    LightHit lit = lights_hit(p, ro, rd);
+    if (lit.hit && (!L.hit || lit.dis < hdepth)) {
+        float mis = power_heuristic(L.last_brdf_pdf, lit.pdf);
+        L.result = L.result + L.throughput * (lit.color * mis);
+    }
+    if (!L.hit) {
+        L.result = L.result + L.throughput * world_at(p, rd);
+        L.depth = 5;                                                         // break, path.py:39
+        lane_next_bounce<COUNT>(p, L, ro, cnt);
+        return;
+    }
+    L.avoid = L.hidx;
+    Hit hit; hit.hit = 1; hit.depth = hdepth; hit.index = L.hidx; hit.u = L.hu; hit.v = L.hv;
+    V3 hitpos, normal; Disney mat;
+    get_geometries(p, hit, ro, rd, &hitpos, &normal, mat);
+    if (COUNT) { cnt.n_shade++; cnt.n_draws += 6; }
+    float sign = -dot(rd, normal);                                           // path.py:44-46 (never negative)
+    if (sign < 0.0f) normal = -normal;
+
+    Rng rng = lane_rng(p, L);
+    LightSample li = lights_sample(p, hitpos, random3(rng));
+    bool want_shadow = any_gt0(li.color);
+    L.direct = v3s(0.0f);
+    if (want_shadow) {
+        // evaluated before the visibility is known; dropped if the shadow ray hits (path.py:50-56)
+        V3 brdf_clr = disney_brdf(mat, normal, sign, -rd, li.dir);
+        float brdf_pdf = vavg(brdf_clr);
+        float mis = power_heuristic(li.pdf, brdf_pdf);
+        V3 direct_li = li.color * mis * brdf_clr * dot_or_zero(normal, li.dir);
+        L.direct = L.throughput * direct_li;
+    }
+    BsdfSample brdf = disney_bounce(mat, normal, sign, -rd, random3(rng));
+    L.rng_i = rng.i;
+    L.throughput = L.throughput * brdf.color;
+    L.prd = brdf.outdir;
+    L.last_brdf_pdf = brdf.pdf;
+    if (want_shadow && p.n >= 2) {
+        lane_start_ray<COUNT>(L, p.n, hitpos, li.dir, li.dis, true, cnt);
+    } else {
+        if (want_shadow) { L.result = L.result + L.direct; if (COUNT) cnt.rays++; }   // no geometry to occlude
+        lane_next_bounce<COUNT>(p, L, hitpos, cnt);
+    }
+}
+
+// do_render up to the camera ray, path.py:82-90
+template <bool COUNT>
+DEV void lane_begin(const MptRenderParams &p, LaneState &L, int i, int j, Cnt &cnt) {
+    L.rng_i = wanghash2(i, j);                                               // path.py:72-73
+    Rng rng = lane_rng(p, L);
+    float dx = rng_random(rng), dy = rng_random(rng);
+    L.rng_i = rng.i;
+    float x = m_div((float)i + dx, (float)p.nx) * 2.0f - 1.0f;
+    float y = m_div((float)j + dy, (float)p.ny) * 2.0f - 1.0f;
+    V3 ro;
+    camera_generate(p, x, y, &ro, &L.prd);
+    L.avoid = -1; L.depth = 0;
+    L.result = v3s(0.0f); L.throughput = v3s(1.0f); L.last_brdf_pdf = 0.0f;
+    if (COUNT) { cnt.samples++; cnt.n_draws += 2; }
+    lane_next_bounce<COUNT>(p, L, ro, cnt);
+}
+
+DEV int wave_count(bool pred) { return (int)__builtin_popcountll(__ballot(pred)); }
+
+template <bool COUNT, class SCENE, class STACK>
+DEV void trace_pool(const MptRenderParams &p, const SCENE &sc, STACK stk, int ti, int tj, int f0, int f1, Cnt &cnt) {
+    const int S = (f1 - f0) * 64;
+    int next = 0;                                   // wave-uniform: next unassigned sample of the pool
+    LaneState L;
+    L.st = ST_NEW;
+    L.sp = 0; L.curr = 0; L.hit = false; L.shadow = false;
+    L.result = v3s(0.0f); L.throughput = v3s(0.0f); L.prd = v3s(0.0f); L.direct = v3s(0.0f);
+    L.to = v3s(0.0f); L.td = v3s(0.0f); L.inv = v3s(0.0f); L.oinv = v3s(0.0f);
+    L.tbest = 0.0f; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f; L.last_brdf_pdf = 0.0f;
+    L.avoid = -1; L.depth = 0; L.rng_i = 0; L.pix = 0; L.frame = f0;
+    for (;;) {
+        // ---- traversal mode: tight loop while the lanes that are traversing outnumber the waiting ones
+        for (;;) {
+            int cn = wave_count(L.st == ST_NODE);
+            int cl = wave_count(L.st == ST_LEAF);
+            int cw = wave_count(L.st == ST_DONE || L.st == ST_NEW);
+            if (cn + cl == 0 || (cn + cl) * p.sched_num < cw * p.sched_den) break;
+            if (cn >= cl) {
+                if (L.st == ST_NODE) stage_node<COUNT>(p, sc, stk, L, cnt);
+            } else {
+                if (L.st == ST_LEAF) stage_leaf<COUNT>(p, sc, stk, L, cnt);
+            }
+        }
+        // ---- shading mode
+        if (wave_count(L.st == ST_DONE && L.shadow) != 0) {
+            if (L.st == ST_DONE && L.shadow) stage_shadow_done<COUNT>(p, L, cnt);
+        }
+        if (wave_count(L.st == ST_DONE && !L.shadow) != 0) {
+            if (L.st == ST_DONE && !L.shadow) stage_shade<COUNT>(p, L, cnt);
+        }
+        unsigned long long m_new = __ballot(L.st == ST_NEW);
+        if (m_new != 0ull) {
+            if (next >= S) {                        // pool drained: those lanes are done
+                if (L.st == ST_NEW) L.st = ST_DEAD;
+            } else {
+                // idle lanes take the next consecutive samples (neighbouring pixels of one frame)
+                int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_new >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_new, 0u));
+                if (L.st == ST_NEW) {
+                    int smp = next + rank;
+                    if (smp < S) {
+                        int q = smp & 63;
+                        int i = ti + (q >> 3), j = tj + (q & 7);
+                        if (i < p.x1 && j < p.ny) {
+                            L.frame = f0 + (smp >> 6);
+                            L.pix = i * p.ny + j;
+                            lane_begin<COUNT>(p, L, i, j, cnt);
+                        }
+                    }
+                }
+                next += (int)__builtin_popcountll(m_new);
+            }
+        }
+        if (wave_count(L.st != ST_DEAD) == 0) break;
+    }
+}
+#endif
 
 // ---------------------------------------------------------------- gather kernel: 16x16 tile x chunk per workgroup
 DEV bool tile_pixel(const MptRenderParams &p, int tile, int *pi, int *pj) {
@@ -188,12 +450,17 @@ __global__ __launch_bounds__(MPT_BLOCK) void MPT_SUFFIX(render_kernel)(const Mpt
 
     int item = xcd_remap(blockIdx.x, gridDim.x);
     int tile = item / p.nchunks, chunk = item - tile * p.nchunks;
-    int i, j;
     Cnt cnt = {};
-    if (tile_pixel(p, tile, &i, &j)) {
-        int f = chunk * p.chunk;
-        trace_pixel<COUNT>(p, tr, i, j, f, min(f + p.chunk, p.nframes), chunk, cnt);
-    }
+#if MPT_STRICT
+    int i, j;
+    if (tile_pixel(p, tile, &i, &j)) trace_pixel<COUNT>(p, tr, i, j, 0, p.nframes, cnt);
+#else
+    int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
+    int wave = threadIdx.x >> 6;
+    int f0 = chunk * p.chunk;
+    trace_pool<COUNT>(p, tr.sc, tr.st, p.x0 + tx * MPT_TILE + (wave >> 1) * 8, ty * MPT_TILE + (wave & 1) * 8,
+                      f0, min(f0 + p.chunk, p.nframes), cnt);
+#endif
     flush_counters<COUNT>(p, cnt);
 }
 
@@ -230,12 +497,8 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
         if (item >= nitems) break;
         int tile = item / p.nchunks, chunk = item - tile * p.nchunks;
         int tx = tile / t8y, ty = tile - tx * t8y;
-        int i = p.x0 + tx * 8 + (lane >> 3);
-        int j = ty * 8 + (lane & 7);
-        if (i < p.x1 && j < p.ny) {
-            int f = chunk * p.chunk;
-            trace_pixel<COUNT>(p, tr, i, j, f, min(f + p.chunk, p.nframes), chunk, cnt);
-        }
+        int f0 = chunk * p.chunk;
+        trace_pool<COUNT>(p, tr.sc, tr.st, p.x0 + tx * 8, ty * 8, f0, min(f0 + p.chunk, p.nframes), cnt);
     }
     flush_counters<COUNT>(p, cnt);
 }

@@ -52,13 +52,15 @@ def parity(name, nx, ny, spp):
     return res
 
 
-def timing(name, mode, chunk, steps=5, spp=32, n=512, lds=1):
+def timing(name, mode, chunk, steps=5, spp=32, n=512, lds=1, sched=(1, 1)):
     common.reset_all()
     eng = setup_engine(scenes.get_scene(name), n, n, mode=mode)
     c = ctx()
     c.set_option('batch', spp)
     c.set_option('chunk', chunk)
     c.set_option('lds', lds)
+    c.set_option('sched_num', sched[0])
+    c.set_option('sched_den', sched[1])
     eng.render(spp)
     c.call('mpt_synchronize')
     c.kernel_time()
@@ -83,9 +85,15 @@ if __name__ == '__main__':
             print(name, nx, ny, spp, json.dumps(out[f'parity_{name}_{nx}x{ny}x{spp}'])[:600], flush=True)
             save()
     if 'timing' in what:
+        for sched in ((1, 0), (4, 1), (2, 1), (1, 1), (1, 2), (1, 4)):
+            for ch in (4, 8, 16):
+                r = timing('s978', 'fast', ch, sched=sched)
+                out[f'sched_{sched[0]}_{sched[1]}_chunk{ch}'] = r
+                print('s978 sched', sched, 'chunk', ch, r, flush=True)
+                save()
         for name in ('s978', 's34'):
             for lds in (1, 0):
-                for ch in (0, 1, 2, 4, 8, 16, 32):
+                for ch in (0, 2, 8, 32):
                     r = timing(name, 'fast', ch, lds=lds)
                     out[f'timing_{name}_fast_lds{lds}_chunk{ch}'] = r
                     print(name, 'fast lds', lds, 'chunk', ch, r, flush=True)
