@@ -230,7 +230,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (dev_alloc(&c->lights, MPT_MAX_LIGHTS)) return bail("lights");
     if (dev_alloc(&c->d_counters, 8)) return bail("counters");
     if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
-    if (dev_alloc(&c->d_work, 4)) return bail("work counter");
+    if (dev_alloc(&c->d_work, 8)) return bail("work counters");
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -781,32 +781,30 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     const int stack = (c->tree_depth + 2 <= 32) ? 32 : 64;
     // LDS-resident kernel: node + triangle records + a 16-bit stack of (depth-1) levels x 1024
     // lanes must fit the CU's 160 KiB; ids must fit int16
-    const int lds_stack = std::max(c->tree_depth, 1);   // one pending sibling (node or leaf) per level
+    const int lds_stack = c->tree_depth + 1;            // sentinel + one pending sibling (node or leaf) per level
     const size_t lds_bytes = ((size_t)(c->nfaces - 1) * 4 + (size_t)c->nfaces * 4) * sizeof(MptVec4) +
                              (size_t)lds_stack * 1024 * sizeof(short);
     const bool lds_kernel = c->mode == MPT_MODE_FAST && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 &&
                             lds_bytes <= 160 * 1024;
     int chunk = B, nchunks = 1;
+    const int tiles8 = ((c->x1 - c->x0 + 7) / 8) * ((c->ny + 7) / 8);
     if (c->mode == MPT_MODE_FAST) {
         chunk = c->chunk;
         if (chunk <= 0) {
-            int items_per_chunk, want_items;
-            if (lds_kernel) {   // 8x8 tiles pulled by 16 waves x CUs persistent waves: ~4 items per wave
-                items_per_chunk = ((c->x1 - c->x0 + 7) / 8) * ((c->ny + 7) / 8);
-                want_items = 4 * 16 * c->num_cus;
-            } else {            // 16x16 tiles dispatched as workgroups: thousands of blocks to balance
-                items_per_chunk = p.ntiles;
-                want_items = 6144;
-            }
-            int want = (want_items + items_per_chunk - 1) / items_per_chunk;
+            // work items are (8x8 tile, chunk of frames); persistent waves refill from the queue as
+            // soon as their pool drains, so small items cost nothing and balance best: aim for
+            // ~16 items per resident wave, at least 2 frames (128 samples) each
+            int want_items = 16 * 16 * c->num_cus;
+            int want = (want_items + tiles8 - 1) / std::max(tiles8, 1);
             want = std::max(1, std::min(want, B));
-            chunk = (B + want - 1) / want;
+            chunk = std::max((B + want - 1) / want, std::min(B, 2));
         }
         chunk = std::min(chunk, B);
         nchunks = (B + chunk - 1) / chunk;
     }
     p.chunk = chunk; p.nchunks = nchunks;
     p.sched_num = c->sched_num; p.sched_den = c->sched_den;
+    p.nitems = tiles8 * nchunks;
     p.work_counter = c->d_work;
     if (c->mode == MPT_MODE_FAST) {
         // one float4 per sample: [frame][pixel]; the combine pass sums frames in order
@@ -819,13 +817,12 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         }
         p.partial = c->partial;
     }
-    if (lds_kernel) HIP_TRY(hipMemsetAsync(c->d_work, 0, sizeof(unsigned int), c->stream));
+    if (c->mode == MPT_MODE_FAST) HIP_TRY(hipMemsetAsync(c->d_work, 0, 8 * sizeof(unsigned int), c->stream));
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(hipEventRecord(e0, c->stream));
-    int grid = p.ntiles * nchunks;
-    if (c->mode == MPT_MODE_STRICT) HIP_TRY(mpt_launch_render_strict(&p, grid, stack, c->count, c->stream));
+    if (c->mode == MPT_MODE_STRICT) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, c->stream));
     else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, c->num_cus, lds_bytes, c->count, c->stream));
-    else HIP_TRY(mpt_launch_render_fast(&p, grid, stack, c->count, c->stream));
+    else HIP_TRY(mpt_launch_render_fast(&p, c->num_cus, stack, c->count, c->stream));
     c->last_kernel = lds_kernel ? 1 : 0;
     HIP_TRY(hipEventRecord(e1, c->stream));
     c->events.push_back({ e0, e1 });

@@ -44,8 +44,9 @@ struct MptImage { int32_t nx, ny, base, pad; };   // image.py:14-16
 struct MptRenderParams {
     int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders
     int32_t nframes, chunk, nchunks, n;     // batch frames; frames per work item; items per tile; #triangles
-    int32_t sobol_dim, nlights, world_tex, tiles_x;
+    int32_t sobol_dim, nlights, world_tex, tiles_x;   // tiles_* : 16x16 tiles of the slab (strict build)
     int32_t tiles_y, ntiles, sched_num, sched_den;  // leave traversal mode when traversing*num < waiting*den
+    int32_t nitems, pad0, pad1, pad2;       // fast build: (8x8 tile, chunk) work items of this launch
     float world_fac[4];
     float v2w[16];
     const MptVec4 *snode;
@@ -62,5 +63,5 @@ struct MptRenderParams {
     MptVec4 *film2;                          // pass 2 (normal)
     MptVec4 *partial;                        // fast build: per-sample radiance [nframes][nx*ny]
     unsigned long long *counters;            // mpt_counters when counting, else unused
-    unsigned int *work_counter;              // persistent (LDS-resident) kernel: next work item
+    unsigned int *work_counter;              // persistent kernels: 8 per-range item counters
 };

@@ -180,6 +180,7 @@ DEV bool box_strict(V3 lo, V3 hi, V3 ro, V3 rd) {
 // per-lane LIFO in LDS: element [level][thread], so a wave's push/pop touches 64 consecutive
 // dwords (conflict-free); replaces GlobalStack's [thread][level] rows in global memory, stack.py:10-60
 struct Stack {
+    static constexpr int SENTINEL = (int)0x80000000;   // bottom-of-stack marker (never a node or leaf id)
     int *base;                 // &lds[threadIdx.x]
     int sp;
     DEV void push(int v) { base[sp * MPT_BLOCK] = v; sp++; }
@@ -222,6 +223,7 @@ struct LdsScene {
 // 16-bit LIFO for the LDS-resident kernel (node ids fit in int16 there), [level][lane of 1024]
 #define MPT_LDS_BLOCK 1024
 struct Stack16 {
+    static constexpr int SENTINEL = -32768;            // leaf ids are ~slot >= -32767 (n < 32768)
     LdsShortPtr base;          // &lds16[threadIdx.x]
     int sp;
     DEV void push(int v) { base[sp * MPT_LDS_BLOCK] = (short)v; sp++; }

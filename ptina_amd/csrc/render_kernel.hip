@@ -209,26 +209,35 @@ DEV Rng lane_rng(const MptRenderParams &p, const LaneState &L) {
     Rng r; r.dim = p.sobol_dim; r.P = p.P + (size_t)L.frame * p.sobol_dim; r.i = L.rng_i; return r;
 }
 
-template <bool COUNT>
-DEV void lane_start_ray(LaneState &L, int n, V3 o, V3 d, float tmax, bool shadow, Cnt &cnt) {
+// the bottom entry of every ray's LIFO is a sentinel, so "pop" never needs an emptiness test:
+// popping the sentinel means the traversal is over
+template <class STACK>
+DEV int classify(int v) {      // what a popped / chosen entry means for the lane's state
+    return v == STACK::SENTINEL ? ST_DONE : (v < 0 ? ST_LEAF : ST_NODE);
+}
+
+template <bool COUNT, class STACK>
+DEV void lane_start_ray(LaneState &L, STACK &stk, V3 o, V3 d, float tmax, bool shadow, Cnt &cnt) {
     L.to = o; L.td = d;
     L.inv = v3(m_rcp(d.x), m_rcp(d.y), m_rcp(d.z));
     L.oinv = o * L.inv;
     L.tbest = tmax; L.shadow = shadow; L.hit = false; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f;
-    L.curr = 0; L.sp = 0;
+    stk.sp = 0;
+    stk.push(STACK::SENTINEL);
+    L.curr = 0; L.sp = 1;
     if (COUNT) cnt.rays++;
     L.st = ST_NODE;
 }
 
 // head of the path_trace loop, path.py:25-29: either the path is over or a closest-hit ray
 // starts from `ro` along L.prd
-template <bool COUNT>
-DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, V3 ro, Cnt &cnt) {
+template <bool COUNT, class STACK>
+DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, STACK &stk, V3 ro, Cnt &cnt) {
     if (L.depth < 5 && any_gt0(L.throughput) && any_ne0(L.prd)) {
         L.depth += 1;
         if (COUNT) cnt.bounces++;
         L.prd = normalized(L.prd);
-        lane_start_ray<COUNT>(L, p.n, ro, L.prd, MPT_INF, false, cnt);
+        lane_start_ray<COUNT>(L, stk, ro, L.prd, MPT_INF, false, cnt);
         // lbvh.py:218,319: with fewer than two faces the root box is never written: no hit
         if (p.n < 2) L.st = ST_DONE;
     } else {
@@ -240,20 +249,10 @@ DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, V3 ro, Cnt &cn
 
 // Traversal steps touch only (curr, sp, st) and, for leaves, the hit record: everything a finished
 // ray triggers happens later, in shading mode, so the traversal loop carries no other live updates.
-template <class STACK>
-DEV void lane_pop(LaneState &L, STACK &stk) {
-    if (L.sp == 0) {
-        L.st = ST_DONE;
-    } else {
-        stk.sp = L.sp;
-        L.curr = stk.pop();
-        L.sp = stk.sp;
-        L.st = L.curr < 0 ? ST_LEAF : ST_NODE;
-    }
-}
-
+// They are written with two flat conditionals each (push / pop) instead of nested ones: on this
+// code the nested form cost more scalar exec-mask bookkeeping than the box arithmetic itself.
 template <bool COUNT, class SCENE, class STACK>
-DEV void stage_node(const MptRenderParams &p, const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
+DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     MptVec4 a, b, c, d;
     sc.node(L.curr, a, b, c, d);
     int id0 = __float_as_int(d.x), id1 = __float_as_int(d.y);
@@ -262,25 +261,21 @@ DEV void stage_node(const MptRenderParams &p, const SCENE &sc, STACK &stk, LaneS
     bool h0 = box_fast(a.x, a.y, a.z, a.w, b.x, b.y, L.inv, L.oinv, L.tbest, &tn0);
     bool h1 = box_fast(b.z, b.w, c.x, c.y, c.z, c.w, L.inv, L.oinv, L.tbest, &tn1);
     // a leaf that is the triangle the ray left from is never tested (lbvh.py:329)
-    if (~id0 == L.avoid) h0 = false;
-    if (~id1 == L.avoid) h1 = false;
-    if (h0 && h1) {
-        bool swap = tn1 < tn0;
-        stk.sp = L.sp;
-        stk.push(swap ? id0 : id1);
-        L.sp = stk.sp;
-        L.curr = swap ? id1 : id0;
-        L.st = L.curr < 0 ? ST_LEAF : ST_NODE;
-    } else if (h0 || h1) {
-        L.curr = h0 ? id0 : id1;
-        L.st = L.curr < 0 ? ST_LEAF : ST_NODE;
-    } else {
-        lane_pop(L, stk);
-    }
+    h0 = h0 && (~id0 != L.avoid);
+    h1 = h1 && (~id1 != L.avoid);
+    bool swap = tn1 < tn0;
+    int nearid = swap ? id1 : id0, farid = swap ? id0 : id1;
+    int next = h0 ? (h1 ? nearid : id0) : id1;
+    stk.sp = L.sp;
+    if (h0 && h1) stk.push(farid);
+    if (!(h0 || h1)) next = stk.pop();
+    L.sp = stk.sp;
+    L.curr = next;
+    L.st = classify<STACK>(next);
 }
 
 template <bool COUNT, class SCENE, class STACK>
-DEV void stage_leaf(const MptRenderParams &p, const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
+DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     int slot = ~L.curr;
     if (COUNT) cnt.n_tri++;
     MptVec4 g0, g1, g2, g3;
@@ -294,22 +289,25 @@ DEV void stage_leaf(const MptRenderParams &p, const SCENE &sc, STACK &stk, LaneS
             L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv; L.hit = true;
         }
     }
-    if (stop) L.st = ST_DONE;
-    else lane_pop(L, stk);
+    stk.sp = L.sp;
+    int next = stk.pop();
+    L.sp = stk.sp;
+    L.curr = next;
+    L.st = stop ? ST_DONE : classify<STACK>(next);
 }
 
 // a shadow ray has finished: add the candidate direct light if nothing was hit (path.py:51,56),
 // then the next bounce starts from hitpos (= the shadow ray's origin), path.py:60
-template <bool COUNT>
-DEV void stage_shadow_done(const MptRenderParams &p, LaneState &L, Cnt &cnt) {
+template <bool COUNT, class STACK>
+DEV void stage_shadow_done(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cnt) {
     if (!L.hit) L.result = L.result + L.direct;
-    lane_next_bounce<COUNT>(p, L, L.to, cnt);
+    lane_next_bounce<COUNT>(p, L, stk, L.to, cnt);
 }
 
 // path.py:31-62 for one bounce.  On entry L.to / L.prd are the path ray r.o / r.d and
 // (L.hit, L.tbest, L.hidx, L.hu, L.hv) the closest hit.
-template <bool COUNT>
-DEV void stage_shade(const MptRenderParams &p, LaneState &L, Cnt &cnt) {
+template <bool COUNT, class STACK>
+DEV void stage_shade(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cnt) {
     V3 ro = L.to, rd = L.prd;
     float hdepth = L.hit ? L.tbest : MPT_INF;
     LightHit lit = lights_hit(p, ro, rd);
@@ -320,7 +318,7 @@ DEV void stage_shade(const MptRenderParams &p, LaneState &L, Cnt &cnt) {
     if (!L.hit) {
         L.result = L.result + L.throughput * world_at(p, rd);
         L.depth = 5;                                                         // break, path.py:39
-        lane_next_bounce<COUNT>(p, L, ro, cnt);
+        lane_next_bounce<COUNT>(p, L, stk, ro, cnt);
         return;
     }
     L.avoid = L.hidx;
@@ -349,16 +347,16 @@ DEV void stage_shade(const MptRenderParams &p, LaneState &L, Cnt &cnt) {
     L.prd = brdf.outdir;
     L.last_brdf_pdf = brdf.pdf;
     if (want_shadow && p.n >= 2) {
-        lane_start_ray<COUNT>(L, p.n, hitpos, li.dir, li.dis, true, cnt);
+        lane_start_ray<COUNT>(L, stk, hitpos, li.dir, li.dis, true, cnt);
     } else {
         if (want_shadow) { L.result = L.result + L.direct; if (COUNT) cnt.rays++; }   // no geometry to occlude
-        lane_next_bounce<COUNT>(p, L, hitpos, cnt);
+        lane_next_bounce<COUNT>(p, L, stk, hitpos, cnt);
     }
 }
 
 // do_render up to the camera ray, path.py:82-90
-template <bool COUNT>
-DEV void lane_begin(const MptRenderParams &p, LaneState &L, int i, int j, Cnt &cnt) {
+template <bool COUNT, class STACK>
+DEV void lane_begin(const MptRenderParams &p, LaneState &L, STACK &stk, int i, int j, Cnt &cnt) {
     L.rng_i = wanghash2(i, j);                                               // path.py:72-73
     Rng rng = lane_rng(p, L);
     float dx = rng_random(rng), dy = rng_random(rng);
@@ -370,22 +368,46 @@ DEV void lane_begin(const MptRenderParams &p, LaneState &L, int i, int j, Cnt &c
     L.avoid = -1; L.depth = 0;
     L.result = v3s(0.0f); L.throughput = v3s(1.0f); L.last_brdf_pdf = 0.0f;
     if (COUNT) { cnt.samples++; cnt.n_draws += 2; }
-    lane_next_bounce<COUNT>(p, L, ro, cnt);
+    lane_next_bounce<COUNT>(p, L, stk, ro, cnt);
 }
 
 DEV int wave_count(bool pred) { return (int)__builtin_popcountll(__ballot(pred)); }
 
+// Work items = (8x8 pixel tile, chunk of frames), tile-major, split into 8 contiguous ranges with
+// one counter each.  A wave starts on the range of its XCD (blocks b, b+8, ... share an XCD) and
+// moves on to the next range when one runs dry, so neighbouring tiles are traced by CUs behind the
+// same L2 for as long as there is local work; every wave leaves when all eight ranges are exhausted.
+struct WorkQueue {
+    unsigned int *ctr;
+    int nitems, q0, qoff;
+    DEV int pull() {           // wave-uniform; -1 = no work left anywhere
+        const int lane = threadIdx.x & 63;
+        while (qoff < 8) {
+            int q = (q0 + qoff) & 7;
+            int lo = (int)(((long long)nitems * q) >> 3), hi = (int)(((long long)nitems * (q + 1)) >> 3);
+            int k = 0;
+            if (lane == 0) k = (int)atomicAdd(ctr + q, 1u);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (lo + k < hi) return lo + k;
+            qoff++;
+        }
+        return -1;
+    }
+};
+
 template <bool COUNT, class SCENE, class STACK>
-DEV void trace_pool(const MptRenderParams &p, const SCENE &sc, STACK stk, int ti, int tj, int f0, int f1, Cnt &cnt) {
-    const int S = (f1 - f0) * 64;
-    int next = 0;                                   // wave-uniform: next unassigned sample of the pool
+DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, WorkQueue wq, Cnt &cnt) {
+    const int t8y = (p.ny + 7) >> 3;
+    int S = 0, next = 0;                            // wave-uniform: current pool = 64*frames samples; next unassigned
+    int ti = 0, tj = 0, f0 = 0;
+    bool more = true;
     LaneState L;
     L.st = ST_NEW;
     L.sp = 0; L.curr = 0; L.hit = false; L.shadow = false;
     L.result = v3s(0.0f); L.throughput = v3s(0.0f); L.prd = v3s(0.0f); L.direct = v3s(0.0f);
     L.to = v3s(0.0f); L.td = v3s(0.0f); L.inv = v3s(0.0f); L.oinv = v3s(0.0f);
     L.tbest = 0.0f; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f; L.last_brdf_pdf = 0.0f;
-    L.avoid = -1; L.depth = 0; L.rng_i = 0; L.pix = 0; L.frame = f0;
+    L.avoid = -1; L.depth = 0; L.rng_i = 0; L.pix = 0; L.frame = 0;
     for (;;) {
         // ---- traversal mode: tight loop while the lanes that are traversing outnumber the waiting ones
         for (;;) {
@@ -394,23 +416,33 @@ DEV void trace_pool(const MptRenderParams &p, const SCENE &sc, STACK stk, int ti
             int cw = wave_count(L.st == ST_DONE || L.st == ST_NEW);
             if (cn + cl == 0 || (cn + cl) * p.sched_num < cw * p.sched_den) break;
             if (cn >= cl) {
-                if (L.st == ST_NODE) stage_node<COUNT>(p, sc, stk, L, cnt);
+                if (L.st == ST_NODE) stage_node<COUNT>(sc, stk, L, cnt);
             } else {
-                if (L.st == ST_LEAF) stage_leaf<COUNT>(p, sc, stk, L, cnt);
+                if (L.st == ST_LEAF) stage_leaf<COUNT>(sc, stk, L, cnt);
             }
         }
         // ---- shading mode
         if (wave_count(L.st == ST_DONE && L.shadow) != 0) {
-            if (L.st == ST_DONE && L.shadow) stage_shadow_done<COUNT>(p, L, cnt);
+            if (L.st == ST_DONE && L.shadow) stage_shadow_done<COUNT>(p, L, stk, cnt);
         }
         if (wave_count(L.st == ST_DONE && !L.shadow) != 0) {
-            if (L.st == ST_DONE && !L.shadow) stage_shade<COUNT>(p, L, cnt);
+            if (L.st == ST_DONE && !L.shadow) stage_shade<COUNT>(p, L, stk, cnt);
         }
         unsigned long long m_new = __ballot(L.st == ST_NEW);
         if (m_new != 0ull) {
-            if (next >= S) {                        // pool drained: those lanes are done
-                if (L.st == ST_NEW) L.st = ST_DEAD;
-            } else {
+            if (next >= S && more) {                // pool drained: fetch the next work item right away,
+                int item = wq.pull();               // while the other lanes are still busy (no per-item tail)
+                if (item < 0) more = false;
+                else {
+                    int tile = item / p.nchunks, chunk = item - tile * p.nchunks;
+                    int tx = tile / t8y, ty = tile - tx * t8y;
+                    ti = p.x0 + tx * 8; tj = ty * 8;
+                    f0 = chunk * p.chunk;
+                    S = (min(f0 + p.chunk, p.nframes) - f0) * 64;
+                    next = 0;
+                }
+            }
+            if (next < S) {
                 // idle lanes take the next consecutive samples (neighbouring pixels of one frame)
                 int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_new >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_new, 0u));
                 if (L.st == ST_NEW) {
@@ -421,11 +453,13 @@ DEV void trace_pool(const MptRenderParams &p, const SCENE &sc, STACK stk, int ti
                         if (i < p.x1 && j < p.ny) {
                             L.frame = f0 + (smp >> 6);
                             L.pix = i * p.ny + j;
-                            lane_begin<COUNT>(p, L, i, j, cnt);
+                            lane_begin<COUNT>(p, L, stk, i, j, cnt);
                         }
                     }
                 }
                 next += (int)__builtin_popcountll(m_new);
+            } else if (!more) {
+                if (L.st == ST_NEW) L.st = ST_DEAD;  // nothing left anywhere: those lanes are done
             }
         }
         if (wave_count(L.st != ST_DEAD) == 0) break;
@@ -447,19 +481,16 @@ template <int STACK, bool COUNT>
 __global__ __launch_bounds__(MPT_BLOCK) void MPT_SUFFIX(render_kernel)(const MptRenderParams p) {
     __shared__ int s_stack[STACK * MPT_BLOCK];
     BlockTracer tr = make_block_tracer(p, s_stack + threadIdx.x);
-
-    int item = xcd_remap(blockIdx.x, gridDim.x);
-    int tile = item / p.nchunks, chunk = item - tile * p.nchunks;
     Cnt cnt = {};
 #if MPT_STRICT
+    // one 16x16 tile per workgroup, every frame of the batch; blockIdx remapped for XCD locality
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
     int i, j;
     if (tile_pixel(p, tile, &i, &j)) trace_pixel<COUNT>(p, tr, i, j, 0, p.nframes, cnt);
 #else
-    int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
-    int wave = threadIdx.x >> 6;
-    int f0 = chunk * p.chunk;
-    trace_pool<COUNT>(p, tr.sc, tr.st, p.x0 + tx * MPT_TILE + (wave >> 1) * 8, ty * MPT_TILE + (wave & 1) * 8,
-                      f0, min(f0 + p.chunk, p.nframes), cnt);
+    // persistent workgroups pulling (8x8 tile, chunk) items; see WorkQueue
+    WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
+    trace_stream<COUNT>(p, tr.sc, tr.st, wq, cnt);
 #endif
     flush_counters<COUNT>(p, cnt);
 }
@@ -477,29 +508,15 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
     }
     __syncthreads();
 
-    Tracer<LdsScene, Stack16> tr;
-    tr.sc.fnode = (LdsVec4Ptr)(void *)smem;
-    tr.sc.tgeo = (LdsVec4Ptr)(void *)(smem + nnode4);
-    tr.st.base = (LdsShortPtr)(void *)(smem + nnode4 + ntri4) + threadIdx.x;
-    tr.st.sp = 0;
-    tr.n = p.n;
-
-    const int lane = threadIdx.x & 63;
-    const int t8y = (p.ny + 7) >> 3;
-    const int t8x = (p.x1 - p.x0 + 7) >> 3;
-    const int nitems = t8x * t8y * p.nchunks;
+    LdsScene sc;
+    sc.fnode = (LdsVec4Ptr)(void *)smem;
+    sc.tgeo = (LdsVec4Ptr)(void *)(smem + nnode4);
+    Stack16 stk;
+    stk.base = (LdsShortPtr)(void *)(smem + nnode4 + ntri4) + threadIdx.x;
+    stk.sp = 0;
     Cnt cnt = {};
-    // every wave pulls work until the counter runs past the last item: all waves leave the loop
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = (int)atomicAdd(p.work_counter, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= nitems) break;
-        int tile = item / p.nchunks, chunk = item - tile * p.nchunks;
-        int tx = tile / t8y, ty = tile - tx * t8y;
-        int f0 = chunk * p.chunk;
-        trace_pool<COUNT>(p, tr.sc, tr.st, p.x0 + tx * 8, ty * 8, f0, min(f0 + p.chunk, p.nframes), cnt);
-    }
+    WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
+    trace_stream<COUNT>(p, sc, stk, wq, cnt);
     flush_counters<COUNT>(p, cnt);
 }
 #endif
@@ -538,8 +555,28 @@ __global__ __launch_bounds__(MPT_BLOCK) void MPT_SUFFIX(preview_kernel)(const Mp
 }
 
 // ---------------------------------------------------------------- host-side launchers
+template <class K>
+static int blocks_per_cu(K kernel) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, MPT_BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
+    return nb;
+}
+
+// strict build: grid = number of 16x16 tiles.  fast build: persistent workgroups, `grid` = number of CUs
+// (scaled here by the blocks each CU can hold); the work items come from p->work_counter.
 extern "C" hipError_t MPT_SUFFIX(mpt_launch_render)(const MptRenderParams *p, int grid, int stack, int count,
                                                      hipStream_t stream) {
+#if !MPT_STRICT
+    static int occ[4] = { 0, 0, 0, 0 };
+    int v = (stack <= 32 ? 0 : 2) + (count ? 1 : 0);
+    if (!occ[v]) {
+        occ[v] = v == 0 ? blocks_per_cu(MPT_SUFFIX(render_kernel)<32, false>)
+               : v == 1 ? blocks_per_cu(MPT_SUFFIX(render_kernel)<32, true>)
+               : v == 2 ? blocks_per_cu(MPT_SUFFIX(render_kernel)<64, false>)
+                        : blocks_per_cu(MPT_SUFFIX(render_kernel)<64, true>);
+    }
+    grid *= occ[v];
+#endif
     if (stack <= 32) {
         if (count) hipLaunchKernelGGL((MPT_SUFFIX(render_kernel)<32, true>), dim3(grid), dim3(MPT_BLOCK), 0, stream, *p);
         else hipLaunchKernelGGL((MPT_SUFFIX(render_kernel)<32, false>), dim3(grid), dim3(MPT_BLOCK), 0, stream, *p);
