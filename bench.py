@@ -40,30 +40,62 @@ def algorithmic_bytes(c):
             + 128 * c['n_shade'])
 
 
-def cpu_baseline(scene, camera, budget_s=20.0):
+def measured_traffic():
+    '''HBM bytes per render launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/: FETCH_SIZE and WRITE_SIZE are in KiB; scattered 16-B accesses, so the guide's x2
+    read correction for wide coalesced streams is not applied), or None'''
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
+        for k, v in d.items():
+            if 'render_kernel_lds<false' in k:
+                return int((v['FETCH_SIZE']['median'] + v['WRITE_SIZE']['median']) * 1024)
+    except Exception:
+        pass
+    return None
+
+
+def host_threads():
+    '''threads for the CPU baseline: the cores this process may run on, capped at the GPU box's
+    per-GPU CPU share (16)'''
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get('MIPTINA_CPU_THREADS', '16'))))
+
+
+def cpu_baseline(scene, camera, budget_s=15.0):
     '''the CPU restatement (oracle, kind "port") on this host's cores, on a column window of the
-    same 512x512 workload sized to ~budget_s'''
+    same 512x512 workload sized to ~budget_s of wall time'''
     import oracle
     from helpers import setup_oracle
-    threads = os.cpu_count() or 1
+    threads = host_threads()
     o = setup_oracle(oracle, scene, NX, NY, camera=camera, threads=threads)
-    o.set_window(248, 256)
+    o.set_window(248, 248 + threads)
+    o.render(1)                                   # thread start-up, page faults
     t0 = time.time()
     o.render(1)
-    per_col_frame = (time.time() - t0) / 8
-    frames = 4
-    cols = int(max(8, min(NX, budget_s / max(per_col_frame * frames, 1e-9))))
-    cols -= cols % 8
-    x0 = (NX - cols) // 2
+    per_col_frame = (time.time() - t0) / threads
+    o.sobol_reset(64)
+    frames = SPP
+    full = per_col_frame * NX * frames            # estimated wall time of the whole workload
+    if full <= 2 * budget_s:
+        cols, x0 = NX, 0                          # the whole 512x512x32 job
+    else:
+        cols = int(max(threads, NX * budget_s / full))
+        cols -= cols % threads
+        x0 = (NX - cols) // 2
     o.set_window(x0, x0 + cols)
+    o.clear()
+    o.render(1)                                   # warm-up frame of exams/benchmark.py:25-27
     o.clear()
     t0 = time.time()
     o.render(frames)
     dt = time.time() - t0
     samples = cols * NY * frames
-    return {'value': samples / dt / 1e6, 'unit': 'Msamples/s', 'cores': threads, 'kind': 'port',
+    return {'value': round(samples / dt / 1e6, 4), 'unit': 'Msamples/s', 'cores': threads, 'kind': 'port',
             'sample': f'columns [{x0},{x0 + cols}) of the 512x512 film x {frames} spp = {samples} samples '
-                      f'in {dt:.1f} s (OpenMP, {threads} threads)'}
+                      f'in {dt:.1f} s (C restatement of PTina\'s algorithm, OpenMP, {threads} threads)'}
 
 
 def main():
@@ -164,12 +196,15 @@ def main():
                                    'unidirectional MIS path tracer, depth<=5', 'film': [NX, NY], 'spp': SPP,
                        'mode': args.mode, 'parallelism': f'film column slabs x{world}' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': None,
-                         'kernel': 'render_kernel_fast<32,false>' if args.mode == 'fast' else 'render_kernel_strict<32,false>',
+                         'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': measured_traffic(),
+                         'kernel': ('render_kernel_lds' if c.get_option('last_kernel') else 'render_kernel_fast')
+                         if args.mode == 'fast' else 'render_kernel_strict',
                          'avg_kernel_ms': round(avg_kernel_s * 1e3, 4), 'launches': nlaunch,
                          'algorithmic_bytes_per_launch': int(bytes_per_launch),
                          'bytes_per_sample': round(bytes_per_launch / (cnt['samples'] / W), 2),
-                         'note': 'working set (<1 MB) is L2-resident: the kernel is latency/divergence-bound, see DESIGN.md'},
+                         'note': 'algorithmic bytes (SURVEY 8d) over kernel time; the 125 KB of nodes+triangles are '
+                                 'served from LDS, so this exceeds what HBM could deliver and HBM is not the binding '
+                                 'limit: the kernel is VALU-issue bound (profiles/, DESIGN.md)'},
             'counters_per_sample': {k: round(v / max(cnt['samples'], 1), 3) for k, v in cnt.items() if k != 'samples'},
             'mrays_per_s': round(cnt['rays'] / W / avg_kernel_s / 1e6, 1),
         }

@@ -22,7 +22,8 @@
 // kernel launchers (render_kernel.hip x2, aux_kernels.hip)
 extern "C" hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
 extern "C" hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
-extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, size_t lds_bytes, int count, hipStream_t);
+extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, size_t lds_bytes, int count, int variant,
+                                            hipStream_t);
 extern "C" hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
 extern "C" hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
 extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
@@ -116,6 +117,7 @@ struct mpt_ctx {
     // options
     int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1;
     int num_cus = 256;
+    int variant = 2;                     // A/B switch of the LDS-resident kernel (render_kernel.hip VARIANT)
     int sched_num = 2, sched_den = 1;    // scheduler: stay in traversal mode while traversing*num >= waiting*den (tuned on MI355X)
     int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
 
@@ -284,6 +286,8 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->count = value ? 1 : 0;
     } else if (k == "lds") {
         c->use_lds = value ? 1 : 0;
+    } else if (k == "variant") {
+        c->variant = value;
     } else if (k == "sched_num") {
         if (value < 1) return fail("sched_num must be >= 1");
         c->sched_num = value;
@@ -611,9 +615,7 @@ extern "C" int mpt_build_tree(mpt_ctx *c) {
                 id[k] = ch - n;
             }
         }
-        fnode[(size_t)i * 4 + 0] = { l[0][0], l[0][1], l[0][2], h[0][0] };
-        fnode[(size_t)i * 4 + 1] = { h[0][1], h[0][2], l[1][0], l[1][1] };
-        fnode[(size_t)i * 4 + 2] = { l[1][2], h[1][0], h[1][1], h[1][2] };
+        for (int a = 0; a < 3; a++) fnode[(size_t)i * 4 + a] = { l[0][a], l[1][a], h[0][a], h[1][a] };
         fnode[(size_t)i * 4 + 3] = { asf(id[0]), asf(id[1]), 0.f, 0.f };
     }
     for (int slot = 0; slot < n; slot++) {
@@ -821,7 +823,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(hipEventRecord(e0, c->stream));
     if (c->mode == MPT_MODE_STRICT) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, c->stream));
-    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, c->num_cus, lds_bytes, c->count, c->stream));
+    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, c->num_cus, lds_bytes, c->count, c->variant, c->stream));
     else HIP_TRY(mpt_launch_render_fast(&p, c->num_cus, stack, c->count, c->stream));
     c->last_kernel = lds_kernel ? 1 : 0;
     HIP_TRY(hipEventRecord(e1, c->stream));

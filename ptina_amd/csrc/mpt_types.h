@@ -3,8 +3,10 @@
 // HBM layout (all SoA-of-records, 16-byte aligned so every fetch is a dwordx4):
 //   snode  float4[(n-1)*2]  reference-shaped node: {bmin.xyz, child0}, {bmax.xyz, child1}
 //                           (tree/lbvh.py:48-53 keeps four separate arrays; one 32-B record here)
-//   fnode  float4[(n-1)*4]  traversal node: both CHILD boxes + child ids in one 64-B record
-//                           {c0.lo.xyz, c0.hi.x} {c0.hi.yz, c1.lo.xy} {c1.lo.z, c1.hi.xyz} {id0, id1, -, -}
+//   fnode  float4[(n-1)*4]  traversal node: both CHILD boxes + child ids in one 64-B record, axis by axis
+//                           with the two children side by side so that a dwordx4 fetch lands in the
+//                           register pairs v_pk_fma_f32 wants:
+//                           {c0.lo.x, c1.lo.x, c0.hi.x, c1.hi.x} {..y..} {..z..} {id0, id1, -, -}
 //                           id >= 0: internal node index; id < 0: leaf, slot = ~id
 //   tgeo   float4[n*4]      per-leaf-slot triangle, ray-independent terms of geometries.py:118-148
 //                           hoisted: {v0.xyz, D} {u.xyz, uu} {v.xyz, uv} {n.xyz, vv}

@@ -304,8 +304,8 @@ DEV Hit bvh_walk(const SCENE &sc, int n, STACK st, V3 ro, V3 rd, int avoid, floa
         int id0 = __float_as_int(d.x), id1 = __float_as_int(d.y);
         if (COUNT) { cnt.n_node++; cnt.n_box += 2; }
         float tn0, tn1;
-        bool h0 = box_fast(a.x, a.y, a.z, a.w, b.x, b.y, inv, oinv, ret.depth, &tn0);
-        bool h1 = box_fast(b.z, b.w, c.x, c.y, c.z, c.w, inv, oinv, ret.depth, &tn1);
+        bool h0 = box_fast(a.x, b.x, c.x, a.z, b.z, c.z, inv, oinv, ret.depth, &tn0);
+        bool h1 = box_fast(a.y, b.y, c.y, a.w, b.w, c.w, inv, oinv, ret.depth, &tn1);
         if (h0 && id0 < 0) {
             h0 = false;
             int slot = ~id0;

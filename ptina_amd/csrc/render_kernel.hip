@@ -251,18 +251,42 @@ DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, STACK &stk, V3
 // ray triggers happens later, in shading mode, so the traversal loop carries no other live updates.
 // They are written with two flat conditionals each (push / pop) instead of nested ones: on this
 // code the nested form cost more scalar exec-mask bookkeeping than the box arithmetic itself.
-template <bool COUNT, class SCENE, class STACK>
+typedef float mpt_f2 __attribute__((ext_vector_type(2)));
+
+// VARIANT bits (A/B switches timed against each other in one process, tools/gpu_diag.py):
+//   1 : box plane distances as six v_pk_fma_f32 instead of twelve v_fma_f32
+//   2 : filter the triangle the ray left from in the leaf stage instead of in the node stage
+template <bool COUNT, int VARIANT, class SCENE, class STACK>
 DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     MptVec4 a, b, c, d;
     sc.node(L.curr, a, b, c, d);
     int id0 = __float_as_int(d.x), id1 = __float_as_int(d.y);
     if (COUNT) { cnt.n_node++; cnt.n_box += 2; }
     float tn0, tn1;
-    bool h0 = box_fast(a.x, a.y, a.z, a.w, b.x, b.y, L.inv, L.oinv, L.tbest, &tn0);
-    bool h1 = box_fast(b.z, b.w, c.x, c.y, c.z, c.w, L.inv, L.oinv, L.tbest, &tn1);
-    // a leaf that is the triangle the ray left from is never tested (lbvh.py:329)
-    h0 = h0 && (~id0 != L.avoid);
-    h1 = h1 && (~id1 != L.avoid);
+    bool h0, h1;
+    if (VARIANT & 1) {
+        mpt_f2 ix = { L.inv.x, L.inv.x }, iy = { L.inv.y, L.inv.y }, iz = { L.inv.z, L.inv.z };
+        mpt_f2 ox = { -L.oinv.x, -L.oinv.x }, oy = { -L.oinv.y, -L.oinv.y }, oz = { -L.oinv.z, -L.oinv.z };
+        mpt_f2 lx = { a.x, a.y }, hx = { a.z, a.w };
+        mpt_f2 ly = { b.x, b.y }, hy = { b.z, b.w };
+        mpt_f2 lz = { c.x, c.y }, hz = { c.z, c.w };
+        mpt_f2 t1x = __builtin_elementwise_fma(lx, ix, ox), t2x = __builtin_elementwise_fma(hx, ix, ox);
+        mpt_f2 t1y = __builtin_elementwise_fma(ly, iy, oy), t2y = __builtin_elementwise_fma(hy, iy, oy);
+        mpt_f2 t1z = __builtin_elementwise_fma(lz, iz, oz), t2z = __builtin_elementwise_fma(hz, iz, oz);
+        tn0 = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fmaxf(fminf(t1z.x, t2z.x), 0.0f));
+        float tf0 = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fminf(fmaxf(t1z.x, t2z.x), L.tbest));
+        tn1 = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fmaxf(fminf(t1z.y, t2z.y), 0.0f));
+        float tf1 = fminf(fminf(fmaxf(t1x.y, t2x.y), fmaxf(t1y.y, t2y.y)), fminf(fmaxf(t1z.y, t2z.y), L.tbest));
+        h0 = tn0 <= tf0; h1 = tn1 <= tf1;
+    } else {
+        h0 = box_fast(a.x, b.x, c.x, a.z, b.z, c.z, L.inv, L.oinv, L.tbest, &tn0);
+        h1 = box_fast(a.y, b.y, c.y, a.w, b.w, c.w, L.inv, L.oinv, L.tbest, &tn1);
+    }
+    if (!(VARIANT & 2)) {
+        // a leaf that is the triangle the ray left from is never tested (lbvh.py:329)
+        h0 = h0 && (~id0 != L.avoid);
+        h1 = h1 && (~id1 != L.avoid);
+    }
     bool swap = tn1 < tn0;
     int nearid = swap ? id1 : id0, farid = swap ? id0 : id1;
     int next = h0 ? (h1 ? nearid : id0) : id1;
@@ -274,19 +298,21 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     L.st = classify<STACK>(next);
 }
 
-template <bool COUNT, class SCENE, class STACK>
+template <bool COUNT, int VARIANT, class SCENE, class STACK>
 DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     int slot = ~L.curr;
-    if (COUNT) cnt.n_tri++;
-    MptVec4 g0, g1, g2, g3;
-    sc.tri(slot, g0, g1, g2, g3);
-    float dd, su, sv;
     bool stop = false;
-    if (tri_test(g0, g1, g2, g3, L.to, L.td, &dd, &su, &sv)) {
-        if (L.shadow) {
-            if (dd <= L.tbest) { L.hit = true; stop = true; }               // path.py:51: any occluder within li.dis
-        } else if (dd < L.tbest) {                                          // lbvh.py:331
-            L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv; L.hit = true;
+    if (!(VARIANT & 2) || slot != L.avoid) {                                // lbvh.py:329
+        if (COUNT) cnt.n_tri++;
+        MptVec4 g0, g1, g2, g3;
+        sc.tri(slot, g0, g1, g2, g3);
+        float dd, su, sv;
+        if (tri_test(g0, g1, g2, g3, L.to, L.td, &dd, &su, &sv)) {
+            if (L.shadow) {
+                if (dd <= L.tbest) { L.hit = true; stop = true; }           // path.py:51: any occluder within li.dis
+            } else if (dd < L.tbest) {                                      // lbvh.py:331
+                L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv; L.hit = true;
+            }
         }
     }
     stk.sp = L.sp;
@@ -395,7 +421,7 @@ struct WorkQueue {
     }
 };
 
-template <bool COUNT, class SCENE, class STACK>
+template <bool COUNT, int VARIANT, class SCENE, class STACK>
 DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, WorkQueue wq, Cnt &cnt) {
     const int t8y = (p.ny + 7) >> 3;
     int S = 0, next = 0;                            // wave-uniform: current pool = 64*frames samples; next unassigned
@@ -416,9 +442,9 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             int cw = wave_count(L.st == ST_DONE || L.st == ST_NEW);
             if (cn + cl == 0 || (cn + cl) * p.sched_num < cw * p.sched_den) break;
             if (cn >= cl) {
-                if (L.st == ST_NODE) stage_node<COUNT>(sc, stk, L, cnt);
+                if (L.st == ST_NODE) stage_node<COUNT, VARIANT>(sc, stk, L, cnt);
             } else {
-                if (L.st == ST_LEAF) stage_leaf<COUNT>(sc, stk, L, cnt);
+                if (L.st == ST_LEAF) stage_leaf<COUNT, VARIANT>(sc, stk, L, cnt);
             }
         }
         // ---- shading mode
@@ -490,7 +516,7 @@ __global__ __launch_bounds__(MPT_BLOCK) void MPT_SUFFIX(render_kernel)(const Mpt
 #else
     // persistent workgroups pulling (8x8 tile, chunk) items; see WorkQueue
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
-    trace_stream<COUNT>(p, tr.sc, tr.st, wq, cnt);
+    trace_stream<COUNT, 0>(p, tr.sc, tr.st, wq, cnt);
 #endif
     flush_counters<COUNT>(p, cnt);
 }
@@ -498,7 +524,7 @@ __global__ __launch_bounds__(MPT_BLOCK) void MPT_SUFFIX(render_kernel)(const Mpt
 #if !MPT_STRICT
 // ---------------------------------------------------------------- LDS-resident persistent kernel
 // dynamic LDS: [ (n-1)*4 node float4 | n*4 triangle float4 | lds_stack x 1024 int16 ]
-template <bool COUNT>
+template <bool COUNT, int VARIANT>
 __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRenderParams p) {
     extern __shared__ __attribute__((aligned(16))) MptVec4 smem[];
     const int nnode4 = (p.n - 1) * 4, ntri4 = p.n * 4;
@@ -516,7 +542,7 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
     stk.sp = 0;
     Cnt cnt = {};
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
-    trace_stream<COUNT>(p, sc, stk, wq, cnt);
+    trace_stream<COUNT, VARIANT>(p, sc, stk, wq, cnt);
     flush_counters<COUNT>(p, cnt);
 }
 #endif
@@ -589,21 +615,28 @@ extern "C" hipError_t MPT_SUFFIX(mpt_launch_render)(const MptRenderParams *p, in
 
 #if !MPT_STRICT
 // lds_bytes = scene records + 2 KiB per stack level; grid = one persistent workgroup per CU
-extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *p, int grid, size_t lds_bytes, int count,
-                                            hipStream_t stream) {
+template <bool COUNT, int VARIANT>
+static hipError_t launch_lds(const MptRenderParams *p, int grid, size_t lds_bytes, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)render_kernel_lds<false>,
+        hipError_t e = hipFuncSetAttribute((const void *)render_kernel_lds<COUNT, VARIANT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void *)render_kernel_lds<true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    if (count) hipLaunchKernelGGL(render_kernel_lds<true>, dim3(grid), dim3(MPT_LDS_BLOCK), lds_bytes, stream, *p);
-    else hipLaunchKernelGGL(render_kernel_lds<false>, dim3(grid), dim3(MPT_LDS_BLOCK), lds_bytes, stream, *p);
+    hipLaunchKernelGGL((render_kernel_lds<COUNT, VARIANT>), dim3(grid), dim3(MPT_LDS_BLOCK), lds_bytes, stream, *p);
     return hipGetLastError();
+}
+
+extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *p, int grid, size_t lds_bytes, int count,
+                                            int variant, hipStream_t stream) {
+    if (count) return launch_lds<true, 0>(p, grid, lds_bytes, stream);
+    switch (variant) {
+    case 1: return launch_lds<false, 1>(p, grid, lds_bytes, stream);
+    case 2: return launch_lds<false, 2>(p, grid, lds_bytes, stream);
+    case 3: return launch_lds<false, 3>(p, grid, lds_bytes, stream);
+    default: return launch_lds<false, 0>(p, grid, lds_bytes, stream);
+    }
 }
 #endif
 

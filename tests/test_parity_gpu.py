@@ -306,3 +306,19 @@ def test_full_size_properties_and_window_parity(fresh, oracle_mod):
     want = ref.get_image()[x0:x1]
     assert_parity(imgs['strict'][x0:x1], want, 1e-4, 0.01, 1e-2, what='full-size strict window')
     assert_parity(imgs['fast'][x0:x1], want, 1e-3, 0.02, 1e-2, what='full-size fast window')
+
+
+def test_rccl_film_gather_single_rank(fresh):
+    '''the RCCL path end to end with one rank: dlopen librccl, unique id, communicator, slab,
+    gather (a no-op for one rank), barrier and max all-reduce on the render stream'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.dist import RcclFilm, slab_bounds
+    eng = _engine(None, scenes.scene_s34(), 48, 32)
+    comm = RcclFilm(rank=0, world=1)
+    assert comm.set_slab(48) == slab_bounds(48, 1, 0) == (0, 48)
+    eng.render(2)
+    comm.gather(0, 0)
+    comm.barrier()
+    assert comm.allreduce_max(3.25) == 3.25
+    assert np.all(FilmTable().get_raw()[:, 3] == 2)
+    comm.close()

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+'''copy the rocprofv3 summaries of the last gpurun into profiles/ (tracked), named per round'''
+import csv
+import collections
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+dst = os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+
+
+def newest(pattern):
+    fs = sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', pattern)), key=os.path.getmtime)
+    return fs[-1] if fs else None
+
+
+f = newest('prof/*/*kernel_stats.csv')
+if f:
+    shutil.copy(f, os.path.join(dst, f'{tag}_kernel_stats.csv'))
+    print('kernel stats ->', f'{tag}_kernel_stats.csv')
+
+summary = {}
+for d in ('pmc1', 'pmc2', 'pmc3', 'pmc4'):
+    f = newest(f'{d}/*/*counter_collection.csv')
+    if not f:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+    for k, v in agg.items():
+        if 'render_kernel' not in k:
+            continue
+        for cn, vals in v.items():
+            vals = sorted(vals)
+            summary.setdefault(k, {})[cn] = {'median': vals[len(vals) // 2], 'n': len(vals)}
+if summary:
+    with open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w') as fh:
+        json.dump(summary, fh, indent=1, sort_keys=True)
+    print('pmc summary ->', f'{tag}_pmc_summary.json')
+for name in ('bench.log', 'diag.json'):
+    src = os.path.join(ROOT, 'gpurun_out', name)
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(dst, f'{tag}_{name}'))

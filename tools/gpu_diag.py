@@ -77,8 +77,31 @@ def timing(name, mode, chunk, steps=5, spp=32, n=512, lds=1, sched=(1, 1)):
             'lds_kernel': lk}
 
 
+def ab(variants=(0, 1, 2, 3), rounds=6, spp=32, n=512, name='s978'):
+    '''interleaved A/B of kernel variants in ONE process (median and min kernel ms)'''
+    common.reset_all()
+    eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
+    c = ctx()
+    c.set_option('batch', spp)
+    res = {v: [] for v in variants}
+    for r in range(rounds + 1):
+        for v in variants:
+            c.set_option('variant', v)
+            eng.render(spp)
+            c.call('mpt_synchronize')
+            ms, nl = c.kernel_time()
+            if r > 0:
+                res[v].append(ms / nl)
+    common.reset_all()
+    return {str(v): {'median': float(np.median(t)), 'min': float(np.min(t))} for v, t in res.items()}
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'ab' in what:
+        out['ab'] = ab()
+        print('A/B variants (kernel ms):', json.dumps(out['ab']), flush=True)
+        save()
     if 'parity' in what:
         for name, nx, ny, spp in (('s34', 64, 64, 8), ('s978', 96, 96, 8), ('s978', 128, 128, 32)):
             out[f'parity_{name}_{nx}x{ny}x{spp}'] = parity(name, nx, ny, spp)
