@@ -70,7 +70,10 @@ void mpt_destroy(mpt_ctx *ctx);
 /* "mode" (MPT_MODE_*), "batch" (max frames per launch, 1..64), "chunk" (frames per work item,
  * 0 = auto), "count" (1 = accumulate mpt_counters, slower), "lds" (1 = use the LDS-resident
  * persistent kernel when the scene fits a CU's 160 KiB LDS, default; 0 = always gather from HBM/L2).
- * read-only: "tree_depth", "pending", "last_kernel" (1 = LDS-resident), "num_cus" */
+ * "tree" (fast build: 1 = SAH re-partition of the LBVH's leaves, default; 0 = walk the LBVH itself;
+ * takes effect at the next mpt_build_tree), "sched_num"/"sched_den" (leave traversal mode when
+ * traversing*num < waiting*den), "variant" (A/B switches of the LDS-resident kernel).
+ * read-only: "tree_depth", "fast_depth", "pending", "last_kernel" (1 = LDS-resident), "num_cus" */
 int mpt_set_option(mpt_ctx *ctx, const char *key, int value);
 int mpt_get_option(mpt_ctx *ctx, const char *key, int *value);
 

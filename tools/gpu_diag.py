@@ -96,8 +96,41 @@ def ab(variants=(0, 1, 2, 3), rounds=6, spp=32, n=512, name='s978'):
     return {str(v): {'median': float(np.median(t)), 'min': float(np.min(t))} for v, t in res.items()}
 
 
+def tree_ab(name='s978', rounds=5, spp=32, n=512):
+    from ptina_amd.things import BVHTree
+    common.reset_all()
+    eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
+    c = ctx()
+    c.set_option('batch', spp)
+    res = {}
+    for r in range(rounds + 1):
+        for kind in (0, 1):
+            c.set_option('tree', kind)
+            BVHTree().build()
+            c.set_option('count', 1 if r == 0 else 0)
+            c.call('mpt_reset_counters')
+            eng.render(spp)
+            c.call('mpt_synchronize')
+            ms, nl = c.kernel_time()
+            if r == 0:
+                cnt = c.counters()
+                res[kind] = {'depth': c.get_option('fast_depth'), 'lds_kernel': c.get_option('last_kernel'),
+                             'node_per_ray': cnt['n_node'] / cnt['rays'], 'tri_per_ray': cnt['n_tri'] / cnt['rays'], 'ms': []}
+            else:
+                res[kind]['ms'].append(ms / nl)
+    common.reset_all()
+    for k in res:
+        res[k]['median_ms'] = float(np.median(res[k]['ms']))
+    return res
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'tree' in what:
+        for nm in ('s978', 's34'):
+            out['tree_' + nm] = tree_ab(nm)
+            print('tree A/B', nm, json.dumps(out['tree_' + nm]), flush=True)
+            save()
     if 'ab' in what:
         out['ab'] = ab()
         print('A/B variants (kernel ms):', json.dumps(out['ab']), flush=True)
