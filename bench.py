@@ -107,6 +107,7 @@ def main():
     ap.add_argument('--mode', default='fast')
     ap.add_argument('--chunk', type=int, default=-1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-comm', action='store_true', help='create the RCCL communicator even for one rank')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -126,7 +127,7 @@ def main():
     if args.chunk >= 0:
         c.set_option('chunk', args.chunk)
     c.set_option('batch', SPP)
-    comm = RcclFilm(rank, world) if world > 1 else None
+    comm = RcclFilm(rank, world) if (world > 1 or args.force_comm) else None
     if comm:
         comm.set_slab(NX)
 

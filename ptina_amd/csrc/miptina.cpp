@@ -964,11 +964,11 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         if (chunk <= 0) {
             // work items are (8x8 tile, chunk of frames); persistent waves refill from the queue as
             // soon as their pool drains, so small items cost nothing and balance best: aim for
-            // ~16 items per resident wave, at least 2 frames (128 samples) each
+            // ~16 items per resident wave
             int want_items = 16 * 16 * c->num_cus;
             int want = (want_items + tiles8 - 1) / std::max(tiles8, 1);
             want = std::max(1, std::min(want, B));
-            chunk = std::max((B + want - 1) / want, std::min(B, 2));
+            chunk = std::max((B + want - 1) / want, 1);
         }
         chunk = std::min(chunk, B);
         nchunks = (B + chunk - 1) / chunk;

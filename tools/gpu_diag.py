@@ -141,15 +141,15 @@ if __name__ == '__main__':
             print(name, nx, ny, spp, json.dumps(out[f'parity_{name}_{nx}x{ny}x{spp}'])[:600], flush=True)
             save()
     if 'timing' in what:
-        for sched in ((4, 1), (2, 1), (1, 1)):
-            for ch in (1, 2, 4, 8):
+        for sched in ((8, 1), (4, 1), (3, 1), (2, 1), (3, 2), (1, 1)):
+            for ch in (1, 2, 4):
                 r = timing('s978', 'fast', ch, sched=sched)
                 out[f'sched_{sched[0]}_{sched[1]}_chunk{ch}'] = r
                 print('s978 sched', sched, 'chunk', ch, r, flush=True)
                 save()
         for name in ('s978', 's34'):
             for lds in (1, 0):
-                for ch in (0, 1, 4, 32):
+                for ch in (0,):
                     r = timing(name, 'fast', ch, lds=lds)
                     out[f'timing_{name}_fast_lds{lds}_chunk{ch}'] = r
                     print(name, 'fast lds', lds, 'chunk', ch, r, flush=True)

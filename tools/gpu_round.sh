@@ -33,6 +33,7 @@ for step in "$@"; do
     pmc2)        run pmc2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     pmc3)        run pmc3 400 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     pmc4)        run pmc4 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc4 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
+    torchrun1)   run torchrun1 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --force-comm --no-cpu-baseline ;;
     *) echo "unknown step $step" ;;
   esac
 done
