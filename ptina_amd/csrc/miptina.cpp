@@ -33,6 +33,21 @@ extern "C" hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, 
 extern "C" hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
 extern "C" hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
 
+// on-GPU LBVH build (lbvh_build.hip)
+struct MptLbvhBuffers {
+    const float *verts; const int *mtlids; int n;
+    float *cen; int *bounds;
+    unsigned long long *keys_in, *keys_out;
+    void *sort_tmp; size_t sort_tmp_bytes;
+    int *child, *parent, *leaf, *mc;
+    float *bmin, *bmax;
+    unsigned *arrive;
+    int *depth;
+    MptVec4 *snode, *fnode, *tgeo, *tshade;
+};
+extern "C" hipError_t mpt_lbvh_sort_bytes(int n, size_t *bytes);
+extern "C" hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t stream);
+
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 
@@ -138,6 +153,18 @@ struct mpt_ctx {
     int tree_depth = 0;                  // reference LBVH (strict build)
     int fast_depth = 0;                  // tree the fast build walks (SAH or LBVH)
     int tree_kind = 1;                   // fast build: 1 = SAH re-partition of the LBVH's leaves, 0 = the LBVH itself
+    int gpu_build = 1;                   // 1 = LBVH built on the device (lbvh_build.hip), 0 = host build
+    int sah_max = 1 << 18;               // above this many faces the fast build walks the LBVH itself
+    bool host_tree_valid = false;        // h_child/h_leaf/... mirror the device tree (lazily downloaded)
+    // device-side build workspace
+    float *d_verts = nullptr; int *d_mtlids = nullptr; size_t d_model_cap = 0;
+    float *d_cen = nullptr; int *d_bounds = nullptr; int *d_depth = nullptr;
+    unsigned long long *d_keys_in = nullptr, *d_keys_out = nullptr;
+    void *d_sort_tmp = nullptr; size_t d_sort_bytes = 0;
+    int *d_child = nullptr, *d_parent = nullptr, *d_leaf = nullptr, *d_mc = nullptr;
+    float *d_bmin = nullptr, *d_bmax = nullptr;
+    unsigned *d_arrive = nullptr;
+    size_t d_build_cap = 0;
     std::vector<int32_t> h_child, h_leaf, h_mc;
     std::vector<float> h_bmin, h_bmax;
     MptVec4 *snode = nullptr, *fnode = nullptr, *tgeo = nullptr, *tshade = nullptr;
@@ -266,6 +293,10 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work);
+    hipFree(c->d_verts); hipFree(c->d_mtlids); hipFree(c->d_cen); hipFree(c->d_bounds); hipFree(c->d_depth);
+    hipFree(c->d_keys_in); hipFree(c->d_keys_out); hipFree(c->d_sort_tmp);
+    hipFree(c->d_child); hipFree(c->d_parent); hipFree(c->d_leaf); hipFree(c->d_mc);
+    hipFree(c->d_bmin); hipFree(c->d_bmax); hipFree(c->d_arrive);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -291,6 +322,10 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
     } else if (k == "tree") {
         if (value != 0 && value != 1) return fail("tree must be 0 (LBVH) or 1 (SAH)");
         if (value != c->tree_kind) { c->tree_kind = value; c->tree_valid = false; }
+    } else if (k == "gpu_build") {
+        if ((value ? 1 : 0) != c->gpu_build) { c->gpu_build = value ? 1 : 0; c->tree_valid = false; }
+    } else if (k == "sah_max") {
+        c->sah_max = value; c->tree_valid = false;
     } else if (k == "variant") {
         c->variant = value;
     } else if (k == "sched_num") {
@@ -315,6 +350,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "tree_depth") *value = c->tree_depth;
     else if (k == "fast_depth") *value = c->fast_depth;
     else if (k == "tree") *value = c->tree_kind;
+    else if (k == "gpu_build") *value = c->gpu_build;
     else if (k == "pending") *value = c->pending;
     else if (k == "lds") *value = c->use_lds;
     else if (k == "last_kernel") *value = c->last_kernel;
@@ -633,9 +669,7 @@ struct SahBuild {
     }
 };
 
-extern "C" int mpt_build_tree(mpt_ctx *c) {
-    if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
+static int build_tree_host(mpt_ctx *c) {
     const int n = c->nfaces;
     const float *V = c->verts.data();
     auto pos = [&](int f, int k) { return V + ((size_t)f * 3 + k) * 8; };
@@ -826,6 +860,142 @@ extern "C" int mpt_build_tree(mpt_ctx *c) {
     HIP_TRY(hipMemcpyAsync(c->tshade, tshade.data(), tshade.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->tree_valid = true;
+    c->host_tree_valid = true;
+    return 0;
+}
+
+// fnode records for the fast build from a (child, box) description over leaf slots
+static void pack_fnode(mpt_ctx *c, int n, const std::vector<int32_t> &fchild, const std::vector<float> &flo,
+                       const std::vector<float> &fhi, std::vector<MptVec4> &fnode) {
+    const int ni = n > 1 ? n - 1 : 0;
+    const float *V = c->verts.data();
+    auto asf = [](int32_t v) { float f; memcpy(&f, &v, 4); return f; };
+    fnode.assign((size_t)std::max(ni, 1) * 4, MptVec4{ 0, 0, 0, 0 });
+    for (int i = 0; i < ni; i++) {
+        float l[2][3], h[2][3];
+        int id[2];
+        for (int k = 0; k < 2; k++) {
+            id[k] = fchild[(size_t)i * 2 + k];
+            if (id[k] < 0) {
+                int f = c->h_leaf[~id[k]];
+                for (int a = 0; a < 3; a++) {
+                    const float *p0 = V + ((size_t)f * 3) * 8, *p1 = p0 + 8, *p2 = p0 + 16;
+                    l[k][a] = fminf(fminf(p0[a], p1[a]), p2[a]);
+                    h[k][a] = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
+                }
+            } else for (int a = 0; a < 3; a++) { l[k][a] = flo[(size_t)id[k] * 3 + a]; h[k][a] = fhi[(size_t)id[k] * 3 + a]; }
+        }
+        for (int a = 0; a < 3; a++) fnode[(size_t)i * 4 + a] = { l[0][a], l[1][a], h[0][a], h[1][a] };
+        fnode[(size_t)i * 4 + 3] = { asf(id[0]), asf(id[1]), 0.f, 0.f };
+    }
+}
+
+// lbvh.py:297-305 entirely on the device (lbvh_build.hip); only the depth (4 bytes) comes back,
+// plus the leaf order when the fast build wants its SAH re-partition (a host pass today)
+static int build_tree_gpu(mpt_ctx *c) {
+    const int n = c->nfaces;
+    const int ni = n > 1 ? n - 1 : 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((size_t)std::max(n, 1) > c->d_model_cap) {
+        hipFree(c->d_verts); hipFree(c->d_mtlids); c->d_verts = nullptr; c->d_mtlids = nullptr;
+        if (dev_alloc(&c->d_verts, (size_t)std::max(n, 1) * 24) || dev_alloc(&c->d_mtlids, (size_t)std::max(n, 1))) return 1;
+        c->d_model_cap = std::max(n, 1);
+    }
+    if ((size_t)std::max(n, 1) > c->d_build_cap) {
+        hipFree(c->d_cen); hipFree(c->d_bounds); hipFree(c->d_depth); hipFree(c->d_keys_in); hipFree(c->d_keys_out);
+        hipFree(c->d_sort_tmp); hipFree(c->d_child); hipFree(c->d_parent); hipFree(c->d_leaf); hipFree(c->d_mc);
+        hipFree(c->d_bmin); hipFree(c->d_bmax); hipFree(c->d_arrive);
+        c->d_cen = nullptr; c->d_bounds = nullptr; c->d_depth = nullptr; c->d_keys_in = c->d_keys_out = nullptr;
+        c->d_sort_tmp = nullptr; c->d_child = c->d_parent = c->d_leaf = c->d_mc = nullptr;
+        c->d_bmin = c->d_bmax = nullptr; c->d_arrive = nullptr;
+        size_t m = std::max(n, 1);
+        HIP_TRY(mpt_lbvh_sort_bytes((int)m, &c->d_sort_bytes));
+        if (dev_alloc(&c->d_cen, m * 3) || dev_alloc(&c->d_bounds, 6) || dev_alloc(&c->d_depth, 1) ||
+            dev_alloc(&c->d_keys_in, m) || dev_alloc(&c->d_keys_out, m) ||
+            dev_alloc((char **)&c->d_sort_tmp, std::max<size_t>(c->d_sort_bytes, 16)) ||
+            dev_alloc(&c->d_child, m * 2) || dev_alloc(&c->d_parent, m * 2) || dev_alloc(&c->d_leaf, m) ||
+            dev_alloc(&c->d_mc, m) || dev_alloc(&c->d_bmin, m * 3) || dev_alloc(&c->d_bmax, m * 3) ||
+            dev_alloc(&c->d_arrive, m)) return 1;
+        c->d_build_cap = m;
+    }
+    if ((size_t)std::max(ni, 1) > c->node_cap) {
+        hipFree(c->snode); hipFree(c->fnode); c->snode = c->fnode = nullptr;
+        if (dev_alloc(&c->snode, (size_t)std::max(ni, 1) * 2) || dev_alloc(&c->fnode, (size_t)std::max(ni, 1) * 4)) return 1;
+        c->node_cap = std::max(ni, 1);
+    }
+    if ((size_t)std::max(n, 1) > c->tri_cap) {
+        hipFree(c->tgeo); hipFree(c->tshade); c->tgeo = c->tshade = nullptr;
+        if (dev_alloc(&c->tgeo, (size_t)std::max(n, 1) * 4) || dev_alloc(&c->tshade, (size_t)std::max(n, 1) * 4)) return 1;
+        c->tri_cap = std::max(n, 1);
+    }
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(c->d_verts, c->verts.data(), (size_t)n * 24 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_mtlids, c->mtlids.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    MptLbvhBuffers b{};
+    b.verts = c->d_verts; b.mtlids = c->d_mtlids; b.n = n;
+    b.cen = c->d_cen; b.bounds = c->d_bounds; b.keys_in = c->d_keys_in; b.keys_out = c->d_keys_out;
+    b.sort_tmp = c->d_sort_tmp; b.sort_tmp_bytes = c->d_sort_bytes;
+    b.child = c->d_child; b.parent = c->d_parent; b.leaf = c->d_leaf; b.mc = c->d_mc;
+    b.bmin = c->d_bmin; b.bmax = c->d_bmax; b.arrive = c->d_arrive; b.depth = c->d_depth;
+    b.snode = c->snode; b.fnode = c->fnode; b.tgeo = c->tgeo; b.tshade = c->tshade;
+    HIP_TRY(mpt_lbvh_build(&b, c->stream));
+    int depth = 0;
+    if (ni > 0) HIP_TRY(hipMemcpyAsync(&depth, c->d_depth, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (depth + 2 > 64) return fail("LBVH depth %d exceeds the 64-entry traversal stack", depth);
+    c->tree_depth = depth;
+    c->fast_depth = depth;
+    c->host_tree_valid = false;
+    if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max) {
+        // SAH re-partition of the leaves for the fast build (host pass over the leaf order)
+        c->h_leaf.resize(n);
+        HIP_TRY(hipMemcpy(c->h_leaf.data(), c->d_leaf, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        SahBuild sb;
+        sb.n = n;
+        sb.lo.resize((size_t)n * 3); sb.hi.resize((size_t)n * 3); sb.ctr.resize((size_t)n * 3);
+        const float *V = c->verts.data();
+        for (int slot = 0; slot < n; slot++) {
+            int f = c->h_leaf[slot];
+            const float *p0 = V + ((size_t)f * 3) * 8, *p1 = p0 + 8, *p2 = p0 + 16;
+            for (int a = 0; a < 3; a++) {
+                float l = fminf(fminf(p0[a], p1[a]), p2[a]), h = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
+                sb.lo[(size_t)slot * 3 + a] = l; sb.hi[(size_t)slot * 3 + a] = h; sb.ctr[(size_t)slot * 3 + a] = 0.5f * (l + h);
+            }
+        }
+        sb.run();
+        if (sb.depth + 2 > 64) return fail("BVH depth %d exceeds the 64-entry traversal stack", sb.depth);
+        std::vector<MptVec4> fnode;
+        pack_fnode(c, n, sb.child, sb.blo, sb.bhi, fnode);
+        HIP_TRY(hipMemcpy(c->fnode, fnode.data(), (size_t)ni * 4 * sizeof(MptVec4), hipMemcpyHostToDevice));
+        c->fast_depth = sb.depth;
+    }
+    c->tree_valid = true;
+    return 0;
+}
+
+extern "C" int mpt_build_tree(mpt_ctx *c) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    return c->gpu_build ? build_tree_gpu(c) : build_tree_host(c);
+}
+
+static int download_tree(mpt_ctx *c) {
+    if (c->host_tree_valid) return 0;
+    const int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
+    c->h_child.assign((size_t)std::max(ni, 1) * 2, 0); c->h_leaf.assign(std::max(n, 1), 0); c->h_mc.assign(std::max(n, 1), 0);
+    c->h_bmin.assign((size_t)std::max(ni, 1) * 3, 0.f); c->h_bmax.assign((size_t)std::max(ni, 1) * 3, 0.f);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n > 0) {
+        HIP_TRY(hipMemcpy(c->h_leaf.data(), c->d_leaf, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c->h_mc.data(), c->d_mc, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    if (ni > 0) {
+        HIP_TRY(hipMemcpy(c->h_child.data(), c->d_child, (size_t)ni * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c->h_bmin.data(), c->d_bmin, (size_t)ni * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c->h_bmax.data(), c->d_bmax, (size_t)ni * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    c->host_tree_valid = true;
     return 0;
 }
 
@@ -833,6 +1003,7 @@ extern "C" int mpt_get_tree(mpt_ctx *c, int32_t *child, int32_t *leaf, float *bm
                             int32_t *depth) {
     if (!c) return fail("null context");
     if (!c->tree_valid) return fail("BVH not built: call build_tree() after load_model()");
+    if (download_tree(c)) return 1;
     int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
     if (child) memcpy(child, c->h_child.data(), (size_t)ni * 2 * sizeof(int32_t));
     if (leaf) memcpy(leaf, c->h_leaf.data(), (size_t)n * sizeof(int32_t));

@@ -322,3 +322,40 @@ def test_rccl_film_gather_single_rank(fresh):
     assert comm.allreduce_max(3.25) == 3.25
     assert np.all(FilmTable().get_raw()[:, 3] == 2)
     comm.close()
+
+
+@pytest.mark.parametrize('n', [2, 3, 1000, 60000])
+def test_gpu_lbvh_build_equals_host_build(fresh, n):
+    '''the on-device build (lbvh_build.hip: Morton keys, radix sort, Karras hierarchy, atomic
+    bottom-up boxes) is node-for-node the host build, duplicate Morton codes included'''
+    from ptina_amd.things import init_things, ModelPool, BVHTree
+    from ptina_amd.common import ctx
+    v, m, _, _ = scenes.scene_random_tris(n, seed=n, edge=0.05)
+    if n >= 1000:
+        v[3 * 7:3 * 9] = v[3 * 5:3 * 7]            # exact duplicates -> equal Morton codes
+    init_things()
+    ModelPool().load(v, m)
+    trees = {}
+    for gpu in (1, 0):
+        ctx().set_option('gpu_build', gpu)
+        BVHTree().build()
+        trees[gpu] = BVHTree().to_numpy()
+    for k in ('mc', 'leaf', 'child', 'bmin', 'bmax', 'depth'):
+        assert np.array_equal(trees[0][k], trees[1][k]), k
+    assert sorted(trees[1]['leaf']) == list(range(n))
+
+
+def test_render_does_not_depend_on_where_the_tree_was_built(fresh):
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    films = []
+    for gpu in (1, 0):
+        reset_all()
+        from ptina_amd.things import init_things
+        init_things()
+        ctx().set_option('gpu_build', gpu)
+        eng = _engine(None, scenes.scene_s978(), 48, 40, mode='fast')
+        eng.render(4)
+        films.append(FilmTable().get_raw())
+    reset_all()
+    assert np.array_equal(films[0], films[1])

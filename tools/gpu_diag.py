@@ -124,8 +124,63 @@ def tree_ab(name='s978', rounds=5, spp=32, n=512):
     return res
 
 
+def big(name, res_px, spp, **kw):
+    '''large scenes through the gather kernel: build time, render time, counters, fast-vs-strict'''
+    from ptina_amd.things import FilmTable as FT
+    t0 = time.time()
+    scene = scenes.get_scene(name, **kw)
+    tgen = time.time() - t0
+    world = ([1.0, 1.0, 1.0, 1.0], 0) if scene[3] else None
+    res = {'ntri': int(scene[1].shape[0]), 'gen_s': tgen}
+    imgs = {}
+    for mode in ('fast', 'strict'):
+        common.reset_all()
+        t0 = time.time()
+        n = res_px
+        eng = setup_engine(scene, n, n, mode=mode, world=world)
+        res[mode + '_setup_s'] = time.time() - t0
+        c = ctx()
+        res[mode + '_depth'] = [c.get_option('tree_depth'), c.get_option('fast_depth')]
+        c.set_option('batch', min(spp, 32))
+        eng.render(1)
+        c.call('mpt_synchronize')
+        c.kernel_time()
+        reps = 1 if mode == 'strict' else 3
+        use = spp if mode == 'fast' else min(spp, 4)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.render(use)
+        c.call('mpt_synchronize')
+        dt = time.perf_counter() - t0
+        kms, nl = c.kernel_time()
+        res[mode] = {'msamples_s': n * n * use * reps / dt / 1e6, 'kernel_ms_per_launch': kms / nl, 'spp': use,
+                     'lds_kernel': c.get_option('last_kernel')}
+        if mode == 'fast':
+            c.set_option('count', 1)
+            c.call('mpt_reset_counters')
+            eng.render(1)
+            cnt = c.counters()
+            res['per_ray'] = {k: cnt[k] / max(cnt['rays'], 1) for k in ('n_node', 'n_box', 'n_tri')}
+            res['per_sample'] = {k: cnt[k] / max(cnt['samples'], 1) for k in cnt}
+            c.set_option('count', 0)
+        from ptina_amd.sampling.sobol import SobolSampler
+        SobolSampler().reset()
+        FT().clear()
+        eng.render(4)
+        imgs[mode] = FT().get_image()
+    d, refn, rel = image_stats(imgs['fast'], imgs['strict'])
+    res['fast_vs_strict'] = {'rel_rmse': rel, 'frac_gt_1e-3': float((d > 1e-3 * (1 + refn)).mean()), 'max': float(d.max())}
+    common.reset_all()
+    return res
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'big' in what:
+        for nm, n, spp, kw in (('c4', 512, 16, {}), ('c5', 512, 8, {'n': 1000000})):
+            out['big_' + nm] = big(nm, n, spp, **kw)
+            print('big', nm, json.dumps(out['big_' + nm]), flush=True)
+            save()
     if 'tree' in what:
         for nm in ('s978', 's34'):
             out['tree_' + nm] = tree_ab(nm)

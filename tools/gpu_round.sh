@@ -22,6 +22,7 @@ for step in "$@"; do
     diag_timing) run diag_timing 500 python tools/gpu_diag.py timing ;;
     ab)          run ab 300 python tools/gpu_diag.py ab ;;
     tree)        run tree 300 python tools/gpu_diag.py tree ;;
+    big)         run big 900 python tools/gpu_diag.py big ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
     tests_all)   run tests_all 900 python -m pytest tests -m gpu -q ;;
     bench)       run bench 600 python bench.py ;;
