@@ -50,6 +50,10 @@ typedef struct {
     uint64_t n_draws;        /* Sobol draws                              */
     uint64_t bounces;        /* path-loop iterations                     */
     uint64_t n_node;         /* internal-node records fetched            */
+    uint64_t it_node;        /* wave-level NODE steps issued (n_node / (64 it_node) = lane utilisation) */
+    uint64_t it_leaf;        /* wave-level LEAF steps issued             */
+    uint64_t it_shade;       /* wave-level SHADE stages issued           */
+    uint64_t it_new;         /* wave-level NEW stages issued             */
 } mpt_counters;
 
 #define MPT_LIGHT_POINT 1    /* LightPool.TYPES, ptina/light/__init__.py:11 */

@@ -25,7 +25,8 @@ class Caps(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
-                ('samples', 'rays', 'n_box', 'n_tri', 'n_shade', 'n_draws', 'bounces', 'n_node')]
+                ('samples', 'rays', 'n_box', 'n_tri', 'n_shade', 'n_draws', 'bounces', 'n_node',
+                 'it_node', 'it_leaf', 'it_shade', 'it_new')]
 
     def asdict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -259,7 +259,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (dev_alloc(&c->mats, c->caps.max_materials)) return bail("materials");
     if (dev_alloc(&c->images, c->caps.max_textures)) return bail("images");
     if (dev_alloc(&c->lights, MPT_MAX_LIGHTS)) return bail("lights");
-    if (dev_alloc(&c->d_counters, 8)) return bail("counters");
+    if (dev_alloc(&c->d_counters, 12)) return bail("counters");
     if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
     if (dev_alloc(&c->d_work, 8)) return bail("work counters");
     {
@@ -267,7 +267,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             c->num_cus = prop.multiProcessorCount;
     }
-    hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream);
+    hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), c->stream);
     {   // unset materials: factor 0 (field-zero, mtllib.py:12-13), texture -1 (deviation Q6)
         std::vector<MptMaterial> z(c->caps.max_materials);
         for (auto &m : z) { memset(&m, 0, sizeof m); for (int k = 0; k < 12; k++) m.tex[k] = -1; }
@@ -1270,18 +1270,19 @@ extern "C" int mpt_get_film_raw(mpt_ctx *c, int pass, float *out) {
 extern "C" int mpt_get_counters(mpt_ctx *c, mpt_counters *out) {
     if (use(c)) return 1;
     if (mpt_flush(c)) return 1;
-    unsigned long long h[8];
+    unsigned long long h[12];
     HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     out->samples = h[0]; out->rays = h[1]; out->n_box = h[2]; out->n_tri = h[3];
     out->n_shade = h[4]; out->n_draws = h[5]; out->bounces = h[6]; out->n_node = h[7];
+    out->it_node = h[8]; out->it_leaf = h[9]; out->it_shade = h[10]; out->it_new = h[11];
     return 0;
 }
 
 extern "C" int mpt_reset_counters(mpt_ctx *c) {
     if (use(c)) return 1;
     if (mpt_flush(c)) return 1;
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), c->stream));
     return 0;
 }
 

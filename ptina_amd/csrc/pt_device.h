@@ -122,7 +122,7 @@ DEV float rng_random(Rng &r) {
 DEV V3 random3(Rng &r) { float a = rng_random(r), b = rng_random(r), c = rng_random(r); return v3(a, b, c); }
 
 // ---------------------------------------------------------------- counters
-struct Cnt { unsigned rays, n_box, n_tri, n_shade, n_draws, bounces, n_node, samples; };
+struct Cnt { unsigned rays, n_box, n_tri, n_shade, n_draws, bounces, n_node, samples, it_node, it_leaf, it_shade, it_new; };
 
 // ---------------------------------------------------------------- geometry
 struct Hit { int hit; float depth; int index; float u, v; };

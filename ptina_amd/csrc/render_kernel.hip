@@ -71,9 +71,10 @@ DEV BlockTracer make_block_tracer(const MptRenderParams &p, int *lds) {
 template <bool COUNT>
 DEV void flush_counters(const MptRenderParams &p, const Cnt &c) {
     if (!COUNT) return;
-    unsigned v[8] = { c.samples, c.rays, c.n_box, c.n_tri, c.n_shade, c.n_draws, c.bounces, c.n_node };
+    unsigned v[12] = { c.samples, c.rays, c.n_box, c.n_tri, c.n_shade, c.n_draws, c.bounces, c.n_node,
+                       c.it_node, c.it_leaf, c.it_shade, c.it_new };
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 12; k++) {
         unsigned x = v[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
@@ -436,22 +437,45 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     L.avoid = -1; L.depth = 0; L.rng_i = 0; L.pix = 0; L.frame = 0;
     for (;;) {
         // ---- traversal mode: tight loop while the lanes that are traversing outnumber the waiting ones
-        for (;;) {
-            int cn = wave_count(L.st == ST_NODE);
-            int cl = wave_count(L.st == ST_LEAF);
-            int cw = wave_count(L.st == ST_DONE || L.st == ST_NEW);
-            if (cn + cl == 0 || (cn + cl) * p.sched_num < cw * p.sched_den) break;
-            if (cn >= cl) {
-                if (L.st == ST_NODE) stage_node<COUNT, VARIANT>(sc, stk, L, cnt);
-            } else {
-                if (L.st == ST_LEAF) stage_leaf<COUNT, VARIANT>(sc, stk, L, cnt);
+        bool do_shade = true;
+        if (VARIANT & 4) {
+            // stage-specific thresholds: the expensive SHADE stage waits for sched_num lanes, the cheap
+            // hand-overs (shadow ray finished, new sample) for sched_den lanes
+            for (;;) {
+                int cn = wave_count(L.st == ST_NODE);
+                int cl = wave_count(L.st == ST_LEAF);
+                int cs = wave_count(L.st == ST_DONE && !L.shadow);
+                int cw = wave_count((L.st == ST_DONE && L.shadow) || (L.st == ST_NEW && (more || next < S)));
+                if (cn + cl == 0 || cs >= p.sched_num || cw >= p.sched_den) { do_shade = (cn + cl == 0) || cs >= p.sched_num / 2; break; }
+                if (cn >= cl) {
+                    if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
+                    if (L.st == ST_NODE) stage_node<COUNT, VARIANT>(sc, stk, L, cnt);
+                } else {
+                    if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
+                    if (L.st == ST_LEAF) stage_leaf<COUNT, VARIANT>(sc, stk, L, cnt);
+                }
+            }
+        } else {
+            for (;;) {
+                int cn = wave_count(L.st == ST_NODE);
+                int cl = wave_count(L.st == ST_LEAF);
+                int cw = wave_count(L.st == ST_DONE || L.st == ST_NEW);
+                if (cn + cl == 0 || (cn + cl) * p.sched_num < cw * p.sched_den) break;
+                if (cn >= cl) {
+                    if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
+                    if (L.st == ST_NODE) stage_node<COUNT, VARIANT>(sc, stk, L, cnt);
+                } else {
+                    if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
+                    if (L.st == ST_LEAF) stage_leaf<COUNT, VARIANT>(sc, stk, L, cnt);
+                }
             }
         }
         // ---- shading mode
         if (wave_count(L.st == ST_DONE && L.shadow) != 0) {
             if (L.st == ST_DONE && L.shadow) stage_shadow_done<COUNT>(p, L, stk, cnt);
         }
-        if (wave_count(L.st == ST_DONE && !L.shadow) != 0) {
+        if (do_shade && wave_count(L.st == ST_DONE && !L.shadow) != 0) {
+            if (COUNT && (threadIdx.x & 63) == 0) cnt.it_shade++;
             if (L.st == ST_DONE && !L.shadow) stage_shade<COUNT>(p, L, stk, cnt);
         }
         unsigned long long m_new = __ballot(L.st == ST_NEW);
@@ -469,6 +493,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 }
             }
             if (next < S) {
+                if (COUNT && (threadIdx.x & 63) == 0) cnt.it_new++;
                 // idle lanes take the next consecutive samples (neighbouring pixels of one frame)
                 int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_new >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_new, 0u));
                 if (L.st == ST_NEW) {
@@ -630,12 +655,11 @@ static hipError_t launch_lds(const MptRenderParams *p, int grid, size_t lds_byte
 
 extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *p, int grid, size_t lds_bytes, int count,
                                             int variant, hipStream_t stream) {
-    if (count) return launch_lds<true, 0>(p, grid, lds_bytes, stream);
+    if (count) return variant == 6 ? launch_lds<true, 6>(p, grid, lds_bytes, stream) : launch_lds<true, 2>(p, grid, lds_bytes, stream);
     switch (variant) {
-    case 1: return launch_lds<false, 1>(p, grid, lds_bytes, stream);
-    case 2: return launch_lds<false, 2>(p, grid, lds_bytes, stream);
-    case 3: return launch_lds<false, 3>(p, grid, lds_bytes, stream);
-    default: return launch_lds<false, 0>(p, grid, lds_bytes, stream);
+    case 6: return launch_lds<false, 6>(p, grid, lds_bytes, stream);
+    case 0: return launch_lds<false, 0>(p, grid, lds_bytes, stream);
+    default: return launch_lds<false, 2>(p, grid, lds_bytes, stream);
     }
 }
 #endif

@@ -77,7 +77,8 @@ def timing(name, mode, chunk, steps=5, spp=32, n=512, lds=1, sched=(1, 1)):
             'lds_kernel': lk}
 
 
-def ab(variants=(0, 1, 2, 3), rounds=6, spp=32, n=512, name='s978'):
+def ab(variants=((2, 2, 1), (0, 2, 1), (6, 16, 8), (6, 24, 8), (6, 32, 8), (6, 24, 16), (6, 32, 16), (6, 40, 16), (6, 32, 24), (6, 48, 24)),
+       rounds=5, spp=32, n=512, name='s978'):
     '''interleaved A/B of kernel variants in ONE process (median and min kernel ms)'''
     common.reset_all()
     eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
@@ -86,7 +87,9 @@ def ab(variants=(0, 1, 2, 3), rounds=6, spp=32, n=512, name='s978'):
     res = {v: [] for v in variants}
     for r in range(rounds + 1):
         for v in variants:
-            c.set_option('variant', v)
+            c.set_option('variant', v[0])
+            c.set_option('sched_num', v[1])
+            c.set_option('sched_den', v[2])
             eng.render(spp)
             c.call('mpt_synchronize')
             ms, nl = c.kernel_time()
@@ -174,8 +177,35 @@ def big(name, res_px, spp, **kw):
     return res
 
 
+def util(name='s978', spp=32, n=512):
+    '''lanes per issued stage (of 64) for a few scheduler thresholds'''
+    res = {}
+    for sched in ((1, 1), (2, 1), (4, 1)):
+        common.reset_all()
+        eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
+        c = ctx()
+        c.set_option('batch', spp)
+        c.set_option('sched_num', sched[0])
+        c.set_option('sched_den', sched[1])
+        c.set_option('count', 1)
+        eng.render(spp)
+        k = c.counters()
+        res[f'{sched[0]}:{sched[1]}'] = {
+            'node_lanes': k['n_node'] / max(k['it_node'], 1), 'leaf_lanes': k['n_tri'] / max(k['it_leaf'], 1),
+            'shade_lanes': k['n_shade'] / max(k['it_shade'], 1), 'new_lanes': k['samples'] / max(k['it_new'], 1),
+            'it_node_per_wave_sample': k['it_node'] * 64 / k['samples'], 'it_leaf_pws': k['it_leaf'] * 64 / k['samples'],
+            'it_shade_pws': k['it_shade'] * 64 / k['samples'], 'it_new_pws': k['it_new'] * 64 / k['samples']}
+    common.reset_all()
+    return res
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'util' in what:
+        out['util'] = util()
+        for k, v in out['util'].items():
+            print('util sched', k, json.dumps(v), flush=True)
+        save()
     if 'big' in what:
         for nm, n, spp, kw in (('c4', 512, 16, {}), ('c5', 512, 8, {'n': 1000000})):
             out['big_' + nm] = big(nm, n, spp, **kw)
