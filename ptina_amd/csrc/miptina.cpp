@@ -261,13 +261,14 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (dev_alloc(&c->lights, MPT_MAX_LIGHTS)) return bail("lights");
     if (dev_alloc(&c->d_counters, 12)) return bail("counters");
     if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
-    if (dev_alloc(&c->d_work, 8)) return bail("work counters");
+    if (dev_alloc(&c->d_work, 16)) return bail("work counters");   // 8 queue heads + [8] watchdog flag
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             c->num_cus = prop.multiProcessorCount;
     }
     hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), c->stream);
+    hipMemsetAsync(c->d_work, 0, 16 * sizeof(unsigned int), c->stream);
     {   // unset materials: factor 0 (field-zero, mtllib.py:12-13), texture -1 (deviation Q6)
         std::vector<MptMaterial> z(c->caps.max_materials);
         for (auto &m : z) { memset(&m, 0, sizeof m); for (int k = 0; k < 12; k++) m.tex[k] = -1; }
@@ -1159,7 +1160,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         }
         p.partial = c->partial;
     }
-    if (c->mode == MPT_MODE_FAST) HIP_TRY(hipMemsetAsync(c->d_work, 0, 8 * sizeof(unsigned int), c->stream));
+    if (c->mode == MPT_MODE_FAST) HIP_TRY(hipMemsetAsync(c->d_work, 0, 8 * sizeof(unsigned int), c->stream));   // [8] is sticky
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(hipEventRecord(e0, c->stream));
     if (c->mode == MPT_MODE_STRICT) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, c->stream));
@@ -1209,11 +1210,20 @@ extern "C" int mpt_render_preview(mpt_ctx *c, int nframes) {                   /
     return 0;
 }
 
+// a persistent render kernel that had to be stopped by its watchdog leaves a flag behind
+static int check_watchdog(mpt_ctx *c) {
+    unsigned int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, c->d_work + 8, sizeof flag, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flag) return fail("render kernel stopped by its watchdog (scheduler made no progress): film is incomplete");
+    return 0;
+}
+
 extern "C" int mpt_synchronize(mpt_ctx *c) {                                   // worker.py:17-18
     if (use(c)) return 1;
     if (mpt_flush(c)) return 1;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return check_watchdog(c);
 }
 
 extern "C" int mpt_clear(mpt_ctx *c, int pass) {                               // filmtable.py:44-45: every pass, `id` ignored
@@ -1244,7 +1254,7 @@ extern "C" int mpt_get_image(mpt_ctx *c, int pass, float *out) {               /
     if (mpt_resolve(c, pass)) return 1;
     HIP_TRY(hipMemcpyAsync(out, c->resolved, (size_t)c->nx * c->ny * sizeof(MptVec4), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return check_watchdog(c);
 }
 
 extern "C" int mpt_fast_export_image(mpt_ctx *c, int pass, float *out) {       // filmtable.py:66-79

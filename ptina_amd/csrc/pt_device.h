@@ -559,19 +559,31 @@ DEV V3 disney_brdf(const Disney &m, V3 normal, float sign, V3 indir, V3 outdir) 
         float Foh = schlickFresnel(cosoh);
         V3 Fsheen = m.sheencolor * (Foh * m.sheen);
 
-        float fdf = dielectricFresnel(etao, etai, cosoh);
-
         float Ds = GTR2(cosh_, m.alpha);
         V3 Fs = lerpv(Foh, m.speccolor, v3s(1.0f));
         float Gs = smithGGX(cosi, m.alpha) * smithGGX(coso, m.alpha);
-
+        V3 diffuse = m.basecolor * (MPT_INV_PI * lerpf(m.subsurface, Fd, ss)) + Fsheen;
+#if MPT_STRICT
+        float fdf = dielectricFresnel(etao, etai, cosoh);
         float Dr = GTR1(cosh_, m.clearcoatAlpha);
         float Gr = smithGGX(cosi, 0.25f) * smithGGX(coso, 0.25f);
         float Fr = lerpf(Foh, 0.04f, 1.0f);
-
-        V3 diffuse = m.basecolor * (MPT_INV_PI * lerpf(m.subsurface, Fd, ss)) + Fsheen;
         V3 specular = Fs * Gs * Ds + v3s(0.25f * m.clearcoat * Gr * Fr * Dr);
         V3 transmit = m.basecolor * (MPT_INV_PI * fdf * Ds);
+#else
+        // the clearcoat and transmission lobes are multiplied by their parameter: when that is
+        // exactly zero the term is skipped (identical result whenever the skipped factor is finite)
+        float coat = 0.0f;
+        if (m.clearcoat != 0.0f) {
+            float Dr = GTR1(cosh_, m.clearcoatAlpha);
+            float Gr = smithGGX(cosi, 0.25f) * smithGGX(coso, 0.25f);
+            float Fr = lerpf(Foh, 0.04f, 1.0f);
+            coat = 0.25f * m.clearcoat * Gr * Fr * Dr;
+        }
+        V3 specular = Fs * Gs * Ds + v3s(coat);
+        V3 transmit = v3s(0.0f);
+        if (m.transmission != 0.0f) transmit = m.basecolor * (MPT_INV_PI * dielectricFresnel(etao, etai, cosoh) * Ds);
+#endif
 
         result = diffuse * (1.0f - m.metallic) * (1.0f - m.transmission);
         result = result + transmit * (1.0f - m.metallic) * m.transmission;

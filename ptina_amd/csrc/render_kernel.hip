@@ -435,7 +435,14 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     L.to = v3s(0.0f); L.td = v3s(0.0f); L.inv = v3s(0.0f); L.oinv = v3s(0.0f);
     L.tbest = 0.0f; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f; L.last_brdf_pdf = 0.0f;
     L.avoid = -1; L.depth = 0; L.rng_i = 0; L.pix = 0; L.frame = 0;
-    for (;;) {
+    // Every pass of this loop retires at least one stage for at least one lane, so it ends when the
+    // queues are empty.  The pass counter is a watchdog only: a scheduling bug must not be able to keep
+    // a persistent wave (and with it the GPU) spinning -- the host turns the flag into an error.
+    for (unsigned guard = 0;; guard++) {
+        if (guard > (1u << 26)) {
+            if ((threadIdx.x & 63) == 0) atomicExch(p.work_counter + 8, 1u);
+            break;
+        }
         // ---- traversal mode: tight loop while the lanes that are traversing outnumber the waiting ones
         bool do_shade = true;
         if (VARIANT & 4) {

@@ -77,7 +77,7 @@ def timing(name, mode, chunk, steps=5, spp=32, n=512, lds=1, sched=(1, 1)):
             'lds_kernel': lk}
 
 
-def ab(variants=((2, 2, 1), (0, 2, 1), (6, 16, 8), (6, 24, 8), (6, 32, 8), (6, 24, 16), (6, 32, 16), (6, 40, 16), (6, 32, 24), (6, 48, 24)),
+def ab(variants=((2, 2, 1), (0, 2, 1), (6, 24, 16)),
        rounds=5, spp=32, n=512, name='s978'):
     '''interleaved A/B of kernel variants in ONE process (median and min kernel ms)'''
     common.reset_all()

@@ -20,7 +20,7 @@ for step in "$@"; do
     diag)        run diag 600 python tools/gpu_diag.py parity timing ;;
     diag_parity) run diag_parity 400 python tools/gpu_diag.py parity ;;
     diag_timing) run diag_timing 500 python tools/gpu_diag.py timing ;;
-    ab)          run ab 300 python tools/gpu_diag.py ab ;;
+    ab)          run ab 120 python tools/gpu_diag.py ab ;;
     tree)        run tree 300 python tools/gpu_diag.py tree ;;
     big)         run big 900 python tools/gpu_diag.py big ;;
     util)        run util 300 python tools/gpu_diag.py util ;;
