@@ -132,6 +132,7 @@ struct mpt_ctx {
     // options
     int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1;
     int num_cus = 256;
+    int tile_w_shift = 3, tile_h_shift = 3;   // work-item tile 2^w x 2^h pixels
     int variant = 2;                     // A/B switch of the LDS-resident kernel (render_kernel.hip VARIANT)
     int sched_num = 2, sched_den = 1;    // scheduler: stay in traversal mode while traversing*num >= waiting*den (tuned on MI355X)
     int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
@@ -191,6 +192,20 @@ struct mpt_ctx {
     // command batching
     int pending = 0;
 
+    // launch pipelining (fast build): batch i renders on rstream[i & 1] into partial[i & 1] while the main
+    // stream still combines / gathers / resolves batch i-1, so one launch's tail overlaps the next one's head
+    hipStream_t rstream[2] = { nullptr, nullptr };
+    hipEvent_t ev_render[2] = { nullptr, nullptr };   // render of the batch on rstream[k] finished
+    hipEvent_t ev_free[2] = { nullptr, nullptr };     // combine has consumed partial[k]
+    hipEvent_t ev_sobol = nullptr;                    // latest Sobol advance (X state hand-over between streams)
+    hipEvent_t ev_main = nullptr;                     // main-stream work a render must see (uploads, resets, ...)
+    bool main_dirty = true;
+    int flip = 0;
+    MptVec4 *partial2[2] = { nullptr, nullptr };
+    size_t partial2_cap = 0;                          // float4 elements per buffer
+    float *sP2[2] = { nullptr, nullptr };
+    unsigned int *d_work2[2] = { nullptr, nullptr };
+
     // measurement
     unsigned long long *d_counters = nullptr;
     unsigned int *d_work = nullptr;
@@ -203,9 +218,15 @@ struct mpt_ctx {
     double *d_scratch = nullptr;
 };
 
-static int use(mpt_ctx *c) {
+static int use_ro(mpt_ctx *c) {   // entry of calls that only read results
     if (!c) return fail("null context");
     HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+static int use(mpt_ctx *c) {      // entry of calls that may change what the next render launch reads
+    if (use_ro(c)) return 1;
+    c->main_dirty = true;
     return 0;
 }
 
@@ -262,6 +283,15 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (dev_alloc(&c->d_counters, 12)) return bail("counters");
     if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
     if (dev_alloc(&c->d_work, 16)) return bail("work counters");   // 8 queue heads + [8] watchdog flag
+    for (int k = 0; k < 2; k++) {
+        if (hipStreamCreateWithFlags(&c->rstream[k], hipStreamNonBlocking) != hipSuccess) return bail("render stream");
+        if (hipEventCreateWithFlags(&c->ev_render[k], hipEventDisableTiming) != hipSuccess) return bail("event");
+        if (hipEventCreateWithFlags(&c->ev_free[k], hipEventDisableTiming) != hipSuccess) return bail("event");
+        if (dev_alloc(&c->d_work2[k], 16)) return bail("work counters");
+        hipMemsetAsync(c->d_work2[k], 0, 16 * sizeof(unsigned int), c->stream);
+    }
+    if (hipEventCreateWithFlags(&c->ev_sobol, hipEventDisableTiming) != hipSuccess) return bail("event");
+    if (hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess) return bail("event");
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -284,8 +314,17 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
 extern "C" void mpt_destroy(mpt_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    for (int k = 0; k < 2; k++) if (c->rstream[k]) hipStreamSynchronize(c->rstream[k]);
     hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    for (int k = 0; k < 2; k++) {
+        if (c->rstream[k]) hipStreamDestroy(c->rstream[k]);
+        if (c->ev_render[k]) hipEventDestroy(c->ev_render[k]);
+        if (c->ev_free[k]) hipEventDestroy(c->ev_free[k]);
+        hipFree(c->partial2[k]); hipFree(c->sP2[k]); hipFree(c->d_work2[k]);
+    }
+    if (c->ev_sobol) hipEventDestroy(c->ev_sobol);
+    if (c->ev_main) hipEventDestroy(c->ev_main);
     for (auto &pr : c->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto &ev : c->event_pool) hipEventDestroy(ev);
     for (int p = 0; p < 3; p++) hipFree(c->film[p]);
@@ -323,6 +362,9 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
     } else if (k == "tree") {
         if (value != 0 && value != 1) return fail("tree must be 0 (LBVH) or 1 (SAH)");
         if (value != c->tree_kind) { c->tree_kind = value; c->tree_valid = false; }
+    } else if (k == "tile_w_shift" || k == "tile_h_shift") {
+        if (value < 0 || value > 3) return fail("%s must be in 0..3", k.c_str());
+        (k == "tile_w_shift" ? c->tile_w_shift : c->tile_h_shift) = value;
     } else if (k == "gpu_build") {
         if ((value ? 1 : 0) != c->gpu_build) { c->gpu_build = value ? 1 : 0; c->tree_valid = false; }
     } else if (k == "sah_max") {
@@ -1023,8 +1065,10 @@ extern "C" int mpt_sobol_init(mpt_ctx *c, const int32_t *V, int rows, int dim) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     c->sV = c->sX = nullptr; c->sP = nullptr;
+    for (int k = 0; k < 2; k++) { HIP_TRY(hipStreamSynchronize(c->rstream[k])); hipFree(c->sP2[k]); c->sP2[k] = nullptr; }
     if (dev_alloc(&c->sV, (size_t)rows * dim) || dev_alloc(&c->sX, (size_t)dim) ||
-        dev_alloc(&c->sP, (size_t)MPT_MAX_BATCH * dim)) return 1;
+        dev_alloc(&c->sP, (size_t)MPT_MAX_BATCH * dim) || dev_alloc(&c->sP2[0], (size_t)MPT_MAX_BATCH * dim) ||
+        dev_alloc(&c->sP2[1], (size_t)MPT_MAX_BATCH * dim)) return 1;
     HIP_TRY(hipMemcpyAsync(c->sV, V, (size_t)rows * dim * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->sX, 0, (size_t)dim * sizeof(int), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1032,12 +1076,14 @@ extern "C" int mpt_sobol_init(mpt_ctx *c, const int32_t *V, int rows, int dim) {
     return 0;
 }
 
-static int sobol_advance(mpt_ctx *c, int count, int keep) {
+static int sobol_advance(mpt_ctx *c, int count, int keep, hipStream_t stream = nullptr, float *P = nullptr) {
     // keep = number of trailing frames whose points are written to P[0..keep)
+    if (!stream) stream = c->stream;
+    if (!P) P = c->sP;
     while (count > 0) {
         int step = count;
         int k = std::min(keep, step);
-        HIP_TRY(mpt_launch_sobol_update(c->sX, c->sV, c->sP, c->sdim, c->srows, c->stime, step, k, c->stream));
+        HIP_TRY(mpt_launch_sobol_update(c->sX, c->sV, P, c->sdim, c->srows, c->stime, step, k, stream));
         c->stime = (int32_t)((uint32_t)c->stime + (uint32_t)step);
         count -= step;
     }
@@ -1118,20 +1164,38 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     c->pending = 0;
     MptRenderParams p;
     if (fill_params(c, p, B)) return 1;
-    if (p.ntiles == 0) return sobol_advance(c, B, 0);
-    if (sobol_advance(c, B, B)) return 1;
+    const bool fast = c->mode == MPT_MODE_FAST;
+    // fast build: this batch runs on its own stream; strict build: everything stays on the main stream
+    const int k = fast ? (c->flip++ & 1) : 0;
+    hipStream_t rs = fast ? c->rstream[k] : c->stream;
+    if (fast) {
+        if (c->main_dirty) {       // uploads / resets / option changes enqueued on the main stream come first
+            HIP_TRY(hipEventRecord(c->ev_main, c->stream));
+            c->main_dirty = false;
+        }
+        HIP_TRY(hipStreamWaitEvent(rs, c->ev_main, 0));
+        HIP_TRY(hipStreamWaitEvent(rs, c->ev_sobol, 0));     // X state of the previous batch's advance
+        p.P = c->sP2[k];
+    }
+    if (p.ntiles == 0) {
+        if (sobol_advance(c, B, 0, rs, fast ? c->sP2[k] : nullptr)) return 1;
+        if (fast) { HIP_TRY(hipEventRecord(c->ev_sobol, rs)); HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sobol, 0)); }
+        return 0;
+    }
+    if (sobol_advance(c, B, B, rs, fast ? c->sP2[k] : nullptr)) return 1;
+    if (fast) HIP_TRY(hipEventRecord(c->ev_sobol, rs));
 
     const int stack = ((c->mode == MPT_MODE_STRICT ? c->tree_depth : c->fast_depth) + 2 <= 32) ? 32 : 64;
-    // LDS-resident kernel: node + triangle records + a 16-bit stack of (depth-1) levels x 1024
+    // LDS-resident kernel: node + triangle records + a 16-bit stack of (depth+1) levels x 1024
     // lanes must fit the CU's 160 KiB; ids must fit int16
     const int lds_stack = c->fast_depth + 1;            // sentinel + one pending sibling (node or leaf) per level
     const size_t lds_bytes = ((size_t)(c->nfaces - 1) * 4 + (size_t)c->nfaces * 4) * sizeof(MptVec4) +
                              (size_t)lds_stack * 1024 * sizeof(short);
-    const bool lds_kernel = c->mode == MPT_MODE_FAST && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 &&
-                            lds_bytes <= 160 * 1024;
+    const bool lds_kernel = fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && lds_bytes <= 160 * 1024;
     int chunk = B, nchunks = 1;
-    const int tiles8 = ((c->x1 - c->x0 + 7) / 8) * ((c->ny + 7) / 8);
-    if (c->mode == MPT_MODE_FAST) {
+    const int tw = 1 << c->tile_w_shift, th = 1 << c->tile_h_shift;
+    const int tiles8 = ((c->x1 - c->x0 + tw - 1) / tw) * ((c->ny + th - 1) / th);
+    if (fast) {
         chunk = c->chunk;
         if (chunk <= 0) {
             // work items are (8x8 tile, chunk of frames); persistent waves refill from the queue as
@@ -1148,29 +1212,37 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     p.chunk = chunk; p.nchunks = nchunks;
     p.sched_num = c->sched_num; p.sched_den = c->sched_den;
     p.nitems = tiles8 * nchunks;
-    p.work_counter = c->d_work;
-    if (c->mode == MPT_MODE_FAST) {
+    p.tile_w_shift = c->tile_w_shift; p.tile_h_shift = c->tile_h_shift;
+    if (fast) {
         // one float4 per sample: [frame][pixel]; the combine pass sums frames in order
         size_t need = (size_t)B * c->nx * c->ny;
-        if (need > c->partial_cap) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            hipFree(c->partial); c->partial = nullptr;
-            if (dev_alloc(&c->partial, need)) return 1;
-            c->partial_cap = need;
+        if (need > c->partial2_cap) {
+            HIP_TRY(hipDeviceSynchronize());
+            for (int q = 0; q < 2; q++) { hipFree(c->partial2[q]); c->partial2[q] = nullptr; }
+            if (dev_alloc(&c->partial2[0], need) || dev_alloc(&c->partial2[1], need)) return 1;
+            c->partial2_cap = need;
         }
-        p.partial = c->partial;
+        p.partial = c->partial2[k];
+        p.work_counter = c->d_work2[k];
+        HIP_TRY(hipStreamWaitEvent(rs, c->ev_free[k], 0));   // combine of the batch that last used partial[k]
+        HIP_TRY(hipMemsetAsync(c->d_work2[k], 0, 8 * sizeof(unsigned int), rs));   // [8] (watchdog flag) is sticky
     }
-    if (c->mode == MPT_MODE_FAST) HIP_TRY(hipMemsetAsync(c->d_work, 0, 8 * sizeof(unsigned int), c->stream));   // [8] is sticky
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
-    HIP_TRY(hipEventRecord(e0, c->stream));
-    if (c->mode == MPT_MODE_STRICT) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, c->stream));
-    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, c->num_cus, lds_bytes, c->count, c->variant, c->stream));
-    else HIP_TRY(mpt_launch_render_fast(&p, c->num_cus, stack, c->count, c->stream));
+    HIP_TRY(hipEventRecord(e0, rs));
+    if (!fast) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, rs));
+    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, c->num_cus, lds_bytes, c->count, c->variant, rs));
+    else HIP_TRY(mpt_launch_render_fast(&p, c->num_cus, stack, c->count, rs));
     c->last_kernel = lds_kernel ? 1 : 0;
-    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventRecord(e1, rs));
     c->events.push_back({ e0, e1 });
-    if (c->mode == MPT_MODE_FAST)
-        HIP_TRY(mpt_launch_combine(c->film[0], c->partial, c->nx, c->ny, c->x0, c->x1, B, c->stream));
+    if (fast) {
+        // everything later on the main stream (combine, gather, resolve, read-backs, scene changes) is
+        // ordered after this render; the next batch, on the other stream, is not
+        HIP_TRY(hipEventRecord(c->ev_render[k], rs));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_render[k], 0));
+        HIP_TRY(mpt_launch_combine(c->film[0], c->partial2[k], c->nx, c->ny, c->x0, c->x1, B, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_free[k], c->stream));
+    }
     return 0;
 }
 
@@ -1212,16 +1284,20 @@ extern "C" int mpt_render_preview(mpt_ctx *c, int nframes) {                   /
 
 // a persistent render kernel that had to be stopped by its watchdog leaves a flag behind
 static int check_watchdog(mpt_ctx *c) {
-    unsigned int flag = 0;
+    unsigned int flag = 0, f2[2] = { 0, 0 };
     HIP_TRY(hipMemcpyAsync(&flag, c->d_work + 8, sizeof flag, hipMemcpyDeviceToHost, c->stream));
+    for (int k = 0; k < 2; k++)
+        HIP_TRY(hipMemcpyAsync(&f2[k], c->d_work2[k] + 8, sizeof flag, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    flag |= f2[0] | f2[1];
     if (flag) return fail("render kernel stopped by its watchdog (scheduler made no progress): film is incomplete");
     return 0;
 }
 
 extern "C" int mpt_synchronize(mpt_ctx *c) {                                   // worker.py:17-18
-    if (use(c)) return 1;
+    if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
+    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(c->rstream[k]));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return check_watchdog(c);
 }
@@ -1243,7 +1319,7 @@ static int check_pass(mpt_ctx *c, int pass) {
 }
 
 extern "C" int mpt_resolve(mpt_ctx *c, int pass) {
-    if (use(c)) return 1;
+    if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
     if (check_pass(c, pass)) return 1;
     HIP_TRY(mpt_launch_resolve(c->film[pass], c->resolved, (size_t)c->nx * c->ny, c->stream));
@@ -1258,7 +1334,7 @@ extern "C" int mpt_get_image(mpt_ctx *c, int pass, float *out) {               /
 }
 
 extern "C" int mpt_fast_export_image(mpt_ctx *c, int pass, float *out) {       // filmtable.py:66-79
-    if (use(c)) return 1;
+    if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
     if (check_pass(c, pass)) return 1;
     HIP_TRY(mpt_launch_export(c->film[pass], c->exported, c->nx, c->ny, c->stream));
@@ -1268,7 +1344,7 @@ extern "C" int mpt_fast_export_image(mpt_ctx *c, int pass, float *out) {       /
 }
 
 extern "C" int mpt_get_film_raw(mpt_ctx *c, int pass, float *out) {
-    if (use(c)) return 1;
+    if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
     if (check_pass(c, pass)) return 1;
     HIP_TRY(hipMemcpyAsync(out, c->film[pass], (size_t)c->nx * c->ny * sizeof(MptVec4), hipMemcpyDeviceToHost, c->stream));
@@ -1278,7 +1354,7 @@ extern "C" int mpt_get_film_raw(mpt_ctx *c, int pass, float *out) {
 
 // ------------------------------------------------------------------ measurement
 extern "C" int mpt_get_counters(mpt_ctx *c, mpt_counters *out) {
-    if (use(c)) return 1;
+    if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
     unsigned long long h[12];
     HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -1297,8 +1373,9 @@ extern "C" int mpt_reset_counters(mpt_ctx *c) {
 }
 
 extern "C" int mpt_kernel_time(mpt_ctx *c, double *ms, int *launches) {
-    if (use(c)) return 1;
+    if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
+    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(c->rstream[k]));
     HIP_TRY(hipStreamSynchronize(c->stream));
     double total = 0;
     for (auto &pr : c->events) {
@@ -1341,7 +1418,7 @@ extern "C" int mpt_comm_init(mpt_ctx *c, const char uid[128], int nranks, int ra
 }
 
 extern "C" int mpt_comm_gather_film(mpt_ctx *c, int pass, int root) {
-    if (use(c)) return 1;
+    if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
     if (check_pass(c, pass)) return 1;
     if (!c->comm) return fail("communicator not initialised");
@@ -1363,7 +1440,7 @@ extern "C" int mpt_comm_gather_film(mpt_ctx *c, int pass, int root) {
 }
 
 extern "C" int mpt_comm_barrier(mpt_ctx *c) {
-    if (use(c)) return 1;
+    if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
     if (!c->comm) return fail("communicator not initialised");
     HIP_TRY(hipMemsetAsync(c->d_scratch, 0, sizeof(double), c->stream));
@@ -1373,7 +1450,7 @@ extern "C" int mpt_comm_barrier(mpt_ctx *c) {
 }
 
 extern "C" int mpt_comm_allreduce_max(mpt_ctx *c, double *value) {
-    if (use(c)) return 1;
+    if (use_ro(c)) return 1;
     if (!c->comm) return fail("communicator not initialised");
     HIP_TRY(hipMemcpyAsync(c->d_scratch, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
     NCCL_TRY(g_rccl.AllReduce(c->d_scratch, c->d_scratch, 1, ncclDouble, ncclMax, c->comm, c->stream));

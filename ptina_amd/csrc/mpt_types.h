@@ -48,7 +48,7 @@ struct MptRenderParams {
     int32_t nframes, chunk, nchunks, n;     // batch frames; frames per work item; items per tile; #triangles
     int32_t sobol_dim, nlights, world_tex, tiles_x;   // tiles_* : 16x16 tiles of the slab (strict build)
     int32_t tiles_y, ntiles, sched_num, sched_den;  // leave traversal mode when traversing*num < waiting*den
-    int32_t nitems, pad0, pad1, pad2;       // fast build: (8x8 tile, chunk) work items of this launch
+    int32_t nitems, tile_w_shift, tile_h_shift, pad2;   // fast build: (2^w x 2^h tile, chunk) work items of this launch
     float world_fac[4];
     float v2w[16];
     const MptVec4 *snode;

@@ -424,7 +424,10 @@ struct WorkQueue {
 
 template <bool COUNT, int VARIANT, class SCENE, class STACK>
 DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, WorkQueue wq, Cnt &cnt) {
-    const int t8y = (p.ny + 7) >> 3;
+    // work-item tiles are 2^tw_shift x 2^th_shift pixels (8x8 by default; smaller tiles shorten the
+    // end-of-launch skew between waves at the price of primary-ray coherence)
+    const int tws = p.tile_w_shift, ths = p.tile_h_shift, tps = tws + ths;
+    const int t8y = (p.ny + (1 << ths) - 1) >> ths;
     int S = 0, next = 0;                            // wave-uniform: current pool = 64*frames samples; next unassigned
     int ti = 0, tj = 0, f0 = 0;
     bool more = true;
@@ -493,9 +496,9 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 else {
                     int tile = item / p.nchunks, chunk = item - tile * p.nchunks;
                     int tx = tile / t8y, ty = tile - tx * t8y;
-                    ti = p.x0 + tx * 8; tj = ty * 8;
+                    ti = p.x0 + (tx << tws); tj = ty << ths;
                     f0 = chunk * p.chunk;
-                    S = (min(f0 + p.chunk, p.nframes) - f0) * 64;
+                    S = (min(f0 + p.chunk, p.nframes) - f0) << tps;
                     next = 0;
                 }
             }
@@ -506,10 +509,10 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 if (L.st == ST_NEW) {
                     int smp = next + rank;
                     if (smp < S) {
-                        int q = smp & 63;
-                        int i = ti + (q >> 3), j = tj + (q & 7);
+                        int q = smp & ((1 << tps) - 1);
+                        int i = ti + (q >> ths), j = tj + (q & ((1 << ths) - 1));
                         if (i < p.x1 && j < p.ny) {
-                            L.frame = f0 + (smp >> 6);
+                            L.frame = f0 + (smp >> tps);
                             L.pix = i * p.ny + j;
                             lane_begin<COUNT>(p, L, stk, i, j, cnt);
                         }

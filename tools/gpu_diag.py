@@ -199,8 +199,44 @@ def util(name='s978', spp=32, n=512):
     return res
 
 
+def slabs(name='s978', spp=32, n=512, steps=20, tiles=((3, 3),)):
+    '''per-rank cost of a 1/N column slab (what one GPU of N does per step, without the gather)'''
+    res = {}
+    for parts, tile in [(pp, tt) for pp in (1, 2, 4, 8) for tt in tiles]:
+        per = []
+        for r in sorted(set((0, parts // 2,))):
+            common.reset_all()
+            x0, x1 = r * n // parts, (r + 1) * n // parts
+            eng = setup_engine(scenes.get_scene(name), n, n, mode='fast', slab=(x0, x1))
+            c = ctx()
+            c.set_option('batch', spp)
+            c.set_option('tile_w_shift', tile[0])
+            c.set_option('tile_h_shift', tile[1])
+            eng.render(spp)
+            c.call('mpt_resolve', 0)
+            c.call('mpt_synchronize')
+            c.kernel_time()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.render(spp)
+                c.call('mpt_flush')
+                c.call('mpt_resolve', 0)
+            c.call('mpt_synchronize')
+            dt = (time.perf_counter() - t0) / steps * 1e3
+            kms, nl = c.kernel_time()
+            per.append({'rank': r, 'step_ms': dt, 'kernel_ms': kms / nl})
+        res[f'{parts}:{tile}'] = per
+    common.reset_all()
+    return res
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'slabs' in what:
+        out['slabs'] = slabs()
+        for k, v in out['slabs'].items():
+            print('slabs', k, json.dumps(v), flush=True)
+        save()
     if 'util' in what:
         out['util'] = util()
         for k, v in out['util'].items():
