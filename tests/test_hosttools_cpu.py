@@ -1,0 +1,123 @@
+'''CPU tests of the host-side scene ingestion mirrors: OBJ, mesh composition, glTF,
+the worker-thread proxy.  No GPU.'''
+
+import base64
+import io
+import json
+import threading
+
+import numpy as np
+
+
+def test_readobj_layout_and_triangulation():
+    from ptina_amd.tools.readobj import readobj, writeobj
+    src = b"""# quad + triangle + pentagon
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0.5 2 0
+vt 0 0
+vt 1 1
+vn 0 0 1
+usemtl red
+f 1/1/1 2/2/1 3/1/1 4/2/1
+f 1//1 2//1 3//1
+usemtl blue
+f 1 2 3 4 5
+"""
+    obj = readobj(io.BytesIO(src))
+    assert obj['v'].shape == (5, 3) and obj['vt'].shape == (2, 2) and obj['vn'].shape == (1, 3)
+    f = obj['f']
+    assert f.shape == (2 + 1 + 3, 3, 3) and f.dtype == np.int32
+    assert f[0, :, 0].tolist() == [0, 1, 2] and f[1, :, 0].tolist() == [2, 3, 0]       # quad split
+    assert f[2].tolist() == [[0, 0, 0], [1, 0, 0], [2, 0, 0]]                          # missing vt -> 0
+    assert [t[:, 0].tolist() for t in f[3:]] == [[0, 1, 2], [0, 2, 3], [0, 3, 4]]      # fan
+    assert obj['usemtl'] == [[0, b'red'], [3, b'blue']]
+    v, tri = readobj(io.BytesIO(src), simple=True)
+    assert tri.shape == (6, 3)
+    out = io.StringIO()
+    writeobj(out, obj)
+    again = readobj(io.BytesIO(out.getvalue().encode()))
+    assert np.array_equal(again['f'], obj['f']) and np.allclose(again['v'], obj['v'])
+
+
+def test_modelpool_dict_packing_matches_reference_indexing():
+    '''ModelPool.load(dict): verts = v[f[:,:,0]], norms = vn[f[:,:,2]], coords = vt[f[:,:,1]]'''
+    from ptina_amd.tools.readobj import readobj
+    obj = readobj(io.BytesIO(b"v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0.25 0.75\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1\n"))
+    f = obj['f']
+    arr = np.concatenate([obj['v'][f[:, :, 0]].reshape(-1, 3), obj['vn'][f[:, :, 2]].reshape(-1, 3),
+                          obj['vt'][f[:, :, 1]].reshape(-1, 2)], axis=1)
+    assert arr.shape == (3, 8)
+    assert arr[1].tolist() == [1, 0, 0, 0, 0, 1, 0.25, 0.75]
+
+
+def test_compose_multiple_meshes():
+    from ptina_amd.multimesh import compose_multiple_meshes
+    from ptina_amd.tools.matrix import translate, scale
+    p = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], float)
+    n = np.array([[[0, 0, 1]] * 3], float)
+    t = np.array([[[0, 0], [1, 0], [0, 1]]], float)
+    verts, mtl = compose_multiple_meshes([(p, n, t, translate([1, 2, 3]), 4),
+                                          (p, n, None, scale([2, 2, 2]), None)])
+    assert verts.shape == (6, 8) and verts.dtype == np.float64 and mtl.tolist() == [4, -1]
+    assert verts[1, :3].tolist() == [2, 2, 3] and verts[1, 6:].tolist() == [1, 0]
+    assert verts[4, :3].tolist() == [2, 0, 0] and verts[4, 3:6].tolist() == [0, 0, 1]     # normals re-normalised
+    assert verts[4, 6:].tolist() == [0, 0]
+
+
+def _tiny_gltf():
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], np.float32)
+    nrm = np.array([[0, 0, 1]] * 4, np.float32)
+    idx = np.array([0, 1, 2, 2, 1, 3], np.uint16)
+    blob = pos.tobytes() + nrm.tobytes() + idx.tobytes()
+    uri = 'data:application/octet-stream;base64,' + base64.b64encode(blob).decode()
+    return {
+        'asset': {'version': '2.0'}, 'scene': 0, 'scenes': [{'nodes': [0]}],
+        'nodes': [{'mesh': 0, 'translation': [0, 0, -2], 'scale': [2, 1, 1]}],
+        'meshes': [{'primitives': [{'attributes': {'POSITION': 0, 'NORMAL': 1}, 'indices': 2, 'material': 0}]}],
+        'materials': [{'pbrMetallicRoughness': {'baseColorFactor': [0.8, 0.1, 0.1, 1], 'metallicFactor': 0.0,
+                                                'roughnessFactor': 0.5}}],
+        'buffers': [{'uri': uri, 'byteLength': len(blob)}],
+        'bufferViews': [{'buffer': 0, 'byteOffset': 0, 'byteLength': 48},
+                        {'buffer': 0, 'byteOffset': 48, 'byteLength': 48},
+                        {'buffer': 0, 'byteOffset': 96, 'byteLength': 12}],
+        'accessors': [{'bufferView': 0, 'componentType': 5126, 'count': 4, 'type': 'VEC3'},
+                      {'bufferView': 1, 'componentType': 5126, 'count': 4, 'type': 'VEC3'},
+                      {'bufferView': 2, 'componentType': 5123, 'count': 6, 'type': 'SCALAR'}],
+    }
+
+
+def test_readgltf_minimal(tmp_path):
+    from ptina_amd.tools.readgltf import readgltf
+    path = tmp_path / 'quad.gltf'
+    path.write_text(json.dumps(_tiny_gltf()))
+    vertices, mtlids, materials, images = readgltf(str(path))
+    assert vertices.shape == (6, 8) and mtlids.tolist() == [0, 0] and images == []
+    assert vertices[1, :3].tolist() == [2, 0, -2]                 # scale then translate
+    assert np.allclose(vertices[:, 3:6], [0, 0, 1])
+    (b, bt), (m, mt), (r, rt) = materials[0]
+    assert b == [0.8, 0.1, 0.1, 1] and bt == -1 and (m, mt, r, rt) == (0.0, -1, 0.5, -1)
+    # the 3-tuple is what MaterialPool.load zips against its 12 parameters
+    assert len(materials[0]) == 3
+
+
+def test_daemon_module_runs_on_one_thread():
+    from ptina_amd.tools.mtworker import DaemonModule, OnDemandProxy
+
+    class Fake:
+        def __init__(self):
+            self.ids = []
+
+        def where(self):
+            self.ids.append(threading.get_ident())
+            return threading.get_ident()
+
+        def boom(self):
+            raise RuntimeError('x')
+    fake = Fake()
+    mod = OnDemandProxy(lambda: DaemonModule(lambda: fake))
+    a, b = mod.where(), mod.where()
+    assert a == b != threading.get_ident()
+    assert mod.boom() is None                                      # swallowed and printed, like the reference
