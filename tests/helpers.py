@@ -16,6 +16,10 @@ def setup_engine(scene, nx, ny, mode='fast', camera=scenes.BENCH_CAMERA, lights=
     init_things(**caps)
     eng = PathEngine()
     ctx().set_option('mode', _lib.MODE_STRICT if mode == 'strict' else _lib.MODE_FAST)
+    import os
+    for key in ('variant', 'sched_num', 'sched_den'):                # experiment switches (tools/gpu_round.sh)
+        if os.environ.get('MIPTINA_' + key.upper()):
+            ctx().set_option(key, int(os.environ['MIPTINA_' + key.upper()]))
     FilmTable().set_size(nx, ny)
     vertices, mtlids, materials, images = scene
     ModelPool().load(vertices, mtlids)

@@ -230,8 +230,34 @@ def slabs(name='s978', spp=32, n=512, steps=20, tiles=((3, 3),)):
     return res
 
 
+def c3(n=2048, spp=64):
+    '''config 3's film on one GPU: S978 at 2048x2048 (needs max_filmsize = 2^22)'''
+    common.reset_all()
+    eng = setup_engine(scenes.get_scene('s978'), n, n, mode='fast', max_filmsize=n * n)
+    c = ctx()
+    c.set_option('batch', 32)
+    eng.render(1)
+    c.call('mpt_synchronize')
+    c.kernel_time()
+    t0 = time.perf_counter()
+    eng.render(spp)
+    c.call('mpt_resolve', 0)
+    c.call('mpt_synchronize')
+    dt = time.perf_counter() - t0
+    kms, nl = c.kernel_time()
+    from ptina_amd.things import FilmTable as FT
+    raw = FT().get_raw()
+    ok = bool(np.all(raw[:, 3] == spp + 1) and np.isfinite(raw).all())
+    common.reset_all()
+    return {'msamples_s': n * n * spp / dt / 1e6, 'kernel_ms': kms / nl, 'launches': nl, 'film_ok': ok}
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'c3' in what:
+        out['c3'] = c3()
+        print('c3 2048x2048', json.dumps(out['c3']), flush=True)
+        save()
     if 'slabs' in what:
         out['slabs'] = slabs()
         for k, v in out['slabs'].items():

@@ -25,6 +25,7 @@ for step in "$@"; do
     big)         run big 900 python tools/gpu_diag.py big ;;
     util)        run util 300 python tools/gpu_diag.py util ;;
     slabs)       run slabs 300 python tools/gpu_diag.py slabs ;;
+    c3)          run c3 300 python tools/gpu_diag.py c3 ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
     tests_all)   run tests_all 900 python -m pytest tests -m gpu -q ;;
     bench)       run bench 600 python bench.py ;;
