@@ -538,8 +538,14 @@ DEV bool tile_pixel(const MptRenderParams &p, int tile, int *pi, int *pj) {
     return i < p.x1 && j < p.ny;
 }
 
+#if MPT_STRICT
+#define MPT_RENDER_BOUNDS __launch_bounds__(MPT_BLOCK)
+#else
+// gathers from L2 / Infinity Cache are latency-bound: ask for 4 waves per SIMD (126 VGPRs, no spills)
+#define MPT_RENDER_BOUNDS __launch_bounds__(MPT_BLOCK, 4)
+#endif
 template <int STACK, bool COUNT>
-__global__ __launch_bounds__(MPT_BLOCK) void MPT_SUFFIX(render_kernel)(const MptRenderParams p) {
+__global__ MPT_RENDER_BOUNDS void MPT_SUFFIX(render_kernel)(const MptRenderParams p) {
     __shared__ int s_stack[STACK * MPT_BLOCK];
     BlockTracer tr = make_block_tracer(p, s_stack + threadIdx.x);
     Cnt cnt = {};
