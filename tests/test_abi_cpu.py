@@ -122,3 +122,19 @@ def test_scenes_have_the_quoted_triangle_counts():
         assert m.max() < len(mats) and all(len(x) == 12 for x in mats)
         nrm = np.linalg.norm(v[:, 3:6], axis=1)
         assert np.allclose(nrm, 1, atol=1e-5)
+
+
+def test_ptina_alias_package_maps_onto_ptina_amd():
+    '''`from ptina.things import *` etc. resolve to the ptina_amd modules (drop-in imports)'''
+    import importlib
+    import ptina_amd.filmtable
+    import ptina_amd.engine.path
+    import ptina_amd.tools.matrix
+    assert importlib.import_module('ptina.filmtable') is ptina_amd.filmtable
+    assert importlib.import_module('ptina.engine.path') is ptina_amd.engine.path
+    assert importlib.import_module('ptina.tools.matrix') is ptina_amd.tools.matrix
+    ns = {}
+    exec('from ptina.things import *\nfrom ptina.engine.path import *', ns)
+    for name in ('init_things', 'FilmTable', 'ModelPool', 'MaterialPool', 'ImagePool', 'BVHTree', 'Camera',
+                 'LightPool', 'WorldLight', 'PathEngine', 'ti', 'np'):
+        assert name in ns, name

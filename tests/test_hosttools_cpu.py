@@ -121,3 +121,25 @@ def test_daemon_module_runs_on_one_thread():
     a, b = mod.where(), mod.where()
     assert a == b != threading.get_ident()
     assert mod.boom() is None                                      # swallowed and printed, like the reference
+
+
+def test_benchmark_asset_round_trip(tmp_path):
+    '''tools/make_assets.py writes the procedural scenes where PTina's scripts expect their glTF
+    assets; reading them back yields the same triangles, grouped by material'''
+    import importlib.util
+    import os
+    from ptina_amd import scenes
+    from ptina_amd.tools.readgltf import readgltf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('make_assets', os.path.join(root, 'tools', 'make_assets.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(str(tmp_path))
+    vertices, mtlids, materials, images = readgltf(str(tmp_path / 'monkey_cornell.gltf'))
+    ref_v, ref_m, ref_mats, _ = scenes.scene_s978()
+    assert vertices.shape == (3 * 978, 8) and images == []
+    order = np.argsort(ref_m, kind='stable')
+    assert np.array_equal(mtlids, ref_m[order])
+    assert np.allclose(vertices.reshape(-1, 3, 8), ref_v.reshape(-1, 3, 8)[order], atol=1e-6)
+    assert len(materials) == len(ref_mats) and all(len(m) == 3 for m in materials)
+    assert np.allclose(materials[3][0][0][:3], ref_mats[3][0][0])

@@ -359,3 +359,43 @@ def test_render_does_not_depend_on_where_the_tree_was_built(fresh):
         films.append(FilmTable().get_raw())
     reset_all()
     assert np.array_equal(films[0], films[1])
+
+
+def test_ptina_named_driver_script_runs_unchanged(fresh, tmp_path, monkeypatch):
+    '''a driver written against PTina's own module names (`from ptina.things import *`, readgltf of
+    assets/monkey_cornell.gltf, the pools, BVHTree, Camera, PathEngine, FilmTable) runs as is'''
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('make_assets', os.path.join(root, 'tools', 'make_assets.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(str(tmp_path / 'assets'))
+    monkeypatch.chdir(tmp_path)
+    script = """
+from ptina.things import *
+from ptina.engine.path import *
+from ptina.tools.readgltf import readgltf
+import time
+
+ti.init(ti.cuda)
+init_things()
+PathEngine()
+FilmTable().set_size(128, 128)
+vertices, mtlids, materials, images = readgltf('assets/monkey_cornell.gltf')
+ModelPool().load(vertices, mtlids)
+MaterialPool().load(materials)
+ImagePool().load(images)
+BVHTree().build()
+Camera().set_perspective(np.array(CAMERA))
+PathEngine().render()
+FilmTable().get_image()
+FilmTable().clear()
+for i in range(8):
+    PathEngine().render()
+img = FilmTable().get_image()
+"""
+    ns = {'CAMERA': scenes.BENCH_CAMERA.tolist()}
+    exec(script, ns)
+    img = ns['img']
+    assert img.shape == (128, 128, 4) and np.all(img[..., 3] == 1.0) and np.isfinite(img).all()
+    assert 0.05 < img[..., :3].mean() < 2.0
