@@ -93,7 +93,15 @@ def cpu_baseline(scene, camera, budget_s=15.0):
     o.render(frames)
     dt = time.time() - t0
     samples = cols * NY * frames
+    # single-thread rate on 8 centre columns x 4 spp (SURVEY 8d asks for both figures)
+    o1 = setup_oracle(oracle, scene, NX, NY, camera=camera, threads=1)
+    o1.set_window(252, 260)
+    o1.render(1)
+    t1 = time.time()
+    o1.render(4)
+    one = 8 * NY * 4 / (time.time() - t1) / 1e6
     return {'value': round(samples / dt / 1e6, 4), 'unit': 'Msamples/s', 'cores': threads, 'kind': 'port',
+            'value_1thread': round(one, 4),
             'sample': f'columns [{x0},{x0 + cols}) of the 512x512 film x {frames} spp = {samples} samples '
                       f'in {dt:.1f} s (C restatement of PTina\'s algorithm, OpenMP, {threads} threads)'}
 
