@@ -133,7 +133,7 @@ struct mpt_ctx {
     int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1;
     int num_cus = 256;
     int tile_w_shift = 3, tile_h_shift = 3;   // work-item tile 2^w x 2^h pixels
-    int variant = 2;                     // A/B switch of the LDS-resident kernel (render_kernel.hip VARIANT)
+    int variant = 0;                     // A/B switch of the LDS-resident kernel (render_kernel.hip VARIANT)
     int sched_num = 2, sched_den = 1;    // scheduler: stay in traversal mode while traversing*num >= waiting*den (tuned on MI355X)
     int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
 

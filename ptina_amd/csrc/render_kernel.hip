@@ -210,6 +210,31 @@ DEV Rng lane_rng(const MptRenderParams &p, const LaneState &L) {
     Rng r; r.dim = p.sobol_dim; r.P = p.P + (size_t)L.frame * p.sobol_dim; r.i = L.rng_i; return r;
 }
 
+// N consecutive draws of the lane's Sobol proxy (sobol.py:121-125).  The proxy's counter is an i32
+// that the reference reduces mod dim (floor-mod) at every draw; unless the counter is about to wrap
+// (probability ~N/2^32 per pixel) the N indices are k, k+1, ... with one wrap at dim, so one integer
+// division serves all of them.  The wrapping case takes the literal per-draw path.
+template <int N>
+DEV void lane_draws(const MptRenderParams &p, LaneState &L, float *out) {
+    const float *P = p.P + (size_t)L.frame * p.sobol_dim;
+    const int dim = p.sobol_dim;
+    if (L.rng_i <= 0x7fffffff - N) {
+        int k = L.rng_i % dim;
+        if (k < 0) k += dim;
+#pragma unroll
+        for (int t = 0; t < N; t++) {
+            out[t] = P[k];
+            k = (k + 1 == dim) ? 0 : k + 1;
+        }
+        L.rng_i += N;
+    } else {
+        Rng rng = lane_rng(p, L);
+#pragma unroll
+        for (int t = 0; t < N; t++) out[t] = rng_random(rng);
+        L.rng_i = rng.i;
+    }
+}
+
 // the bottom entry of every ray's LIFO is a sentinel, so "pop" never needs an emptiness test:
 // popping the sentinel means the traversal is over
 template <class STACK>
@@ -356,8 +381,9 @@ DEV void stage_shade(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cn
     float sign = -dot(rd, normal);                                           // path.py:44-46 (never negative)
     if (sign < 0.0f) normal = -normal;
 
-    Rng rng = lane_rng(p, L);
-    LightSample li = lights_sample(p, hitpos, random3(rng));
+    float u[6];                                                              // path.py:48,58: light triple, then BSDF triple
+    lane_draws<6>(p, L, u);
+    LightSample li = lights_sample(p, hitpos, v3(u[0], u[1], u[2]));
     bool want_shadow = any_gt0(li.color);
     L.direct = v3s(0.0f);
     if (want_shadow) {
@@ -368,8 +394,7 @@ DEV void stage_shade(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cn
         V3 direct_li = li.color * mis * brdf_clr * dot_or_zero(normal, li.dir);
         L.direct = L.throughput * direct_li;
     }
-    BsdfSample brdf = disney_bounce(mat, normal, sign, -rd, random3(rng));
-    L.rng_i = rng.i;
+    BsdfSample brdf = disney_bounce(mat, normal, sign, -rd, v3(u[3], u[4], u[5]));
     L.throughput = L.throughput * brdf.color;
     L.prd = brdf.outdir;
     L.last_brdf_pdf = brdf.pdf;
@@ -385,9 +410,9 @@ DEV void stage_shade(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cn
 template <bool COUNT, class STACK>
 DEV void lane_begin(const MptRenderParams &p, LaneState &L, STACK &stk, int i, int j, Cnt &cnt) {
     L.rng_i = wanghash2(i, j);                                               // path.py:72-73
-    Rng rng = lane_rng(p, L);
-    float dx = rng_random(rng), dy = rng_random(rng);
-    L.rng_i = rng.i;
+    float jit[2];
+    lane_draws<2>(p, L, jit);                                                // random2: dx then dy, path.py:87
+    float dx = jit[0], dy = jit[1];
     float x = m_div((float)i + dx, (float)p.nx) * 2.0f - 1.0f;
     float y = m_div((float)j + dy, (float)p.ny) * 2.0f - 1.0f;
     V3 ro;

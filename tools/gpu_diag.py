@@ -199,10 +199,10 @@ def util(name='s978', spp=32, n=512):
     return res
 
 
-def slabs(name='s978', spp=32, n=512, steps=20, tiles=((3, 3),)):
+def slabs(name='s978', spp=32, n=512, steps=20, tiles=((3, 3),), lds=(1, 0)):
     '''per-rank cost of a 1/N column slab (what one GPU of N does per step, without the gather)'''
     res = {}
-    for parts, tile in [(pp, tt) for pp in (1, 2, 4, 8) for tt in tiles]:
+    for parts, tile, use_lds in [(pp, tt, ll) for pp in (1, 2, 4, 8) for tt in tiles for ll in lds]:
         per = []
         for r in sorted(set((0, parts // 2,))):
             common.reset_all()
@@ -210,6 +210,7 @@ def slabs(name='s978', spp=32, n=512, steps=20, tiles=((3, 3),)):
             eng = setup_engine(scenes.get_scene(name), n, n, mode='fast', slab=(x0, x1))
             c = ctx()
             c.set_option('batch', spp)
+            c.set_option('lds', use_lds)
             c.set_option('tile_w_shift', tile[0])
             c.set_option('tile_h_shift', tile[1])
             eng.render(spp)
@@ -225,7 +226,7 @@ def slabs(name='s978', spp=32, n=512, steps=20, tiles=((3, 3),)):
             dt = (time.perf_counter() - t0) / steps * 1e3
             kms, nl = c.kernel_time()
             per.append({'rank': r, 'step_ms': dt, 'kernel_ms': kms / nl})
-        res[f'{parts}:{tile}'] = per
+        res[f'{parts}:lds{use_lds}'] = per
     common.reset_all()
     return res
 
