@@ -399,3 +399,47 @@ img = FilmTable().get_image()
     img = ns['img']
     assert img.shape == (128, 128, 4) and np.all(img[..., 3] == 1.0) and np.isfinite(img).all()
     assert 0.05 < img[..., :3].mean() < 2.0
+
+
+def test_mid_size_scene_with_environment_vs_oracle(fresh, oracle_mod):
+    '''config-4-shaped case at a size the oracle finishes in seconds: ~7k-triangle displaced blob in
+    the cornell walls, equirect environment texture as world light, gather kernel (scene > LDS)'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    scene = scenes.scene_c4(n_side=24)
+    assert scene[1].shape[0] == 10 + 12 * 24 * 24
+    world = ([1.0, 1.0, 1.0, 1.0], 0)
+    ref = setup_oracle(oracle_mod, scene, 64, 64, world=world)
+    ref.render(8)
+    for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
+        reset_all()
+        eng = _engine(None, scene, 64, 64, mode=mode, world=world)
+        eng.render(8)
+        if mode == 'fast':
+            assert ctx().get_option('last_kernel') == 0
+        assert_parity(FilmTable().get_image(), ref.get_image(), tol, 0.03, 3e-2, what=f'c4-small {mode}')
+    reset_all()
+
+
+def test_large_scene_fast_vs_strict(fresh):
+    '''config 4 at full triangle count (99 382) and a 200k random-triangle soup: device-built LBVH,
+    SAH re-partition (c4) / raw LBVH (soup > sah_max is not reached here, so force it), fast vs strict'''
+    from helpers import assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.sampling.sobol import SobolSampler
+    from ptina_amd.common import ctx, reset_all
+    for scene, world, tree in ((scenes.scene_c4(), ([1.0, 1.0, 1.0, 1.0], 0), 1),
+                               (scenes.scene_random_tris(200000, seed=3), None, 0)):
+        imgs = {}
+        for mode in ('strict', 'fast'):
+            reset_all()
+            from ptina_amd.things import init_things
+            init_things()
+            ctx().set_option('tree', tree)
+            eng = _engine(None, scene, 96, 96, mode=mode, world=world)
+            eng.render(8)
+            imgs[mode] = FilmTable().get_image()
+            assert np.isfinite(imgs[mode]).all() and np.all(imgs[mode][..., 3] == 1)
+        assert_parity(imgs['fast'], imgs['strict'], 1e-3, 0.03, 3e-2, what=f'large scene tree={tree}')
+    reset_all()

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+'''Measure every BASELINE.json configuration that fits one GPU (BASELINE.md section 3's table):
+Msamples/s, counted algorithmic bytes -> GB/s and % of the 8 TB/s HBM peak, traversal counters.
+Writes gpurun_out/configs.json.'''
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np  # noqa: E402
+from ptina_amd import scenes, common  # noqa: E402
+from ptina_amd.common import ctx  # noqa: E402
+from helpers import setup_engine  # noqa: E402
+from bench import algorithmic_bytes  # noqa: E402
+
+CONFIGS = [
+    ('C1 s34 512x512x32', 's34', {}, 512, 32, None),
+    ('C2 s978 512x512x32', 's978', {}, 512, 32, None),
+    ('C3-film s978 2048x2048x64 (one GPU)', 's978', {}, 2048, 64, None),
+    ('C4 99k-tri blob + env light 1024x1024x64', 'c4', {}, 1024, 64, ([1.0, 1.0, 1.0, 1.0], 0)),
+    ('C5 1M random tris 1024x1024x16', 'c5', {'n': 1000000}, 1024, 16, None),
+]
+out = {}
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+for title, name, kw, n, spp, world in CONFIGS:
+    common.reset_all()
+    t0 = time.time()
+    scene = scenes.get_scene(name, **kw)
+    eng = setup_engine(scene, n, n, mode='fast', world=world, max_filmsize=max(n * n, 1 << 21))
+    c = ctx()
+    setup_s = time.time() - t0
+    c.set_option('batch', 32)
+    eng.render(1)
+    c.call('mpt_synchronize')
+    c.set_option('count', 1)
+    c.call('mpt_reset_counters')
+    eng.render(min(spp, 32))
+    cnt = c.counters()
+    c.set_option('count', 0)
+    c.call('mpt_synchronize')
+    c.kernel_time()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        eng.render(spp)
+        c.call('mpt_resolve', 0)
+    c.call('mpt_synchronize')
+    dt = (time.perf_counter() - t0) / reps
+    kms, nl = c.kernel_time()
+    bps = algorithmic_bytes(cnt) / cnt['samples']
+    ms = n * n * spp / dt / 1e6
+    out[title] = {'ntri': int(scene[1].shape[0]), 'setup_s': round(setup_s, 3), 'msamples_s': round(ms, 1),
+                  'ms_per_step': round(dt * 1e3, 3), 'kernel': 'lds' if c.get_option('last_kernel') else 'gather',
+                  'bytes_per_sample': round(bps, 1), 'achieved_GBs': round(bps * ms * 1e6 / 1e9, 1),
+                  'pct_of_8TBs': round(bps * ms * 1e6 / 8e12 * 100, 1),
+                  'rays_per_sample': round(cnt['rays'] / cnt['samples'], 2),
+                  'nodes_per_ray': round(cnt['n_node'] / cnt['rays'], 2), 'tris_per_ray': round(cnt['n_tri'] / cnt['rays'], 2),
+                  'mrays_s': round(cnt['rays'] / cnt['samples'] * ms, 1),
+                  'tree_depth': [c.get_option('tree_depth'), c.get_option('fast_depth')]}
+    print(title, json.dumps(out[title]), flush=True)
+    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'configs.json'), 'w'), indent=1)
+common.reset_all()
