@@ -76,7 +76,9 @@ void mpt_destroy(mpt_ctx *ctx);
  * persistent kernel when the scene fits a CU's 160 KiB LDS, default; 0 = always gather from HBM/L2).
  * "tree" (fast build: 1 = SAH re-partition of the LBVH's leaves, default; 0 = walk the LBVH itself;
  * takes effect at the next mpt_build_tree), "sched_num"/"sched_den" (leave traversal mode when
- * traversing*num < waiting*den), "variant" (A/B switches of the LDS-resident kernel).
+ * traversing*num < waiting*den), "tile_w_shift"/"tile_h_shift" (work-item tile 2^w x 2^h pixels),
+ * "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
+ * walks the LBVH itself).
  * read-only: "tree_depth", "fast_depth", "pending", "last_kernel" (1 = LDS-resident), "num_cus" */
 int mpt_set_option(mpt_ctx *ctx, const char *key, int value);
 int mpt_get_option(mpt_ctx *ctx, const char *key, int *value);

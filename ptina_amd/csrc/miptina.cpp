@@ -22,8 +22,7 @@
 // kernel launchers (render_kernel.hip x2, aux_kernels.hip)
 extern "C" hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
 extern "C" hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
-extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, size_t lds_bytes, int count, int variant,
-                                            hipStream_t);
+extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, size_t lds_bytes, int count, hipStream_t);
 extern "C" hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
 extern "C" hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
 extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
@@ -133,7 +132,6 @@ struct mpt_ctx {
     int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1;
     int num_cus = 256;
     int tile_w_shift = 3, tile_h_shift = 3;   // work-item tile 2^w x 2^h pixels
-    int variant = 0;                     // A/B switch of the LDS-resident kernel (render_kernel.hip VARIANT)
     int sched_num = 2, sched_den = 1;    // scheduler: stay in traversal mode while traversing*num >= waiting*den (tuned on MI355X)
     int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
 
@@ -143,8 +141,6 @@ struct mpt_ctx {
     size_t film_cap = 0;                 // pixels allocated per pass
     MptVec4 *resolved = nullptr;         // nx*ny float4 (get_image staging on device)
     float *exported = nullptr;           // nx*ny*3
-    MptVec4 *partial = nullptr;
-    size_t partial_cap = 0;              // float4 elements
 
     // model (host copy kept for the tree build)
     int nfaces = 0;
@@ -328,7 +324,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     for (auto &pr : c->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto &ev : c->event_pool) hipEventDestroy(ev);
     for (int p = 0; p < 3; p++) hipFree(c->film[p]);
-    hipFree(c->resolved); hipFree(c->exported); hipFree(c->partial);
+    hipFree(c->resolved); hipFree(c->exported);
     hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade);
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
@@ -369,8 +365,6 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         if ((value ? 1 : 0) != c->gpu_build) { c->gpu_build = value ? 1 : 0; c->tree_valid = false; }
     } else if (k == "sah_max") {
         c->sah_max = value; c->tree_valid = false;
-    } else if (k == "variant") {
-        c->variant = value;
     } else if (k == "sched_num") {
         if (value < 1) return fail("sched_num must be >= 1");
         c->sched_num = value;
@@ -604,8 +598,8 @@ struct SahBuild {
         int best_axis = -1, best_k = -1;
         float best_pos = 0.f;
         bool binned = cnt > 8192;
-        std::vector<std::pair<float, int>> key(cnt);
-        std::vector<float> rarea(cnt);
+        std::vector<std::pair<float, int>> key(binned ? 0 : cnt);
+        std::vector<float> rarea(binned ? 0 : cnt);
         float cl[3] = { INFINITY, INFINITY, INFINITY }, ch[3] = { -INFINITY, -INFINITY, -INFINITY };
         for (int t = b; t < e; t++)
             for (int a = 0; a < 3; a++) {
@@ -1230,7 +1224,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(hipEventRecord(e0, rs));
     if (!fast) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, rs));
-    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, c->num_cus, lds_bytes, c->count, c->variant, rs));
+    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, c->num_cus, lds_bytes, c->count, rs));
     else HIP_TRY(mpt_launch_render_fast(&p, c->num_cus, stack, c->count, rs));
     c->last_kernel = lds_kernel ? 1 : 0;
     HIP_TRY(hipEventRecord(e1, rs));

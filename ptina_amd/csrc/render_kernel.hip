@@ -4,28 +4,24 @@
 // Built twice from this one source: MPT_STRICT=1 -> symbols mpt_launch_*_strict,
 // MPT_STRICT=0 -> mpt_launch_*_fast (see pt_device.h).
 //
-// Common to every kernel here (gfx950, wave64):
-//   * a wave owns an 8x8 pixel tile x a chunk of consecutive frames (spp) = a pool of samples;
-//     lanes are NOT tied to pixels: idle lanes are compacted with ballot + mbcnt and handed the
-//     next samples of the pool the moment their path ends (trace_pool), so no lane idles while
-//     its neighbours finish a 5-bounce path;
-//   * every sample's radiance is stored to a [frame][pixel] slab and a combine pass adds the
-//     frames to the film in frame order: the reference's summation order, no float atomics,
-//     bit-reproducible and identical for any slab split across GPUs;
-//   * (strict build only) a lane owns one pixel and sums its frames in a register, in order.
-//
-// render_kernel (any scene size): scene records are gathered from HBM/L2; one 256-lane
-//   workgroup = a 16x16 tile x one chunk; grid = tiles x chunks so the hardware dispatcher
-//   balances thousands of items over 256 CUs; blockIdx is remapped so that the blocks an XCD
-//   receives cover a contiguous run of tiles (its private 4 MiB L2 then holds that region's
-//   subtrees); per-lane traversal stack in LDS, [level][lane].
-//
-// render_kernel_lds (fast build, scenes whose nodes + triangles fit the 160 KiB LDS): measured
-//   on MI355X the gather version spends its time in the vector L1 -- a wave's node fetch touches
-//   up to 64 different cache lines per load instruction, four instructions per node -- so for
-//   small scenes the node and triangle records are copied ONCE per CU into LDS by a persistent
-//   1024-lane workgroup (one per CU), and every traversal step becomes four ds_read_b128.  Waves
-//   then pull (8x8 tile, chunk) work items from a global counter until it runs out.
+// Fast build (gfx950, wave64) -- see trace_stream:
+//   * persistent workgroups pull (8x8 pixel tile, chunk of frames) work items from eight per-XCD queues
+//     with stealing; a wave's item is a pool of samples and lanes are NOT tied to pixels: idle lanes are
+//     compacted with ballot + mbcnt and handed the next samples the moment their path ends;
+//   * the wave runs an in-wave state machine (NODE / LEAF steps in a tight loop, then one SHADE stage
+//     per bounce, then NEW) so that each issued stage has as many ready lanes as possible;
+//   * every sample's radiance is stored to a [frame][pixel] slab and a combine pass adds the frames
+//     to the film in frame order: the reference's summation order, no float atomics, bit-reproducible
+//     and identical for any slab split across GPUs.
+//   render_kernel_fast (any scene size): 256-lane workgroups, 4 waves per SIMD, scene records gathered
+//     from HBM / L2 / Infinity Cache, per-lane int32 traversal stack in LDS, [level][lane].
+//   render_kernel_lds (scenes whose node + triangle records fit the CU's 160 KiB LDS): measured on
+//     MI355X the gather version spends its time in the vector L1 -- a wave's node fetch touches up to 64
+//     different cache lines per load instruction, four instructions per node -- so one persistent
+//     1024-lane workgroup per CU copies the records into LDS once and every traversal step becomes four
+//     ds_read_b128; int16 stacks.
+// Strict build: one lane per pixel, frames summed in a register in order, the reference's traversal;
+//   one 16x16 tile per workgroup, blockIdx remapped so an XCD's blocks cover a contiguous run of tiles.
 
 #include "pt_device.h"
 
@@ -277,42 +273,21 @@ DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, STACK &stk, V3
 // ray triggers happens later, in shading mode, so the traversal loop carries no other live updates.
 // They are written with two flat conditionals each (push / pop) instead of nested ones: on this
 // code the nested form cost more scalar exec-mask bookkeeping than the box arithmetic itself.
-typedef float mpt_f2 __attribute__((ext_vector_type(2)));
-
-// VARIANT bits (A/B switches timed against each other in one process, tools/gpu_diag.py):
-//   1 : box plane distances as six v_pk_fma_f32 instead of twelve v_fma_f32
-//   2 : filter the triangle the ray left from in the leaf stage instead of in the node stage
-template <bool COUNT, int VARIANT, class SCENE, class STACK>
+// (Measured in-process A/B on MI355X and not kept: the twelve plane distances as six v_pk_fma_f32 --
+//  5 % slower, packed f32 is not double-rate here; filtering the origin triangle in the leaf stage
+//  instead of here -- within noise; per-stage instead of ratio scheduler thresholds -- within +-1 %.)
+template <bool COUNT, class SCENE, class STACK>
 DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     MptVec4 a, b, c, d;
     sc.node(L.curr, a, b, c, d);
     int id0 = __float_as_int(d.x), id1 = __float_as_int(d.y);
     if (COUNT) { cnt.n_node++; cnt.n_box += 2; }
     float tn0, tn1;
-    bool h0, h1;
-    if (VARIANT & 1) {
-        mpt_f2 ix = { L.inv.x, L.inv.x }, iy = { L.inv.y, L.inv.y }, iz = { L.inv.z, L.inv.z };
-        mpt_f2 ox = { -L.oinv.x, -L.oinv.x }, oy = { -L.oinv.y, -L.oinv.y }, oz = { -L.oinv.z, -L.oinv.z };
-        mpt_f2 lx = { a.x, a.y }, hx = { a.z, a.w };
-        mpt_f2 ly = { b.x, b.y }, hy = { b.z, b.w };
-        mpt_f2 lz = { c.x, c.y }, hz = { c.z, c.w };
-        mpt_f2 t1x = __builtin_elementwise_fma(lx, ix, ox), t2x = __builtin_elementwise_fma(hx, ix, ox);
-        mpt_f2 t1y = __builtin_elementwise_fma(ly, iy, oy), t2y = __builtin_elementwise_fma(hy, iy, oy);
-        mpt_f2 t1z = __builtin_elementwise_fma(lz, iz, oz), t2z = __builtin_elementwise_fma(hz, iz, oz);
-        tn0 = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fmaxf(fminf(t1z.x, t2z.x), 0.0f));
-        float tf0 = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fminf(fmaxf(t1z.x, t2z.x), L.tbest));
-        tn1 = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fmaxf(fminf(t1z.y, t2z.y), 0.0f));
-        float tf1 = fminf(fminf(fmaxf(t1x.y, t2x.y), fmaxf(t1y.y, t2y.y)), fminf(fmaxf(t1z.y, t2z.y), L.tbest));
-        h0 = tn0 <= tf0; h1 = tn1 <= tf1;
-    } else {
-        h0 = box_fast(a.x, b.x, c.x, a.z, b.z, c.z, L.inv, L.oinv, L.tbest, &tn0);
-        h1 = box_fast(a.y, b.y, c.y, a.w, b.w, c.w, L.inv, L.oinv, L.tbest, &tn1);
-    }
-    if (!(VARIANT & 2)) {
-        // a leaf that is the triangle the ray left from is never tested (lbvh.py:329)
-        h0 = h0 && (~id0 != L.avoid);
-        h1 = h1 && (~id1 != L.avoid);
-    }
+    bool h0 = box_fast(a.x, b.x, c.x, a.z, b.z, c.z, L.inv, L.oinv, L.tbest, &tn0);
+    bool h1 = box_fast(a.y, b.y, c.y, a.w, b.w, c.w, L.inv, L.oinv, L.tbest, &tn1);
+    // a leaf that is the triangle the ray left from is never tested (lbvh.py:329)
+    h0 = h0 && (~id0 != L.avoid);
+    h1 = h1 && (~id1 != L.avoid);
     bool swap = tn1 < tn0;
     int nearid = swap ? id1 : id0, farid = swap ? id0 : id1;
     int next = h0 ? (h1 ? nearid : id0) : id1;
@@ -324,21 +299,19 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     L.st = classify<STACK>(next);
 }
 
-template <bool COUNT, int VARIANT, class SCENE, class STACK>
+template <bool COUNT, class SCENE, class STACK>
 DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     int slot = ~L.curr;
     bool stop = false;
-    if (!(VARIANT & 2) || slot != L.avoid) {                                // lbvh.py:329
-        if (COUNT) cnt.n_tri++;
-        MptVec4 g0, g1, g2, g3;
-        sc.tri(slot, g0, g1, g2, g3);
-        float dd, su, sv;
-        if (tri_test(g0, g1, g2, g3, L.to, L.td, &dd, &su, &sv)) {
-            if (L.shadow) {
-                if (dd <= L.tbest) { L.hit = true; stop = true; }           // path.py:51: any occluder within li.dis
-            } else if (dd < L.tbest) {                                      // lbvh.py:331
-                L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv; L.hit = true;
-            }
+    if (COUNT) cnt.n_tri++;
+    MptVec4 g0, g1, g2, g3;
+    sc.tri(slot, g0, g1, g2, g3);
+    float dd, su, sv;
+    if (tri_test(g0, g1, g2, g3, L.to, L.td, &dd, &su, &sv)) {
+        if (L.shadow) {
+            if (dd <= L.tbest) { L.hit = true; stop = true; }               // path.py:51: any occluder within li.dis
+        } else if (dd < L.tbest) {                                          // lbvh.py:331
+            L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv; L.hit = true;
         }
     }
     stk.sp = L.sp;
@@ -447,7 +420,7 @@ struct WorkQueue {
     }
 };
 
-template <bool COUNT, int VARIANT, class SCENE, class STACK>
+template <bool COUNT, class SCENE, class STACK>
 DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, WorkQueue wq, Cnt &cnt) {
     // work-item tiles are 2^tw_shift x 2^th_shift pixels (8x8 by default; smaller tiles shorten the
     // end-of-launch skew between waves at the price of primary-ray coherence)
@@ -472,44 +445,24 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             break;
         }
         // ---- traversal mode: tight loop while the lanes that are traversing outnumber the waiting ones
-        bool do_shade = true;
-        if (VARIANT & 4) {
-            // stage-specific thresholds: the expensive SHADE stage waits for sched_num lanes, the cheap
-            // hand-overs (shadow ray finished, new sample) for sched_den lanes
-            for (;;) {
-                int cn = wave_count(L.st == ST_NODE);
-                int cl = wave_count(L.st == ST_LEAF);
-                int cs = wave_count(L.st == ST_DONE && !L.shadow);
-                int cw = wave_count((L.st == ST_DONE && L.shadow) || (L.st == ST_NEW && (more || next < S)));
-                if (cn + cl == 0 || cs >= p.sched_num || cw >= p.sched_den) { do_shade = (cn + cl == 0) || cs >= p.sched_num / 2; break; }
-                if (cn >= cl) {
-                    if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
-                    if (L.st == ST_NODE) stage_node<COUNT, VARIANT>(sc, stk, L, cnt);
-                } else {
-                    if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
-                    if (L.st == ST_LEAF) stage_leaf<COUNT, VARIANT>(sc, stk, L, cnt);
-                }
-            }
-        } else {
-            for (;;) {
-                int cn = wave_count(L.st == ST_NODE);
-                int cl = wave_count(L.st == ST_LEAF);
-                int cw = wave_count(L.st == ST_DONE || L.st == ST_NEW);
-                if (cn + cl == 0 || (cn + cl) * p.sched_num < cw * p.sched_den) break;
-                if (cn >= cl) {
-                    if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
-                    if (L.st == ST_NODE) stage_node<COUNT, VARIANT>(sc, stk, L, cnt);
-                } else {
-                    if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
-                    if (L.st == ST_LEAF) stage_leaf<COUNT, VARIANT>(sc, stk, L, cnt);
-                }
+        for (;;) {
+            int cn = wave_count(L.st == ST_NODE);
+            int cl = wave_count(L.st == ST_LEAF);
+            int cw = wave_count(L.st == ST_DONE || L.st == ST_NEW);
+            if (cn + cl == 0 || (cn + cl) * p.sched_num < cw * p.sched_den) break;
+            if (cn >= cl) {
+                if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
+                if (L.st == ST_NODE) stage_node<COUNT>(sc, stk, L, cnt);
+            } else {
+                if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
+                if (L.st == ST_LEAF) stage_leaf<COUNT>(sc, stk, L, cnt);
             }
         }
         // ---- shading mode
         if (wave_count(L.st == ST_DONE && L.shadow) != 0) {
             if (L.st == ST_DONE && L.shadow) stage_shadow_done<COUNT>(p, L, stk, cnt);
         }
-        if (do_shade && wave_count(L.st == ST_DONE && !L.shadow) != 0) {
+        if (wave_count(L.st == ST_DONE && !L.shadow) != 0) {
             if (COUNT && (threadIdx.x & 63) == 0) cnt.it_shade++;
             if (L.st == ST_DONE && !L.shadow) stage_shade<COUNT>(p, L, stk, cnt);
         }
@@ -582,7 +535,7 @@ __global__ MPT_RENDER_BOUNDS void MPT_SUFFIX(render_kernel)(const MptRenderParam
 #else
     // persistent workgroups pulling (8x8 tile, chunk) items; see WorkQueue
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
-    trace_stream<COUNT, 0>(p, tr.sc, tr.st, wq, cnt);
+    trace_stream<COUNT>(p, tr.sc, tr.st, wq, cnt);
 #endif
     flush_counters<COUNT>(p, cnt);
 }
@@ -590,7 +543,7 @@ __global__ MPT_RENDER_BOUNDS void MPT_SUFFIX(render_kernel)(const MptRenderParam
 #if !MPT_STRICT
 // ---------------------------------------------------------------- LDS-resident persistent kernel
 // dynamic LDS: [ (n-1)*4 node float4 | n*4 triangle float4 | lds_stack x 1024 int16 ]
-template <bool COUNT, int VARIANT>
+template <bool COUNT>
 __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRenderParams p) {
     extern __shared__ __attribute__((aligned(16))) MptVec4 smem[];
     const int nnode4 = (p.n - 1) * 4, ntri4 = p.n * 4;
@@ -608,7 +561,7 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
     stk.sp = 0;
     Cnt cnt = {};
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
-    trace_stream<COUNT, VARIANT>(p, sc, stk, wq, cnt);
+    trace_stream<COUNT>(p, sc, stk, wq, cnt);
     flush_counters<COUNT>(p, cnt);
 }
 #endif
@@ -681,27 +634,23 @@ extern "C" hipError_t MPT_SUFFIX(mpt_launch_render)(const MptRenderParams *p, in
 
 #if !MPT_STRICT
 // lds_bytes = scene records + 2 KiB per stack level; grid = one persistent workgroup per CU
-template <bool COUNT, int VARIANT>
+template <bool COUNT>
 static hipError_t launch_lds(const MptRenderParams *p, int grid, size_t lds_bytes, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)render_kernel_lds<COUNT, VARIANT>,
+        hipError_t e = hipFuncSetAttribute((const void *)render_kernel_lds<COUNT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL((render_kernel_lds<COUNT, VARIANT>), dim3(grid), dim3(MPT_LDS_BLOCK), lds_bytes, stream, *p);
+    hipLaunchKernelGGL((render_kernel_lds<COUNT>), dim3(grid), dim3(MPT_LDS_BLOCK), lds_bytes, stream, *p);
     return hipGetLastError();
 }
 
+// lds_bytes = scene records + 2 KiB per stack level; grid = one persistent workgroup per CU
 extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *p, int grid, size_t lds_bytes, int count,
-                                            int variant, hipStream_t stream) {
-    if (count) return variant == 6 ? launch_lds<true, 6>(p, grid, lds_bytes, stream) : launch_lds<true, 2>(p, grid, lds_bytes, stream);
-    switch (variant) {
-    case 6: return launch_lds<false, 6>(p, grid, lds_bytes, stream);
-    case 0: return launch_lds<false, 0>(p, grid, lds_bytes, stream);
-    default: return launch_lds<false, 2>(p, grid, lds_bytes, stream);
-    }
+                                            hipStream_t stream) {
+    return count ? launch_lds<true>(p, grid, lds_bytes, stream) : launch_lds<false>(p, grid, lds_bytes, stream);
 }
 #endif
 

@@ -77,7 +77,7 @@ def timing(name, mode, chunk, steps=5, spp=32, n=512, lds=1, sched=(1, 1)):
             'lds_kernel': lk}
 
 
-def ab(variants=((2, 2, 1), (0, 2, 1), (6, 24, 16)),
+def ab(variants=((0, 2, 1), (0, 3, 2), (0, 1, 1)),
        rounds=5, spp=32, n=512, name='s978'):
     '''interleaved A/B of kernel variants in ONE process (median and min kernel ms)'''
     common.reset_all()
@@ -87,7 +87,6 @@ def ab(variants=((2, 2, 1), (0, 2, 1), (6, 24, 16)),
     res = {v: [] for v in variants}
     for r in range(rounds + 1):
         for v in variants:
-            c.set_option('variant', v[0])
             c.set_option('sched_num', v[1])
             c.set_option('sched_den', v[2])
             eng.render(spp)
@@ -253,8 +252,47 @@ def c3(n=2048, spp=64):
     return {'msamples_s': n * n * spp / dt / 1e6, 'kernel_ms': kms / nl, 'launches': nl, 'film_ok': ok}
 
 
+def c5sah(n=1024, spp=16):
+    '''config 5 with the SAH re-partition forced on (host pass over 1M leaves): build time and rate'''
+    from ptina_amd.things import BVHTree
+    res = {}
+    scene = scenes.get_scene('c5', n=1000000)
+    for sah_max in (1 << 18, 1 << 21):
+        common.reset_all()
+        from ptina_amd.things import init_things
+        init_things()
+        ctx().set_option('sah_max', sah_max)
+        t0 = time.time()
+        eng = setup_engine(scene, n, n, mode='fast')
+        c = ctx()
+        res_key = 'sah' if sah_max > 1000000 else 'lbvh'
+        setup = time.time() - t0
+        c.set_option('batch', 16)
+        eng.render(1)
+        c.call('mpt_synchronize')
+        c.set_option('count', 1)
+        c.call('mpt_reset_counters')
+        eng.render(4)
+        cnt = c.counters()
+        c.set_option('count', 0)
+        c.call('mpt_synchronize')
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.render(spp)
+        c.call('mpt_synchronize')
+        dt = (time.perf_counter() - t0) / 3
+        res[res_key] = {'setup_s': setup, 'msamples_s': n * n * spp / dt / 1e6, 'nodes_per_ray': cnt['n_node'] / cnt['rays'],
+                        'tris_per_ray': cnt['n_tri'] / cnt['rays'], 'depth': c.get_option('fast_depth')}
+        print('c5', res_key, json.dumps(res[res_key]), flush=True)
+    common.reset_all()
+    return res
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'c5sah' in what:
+        out['c5sah'] = c5sah()
+        save()
     if 'c3' in what:
         out['c3'] = c3()
         print('c3 2048x2048', json.dumps(out['c3']), flush=True)

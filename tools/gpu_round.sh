@@ -27,6 +27,7 @@ for step in "$@"; do
     slabs)       run slabs 300 python tools/gpu_diag.py slabs ;;
     c3)          run c3 300 python tools/gpu_diag.py c3 ;;
     configs)     run configs 600 python tools/run_configs.py ;;
+    c5sah)       run c5sah 600 python tools/gpu_diag.py c5sah ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
     tests_all)   run tests_all 900 python -m pytest tests -m gpu -q ;;
     bench)       run bench 600 python bench.py ;;
