@@ -443,3 +443,54 @@ def test_large_scene_fast_vs_strict(fresh):
             assert np.isfinite(imgs[mode]).all() and np.all(imgs[mode][..., 3] == 1)
         assert_parity(imgs['fast'], imgs['strict'], 1e-3, 0.03, 3e-2, what=f'large scene tree={tree}')
     reset_all()
+
+
+def test_gltf_compat_materials_parity(fresh, oracle_mod):
+    '''materials as the reference's glTF loader leaves them: only base colour / metallic /
+    roughness set, the other nine Disney parameters at zero -- specular 0, ior 0 (eta = 1/0)'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
+    v, m, _, _ = scenes.scene_s978()
+    mats = [scenes.gltf_compat_material((0.8, 0.8, 0.8), 0.0, 0.5), scenes.gltf_compat_material((0.8, 0.05, 0.05), 0.0, 0.5),
+            scenes.gltf_compat_material((0.05, 0.8, 0.05), 0.0, 0.5), scenes.gltf_compat_material((0.8, 0.6, 0.2), 0.1, 0.3)]
+    scene = (v, m, mats, [])
+    ref = setup_oracle(oracle_mod, scene, 64, 64)
+    ref.render(16)
+    want = ref.get_image()
+    assert np.isfinite(want).all()
+    for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
+        reset_all()
+        eng = _engine(None, scene, 64, 64, mode=mode)
+        eng.render(16)
+        assert_parity(FilmTable().get_image(), want, tol, 0.02, 2e-2, what=f'gltf-compat {mode}')
+    reset_all()
+
+
+def test_many_lights(fresh, oracle_mod):
+    '''a full light pool (64 lights, alternating POINT / AREA): first-hit-in-index-order semantics of
+    LightPool.hit and the samp.z light pick of LightPool._sample'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.tools.matrix import translate
+    from ptina_amd.common import reset_all
+    rng = np.random.default_rng(11)
+    rot = np.eye(4)
+    rot[:3, :3] = [[1, 0, 0], [0, 0, 1], [0, -1, 0]]
+    lights = []
+    for k in range(64):
+        pos = rng.uniform([-1.6, 2.2, -1.6], [1.6, 3.8, 1.6])
+        col = rng.uniform(0.5, 3.0, 3)
+        if k % 2:
+            lights.append((translate(pos) @ rot, col * 4, 0.15, 'AREA'))
+        else:
+            lights.append((translate(pos), col, 0.1, 'POINT'))
+    scene = scenes.scene_s34()
+    ref = setup_oracle(oracle_mod, scene, 48, 48, lights=lights)
+    ref.render(16)
+    for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
+        reset_all()
+        eng = _engine(None, scene, 48, 48, mode=mode, lights=lights)
+        eng.render(16)
+        assert_parity(FilmTable().get_image(), ref.get_image(), tol, 0.03, 3e-2, what=f'64 lights {mode}')
+    reset_all()
