@@ -24,6 +24,22 @@ if f:
     shutil.copy(f, os.path.join(dst, f'{tag}_kernel_stats.csv'))
     print('kernel stats ->', f'{tag}_kernel_stats.csv')
 
+f = newest('prof/*/*kernel_trace.csv')
+if f:
+    rows = [r for r in csv.DictReader(open(f)) if 'render_kernel' in r['Kernel_Name']]
+    with open(os.path.join(dst, f'{tag}_render_dispatches.csv'), 'w') as fh:
+        fh.write('dispatch,kernel,duration_us,start_ns,end_ns,grid,workgroup,lds_bytes,vgprs,sgprs,scratch\n')
+        durs = []
+        for r in rows:
+            dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+            durs.append(dur)
+            fh.write(f"{r['Dispatch_Id']},\"{r['Kernel_Name']}\",{dur:.1f},{r['Start_Timestamp']},{r['End_Timestamp']},"
+                     f"{r['Grid_Size_X']},{r['Workgroup_Size_X']},{r['LDS_Block_Size']},{r['VGPR_Count']},{r['SGPR_Count']},{r['Scratch_Size']}\n")
+    med = sorted(durs)[len(durs) // 2] if durs else 0
+    full = [d for d in durs if 0.7 * med < d < 1.3 * med]
+    print('render dispatches ->', f'{tag}_render_dispatches.csv', '| launches within 30% of the median:', len(full),
+          'avg ms:', round(sum(full) / max(len(full), 1) / 1e3, 4))
+
 summary = {}
 for d in ('pmc1', 'pmc2', 'pmc3', 'pmc4'):
     f = newest(f'{d}/*/*counter_collection.csv')
