@@ -195,7 +195,9 @@ def main():
         total = NX * NY * SPP * args.steps
         value = total / dt / 1e6
         avg_kernel_s = kms / 1e3 / max(nlaunch, 1)
-        achieved = bytes_per_launch / avg_kernel_s / 1e9
+        # small launches (N > 1 slabs) take 1/G of the CUs each and G of them are resident at once
+        concurrent = max(c.get_option('cur_div'), 1)
+        achieved = bytes_per_launch * concurrent / avg_kernel_s / 1e9
         out = {
             'metric': 'Msamples/sec (pixels x spp / s), 512x512x32spp cornell-monkey (978 tri)',
             'value': round(value, 3), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps,
@@ -208,7 +210,7 @@ def main():
                          'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': measured_traffic(),
                          'kernel': ('render_kernel_lds' if c.get_option('last_kernel') else 'render_kernel_fast')
                          if args.mode == 'fast' else 'render_kernel_strict',
-                         'avg_kernel_ms': round(avg_kernel_s * 1e3, 4), 'launches': nlaunch,
+                         'avg_kernel_ms': round(avg_kernel_s * 1e3, 4), 'launches': nlaunch, 'concurrent_launches': concurrent,
                          'algorithmic_bytes_per_launch': int(bytes_per_launch),
                          'bytes_per_sample': round(bytes_per_launch / (cnt['samples'] / W), 2),
                          'note': 'algorithmic bytes (SURVEY 8d) over kernel time; the 125 KB of nodes+triangles are '

@@ -142,6 +142,9 @@ int mpt_resolve(mpt_ctx *ctx, int pass);
 
 /* measurement */
 int mpt_get_counters(mpt_ctx *ctx, mpt_counters *out);
+/* Diagnostics (option "timeline" = 1): per wave of the last LDS-kernel launch, four 100 MHz timestamps
+ * {start, scene copied to LDS, work queues found empty, exit}.  *nwaves = waves recorded. */
+int mpt_get_timeline(mpt_ctx *ctx, unsigned long long *out /* [cap_waves][4] */, int cap_waves, int *nwaves);
 int mpt_reset_counters(mpt_ctx *ctx);
 /* HIP-event time of the render kernels launched since the last call (ms) and their count */
 int mpt_kernel_time(mpt_ctx *ctx, double *ms, int *launches);

@@ -69,6 +69,7 @@ SIGNATURES = {
     'mpt_get_film_raw': (_i, [_vp, _i, _fp]),
     'mpt_resolve': (_i, [_vp, _i]),
     'mpt_get_counters': (_i, [_vp, C.POINTER(Counters)]),
+    'mpt_get_timeline': (_i, [_vp, C.POINTER(C.c_ulonglong), _i, C.POINTER(_i)]),
     'mpt_reset_counters': (_i, [_vp]),
     'mpt_kernel_time': (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     'mpt_comm_unique_id': (_i, [C.c_char_p]),

@@ -22,7 +22,7 @@
 // kernel launchers (render_kernel.hip x2, aux_kernels.hip)
 extern "C" hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
 extern "C" hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
-extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, size_t lds_bytes, int count, hipStream_t);
+extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
 extern "C" hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
 extern "C" hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
 extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
@@ -122,14 +122,22 @@ static int rccl_load() {
         if (r_ != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(r_));  \
     } while (0)
 
+// Up to MPT_MAX_PIPE render streams, the main stream and the aux stream carry work at the same time.
+// The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told
+// otherwise) and streams that share one are serialised, so ask for more before the runtime starts --
+// unless the user has chosen a value.
+__attribute__((constructor)) static void mpt_want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 // ------------------------------------------------------------------ context
+enum { MPT_MAX_PIPE = 6 };
+
 struct mpt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     mpt_caps caps{};
 
     // options
-    int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1;
+    int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1, lds_block = 0;
     int num_cus = 256;
     int tile_w_shift = 3, tile_h_shift = 3;   // work-item tile 2^w x 2^h pixels
     int sched_num = 2, sched_den = 1;    // scheduler: stay in traversal mode while traversing*num >= waiting*den (tuned on MI355X)
@@ -190,19 +198,26 @@ struct mpt_ctx {
 
     // launch pipelining (fast build): batch i renders on rstream[i & 1] into partial[i & 1] while the main
     // stream still combines / gathers / resolves batch i-1, so one launch's tail overlaps the next one's head
-    hipStream_t rstream[2] = { nullptr, nullptr };
-    hipEvent_t ev_render[2] = { nullptr, nullptr };   // render of the batch on rstream[k] finished
-    hipEvent_t ev_free[2] = { nullptr, nullptr };     // combine has consumed partial[k]
-    hipEvent_t ev_sobol = nullptr;                    // latest Sobol advance (X state hand-over between streams)
+    hipStream_t rstream[MPT_MAX_PIPE] = {};
+    hipEvent_t ev_render[MPT_MAX_PIPE] = {};          // render of the batch on rstream[k] finished
+    hipEvent_t ev_free[MPT_MAX_PIPE] = {};            // combine has consumed partial[k]
+    hipStream_t aux = nullptr;                        // Sobol advances + queue resets of the pipelined batches
+    hipEvent_t ev_sobol2[MPT_MAX_PIPE] = {};          // Sobol points + zeroed queue heads of the batch on rstream[k] ready
+    int pipe_depth = 0;                               // batches in flight (slots of P / partial / queue heads); 0 = auto
+    int grid_div = 0;                                 // each launch takes 1/grid_div of the CUs; 0 = auto
+    int cur_depth = 2, cur_div = 1;                   // what the last launch used
     hipEvent_t ev_main = nullptr;                     // main-stream work a render must see (uploads, resets, ...)
     bool main_dirty = true;
     int flip = 0;
-    MptVec4 *partial2[2] = { nullptr, nullptr };
-    size_t partial2_cap = 0;                          // float4 elements per buffer
-    float *sP2[2] = { nullptr, nullptr };
-    unsigned int *d_work2[2] = { nullptr, nullptr };
+    MptVec4 *partial2[MPT_MAX_PIPE] = {};
+    size_t partial2_cap[MPT_MAX_PIPE] = {};           // float4 elements per buffer
+    float *sP2[MPT_MAX_PIPE] = {};
+    unsigned int *d_work2[MPT_MAX_PIPE] = {};
 
     // measurement
+    int timeline = 0;                    // 1: the LDS kernel records per-wave timestamps of its last launch
+    unsigned long long *d_timeline = nullptr;
+    int timeline_waves = 0;
     unsigned long long *d_counters = nullptr;
     unsigned int *d_work = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -250,6 +265,12 @@ static int upload_lights(mpt_ctx *c) {
     return 0;
 }
 
+static int make_render_streams(mpt_ctx *c) {
+    for (int k = 0; k < MPT_MAX_PIPE; k++)
+        if (!c->rstream[k]) HIP_TRY(hipStreamCreateWithFlags(&c->rstream[k], hipStreamNonBlocking));
+    return 0;
+}
+
 extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -279,20 +300,21 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (dev_alloc(&c->d_counters, 12)) return bail("counters");
     if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
     if (dev_alloc(&c->d_work, 16)) return bail("work counters");   // 8 queue heads + [8] watchdog flag
-    for (int k = 0; k < 2; k++) {
-        if (hipStreamCreateWithFlags(&c->rstream[k], hipStreamNonBlocking) != hipSuccess) return bail("render stream");
+    for (int k = 0; k < MPT_MAX_PIPE; k++) {
+        if (hipEventCreateWithFlags(&c->ev_sobol2[k], hipEventDisableTiming) != hipSuccess) return bail("event");
         if (hipEventCreateWithFlags(&c->ev_render[k], hipEventDisableTiming) != hipSuccess) return bail("event");
         if (hipEventCreateWithFlags(&c->ev_free[k], hipEventDisableTiming) != hipSuccess) return bail("event");
         if (dev_alloc(&c->d_work2[k], 16)) return bail("work counters");
         hipMemsetAsync(c->d_work2[k], 0, 16 * sizeof(unsigned int), c->stream);
     }
-    if (hipEventCreateWithFlags(&c->ev_sobol, hipEventDisableTiming) != hipSuccess) return bail("event");
+    if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) return bail("aux stream");
     if (hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess) return bail("event");
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             c->num_cus = prop.multiProcessorCount;
     }
+    if (make_render_streams(c)) return bail("render streams");
     hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), c->stream);
     hipMemsetAsync(c->d_work, 0, 16 * sizeof(unsigned int), c->stream);
     {   // unset materials: factor 0 (field-zero, mtllib.py:12-13), texture -1 (deviation Q6)
@@ -310,16 +332,18 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
 extern "C" void mpt_destroy(mpt_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
-    for (int k = 0; k < 2; k++) if (c->rstream[k]) hipStreamSynchronize(c->rstream[k]);
+    for (int k = 0; k < MPT_MAX_PIPE; k++) if (c->rstream[k]) hipStreamSynchronize(c->rstream[k]);
+    if (c->aux) { hipStreamSynchronize(c->aux); }
     hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    for (int k = 0; k < 2; k++) {
+    if (c->aux) hipStreamDestroy(c->aux);
+    for (int k = 0; k < MPT_MAX_PIPE; k++) {
         if (c->rstream[k]) hipStreamDestroy(c->rstream[k]);
         if (c->ev_render[k]) hipEventDestroy(c->ev_render[k]);
         if (c->ev_free[k]) hipEventDestroy(c->ev_free[k]);
+        if (c->ev_sobol2[k]) hipEventDestroy(c->ev_sobol2[k]);
         hipFree(c->partial2[k]); hipFree(c->sP2[k]); hipFree(c->d_work2[k]);
     }
-    if (c->ev_sobol) hipEventDestroy(c->ev_sobol);
     if (c->ev_main) hipEventDestroy(c->ev_main);
     for (auto &pr : c->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto &ev : c->event_pool) hipEventDestroy(ev);
@@ -328,7 +352,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade);
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
-    hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work);
+    hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
     hipFree(c->d_verts); hipFree(c->d_mtlids); hipFree(c->d_cen); hipFree(c->d_bounds); hipFree(c->d_depth);
     hipFree(c->d_keys_in); hipFree(c->d_keys_out); hipFree(c->d_sort_tmp);
     hipFree(c->d_child); hipFree(c->d_parent); hipFree(c->d_leaf); hipFree(c->d_mc);
@@ -355,6 +379,18 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->count = value ? 1 : 0;
     } else if (k == "lds") {
         c->use_lds = value ? 1 : 0;
+    } else if (k == "timeline") {
+        c->timeline = value ? 1 : 0;
+    } else if (k == "pipe_depth") {
+        if (value != 0 && (value < 2 || value > MPT_MAX_PIPE)) return fail("pipe_depth must be 0 (auto) or 2..%d", MPT_MAX_PIPE);
+        c->pipe_depth = value;
+    } else if (k == "grid_div") {
+        if (value < 0 || value > 8) return fail("grid_div must be 0 (auto) or 1..8");
+        c->grid_div = value;
+    } else if (k == "lds_block") {
+        if (value != 0 && value != 256 && value != 512 && value != 768 && value != 1024)
+            return fail("lds_block must be 0 (auto), 256, 512, 768 or 1024");
+        c->lds_block = value;
     } else if (k == "tree") {
         if (value != 0 && value != 1) return fail("tree must be 0 (LBVH) or 1 (SAH)");
         if (value != c->tree_kind) { c->tree_kind = value; c->tree_valid = false; }
@@ -390,6 +426,11 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "gpu_build") *value = c->gpu_build;
     else if (k == "pending") *value = c->pending;
     else if (k == "lds") *value = c->use_lds;
+    else if (k == "lds_block") *value = c->lds_block;
+    else if (k == "pipe_depth") *value = c->pipe_depth;
+    else if (k == "grid_div") *value = c->grid_div;
+    else if (k == "cur_depth") *value = c->cur_depth;
+    else if (k == "cur_div") *value = c->cur_div;
     else if (k == "last_kernel") *value = c->last_kernel;
     else if (k == "num_cus") *value = c->num_cus;
     else return fail("unknown option '%s'", k.c_str());
@@ -1059,10 +1100,12 @@ extern "C" int mpt_sobol_init(mpt_ctx *c, const int32_t *V, int rows, int dim) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     c->sV = c->sX = nullptr; c->sP = nullptr;
-    for (int k = 0; k < 2; k++) { HIP_TRY(hipStreamSynchronize(c->rstream[k])); hipFree(c->sP2[k]); c->sP2[k] = nullptr; }
+    HIP_TRY(hipStreamSynchronize(c->aux));
+    for (int k = 0; k < MPT_MAX_PIPE; k++) { HIP_TRY(hipStreamSynchronize(c->rstream[k])); hipFree(c->sP2[k]); c->sP2[k] = nullptr; }
     if (dev_alloc(&c->sV, (size_t)rows * dim) || dev_alloc(&c->sX, (size_t)dim) ||
-        dev_alloc(&c->sP, (size_t)MPT_MAX_BATCH * dim) || dev_alloc(&c->sP2[0], (size_t)MPT_MAX_BATCH * dim) ||
-        dev_alloc(&c->sP2[1], (size_t)MPT_MAX_BATCH * dim)) return 1;
+        dev_alloc(&c->sP, (size_t)MPT_MAX_BATCH * dim)) return 1;
+    for (int k = 0; k < MPT_MAX_PIPE; k++)
+        if (dev_alloc(&c->sP2[k], (size_t)MPT_MAX_BATCH * dim)) return 1;
     HIP_TRY(hipMemcpyAsync(c->sV, V, (size_t)rows * dim * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->sX, 0, (size_t)dim * sizeof(int), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1160,24 +1203,46 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     if (fill_params(c, p, B)) return 1;
     const bool fast = c->mode == MPT_MODE_FAST;
     // fast build: this batch runs on its own stream; strict build: everything stays on the main stream
-    const int k = fast ? (c->flip++ & 1) : 0;
+    if (fast) {
+        // A launch ends with a drain of about one path latency (~0.4 ms on MI355X for depth-5 paths)
+        // in which its lanes run empty one by one; a persistent workgroup leaves only when its
+        // slowest lane has.  A launch that owns every CU pays that on every CU.  Small launches
+        // therefore take 1/G of the CUs each and G of them are resident at once, in different
+        // phases: the drain then idles 1/G of the chip.  (Measured, 1/8 film slab of 512x512x32:
+        // 1.03 ms per step with G=1, 0.78 with G=2, 0.73 with G=4; whole film: 4.69 / 4.62 / 4.84.)
+        const double per_lane = (double)B * (c->x1 - c->x0) * c->ny / ((double)c->num_cus * 1024.0);
+        int div = c->grid_div > 0 ? c->grid_div : (per_lane >= 24.0 ? 1 : per_lane >= 6.0 ? 2 : 4);
+        int depth = c->pipe_depth > 0 ? c->pipe_depth : (div == 1 ? 2 : std::min(div + 2, (int)MPT_MAX_PIPE));
+        if (depth != c->cur_depth) {
+            // slots are reused round-robin: let everything in flight finish before the ring changes size
+            HIP_TRY(hipStreamSynchronize(c->aux));
+            for (int q = 0; q < MPT_MAX_PIPE; q++) HIP_TRY(hipStreamSynchronize(c->rstream[q]));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->flip = 0;
+        }
+        c->cur_depth = depth; c->cur_div = div;
+    }
+    const int k = fast ? (c->flip++ % c->cur_depth) : 0;
     hipStream_t rs = fast ? c->rstream[k] : c->stream;
+    // fast build: the Sobol points and the zeroed queue heads of this batch are prepared on the aux
+    // stream (never behind a render kernel), the render itself goes to rstream[k]
+    hipStream_t ss = fast ? c->aux : c->stream;
     if (fast) {
         if (c->main_dirty) {       // uploads / resets / option changes enqueued on the main stream come first
             HIP_TRY(hipEventRecord(c->ev_main, c->stream));
             c->main_dirty = false;
         }
+        HIP_TRY(hipStreamWaitEvent(ss, c->ev_main, 0));
+        HIP_TRY(hipStreamWaitEvent(ss, c->ev_render[k], 0));   // the batch that last read sP2[k] / d_work2[k]
         HIP_TRY(hipStreamWaitEvent(rs, c->ev_main, 0));
-        HIP_TRY(hipStreamWaitEvent(rs, c->ev_sobol, 0));     // X state of the previous batch's advance
         p.P = c->sP2[k];
     }
     if (p.ntiles == 0) {
-        if (sobol_advance(c, B, 0, rs, fast ? c->sP2[k] : nullptr)) return 1;
-        if (fast) { HIP_TRY(hipEventRecord(c->ev_sobol, rs)); HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sobol, 0)); }
+        if (sobol_advance(c, B, 0, ss, fast ? c->sP2[k] : nullptr)) return 1;
+        if (fast) { HIP_TRY(hipEventRecord(c->ev_sobol2[k], ss)); HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sobol2[k], 0)); }
         return 0;
     }
-    if (sobol_advance(c, B, B, rs, fast ? c->sP2[k] : nullptr)) return 1;
-    if (fast) HIP_TRY(hipEventRecord(c->ev_sobol, rs));
+    if (sobol_advance(c, B, B, ss, fast ? c->sP2[k] : nullptr)) return 1;
 
     const int stack = ((c->mode == MPT_MODE_STRICT ? c->tree_depth : c->fast_depth) + 2 <= 32) ? 32 : 64;
     // LDS-resident kernel: node + triangle records + a 16-bit stack of (depth+1) levels x 1024
@@ -1210,22 +1275,36 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     if (fast) {
         // one float4 per sample: [frame][pixel]; the combine pass sums frames in order
         size_t need = (size_t)B * c->nx * c->ny;
-        if (need > c->partial2_cap) {
+        if (need > c->partial2_cap[k]) {
             HIP_TRY(hipDeviceSynchronize());
-            for (int q = 0; q < 2; q++) { hipFree(c->partial2[q]); c->partial2[q] = nullptr; }
-            if (dev_alloc(&c->partial2[0], need) || dev_alloc(&c->partial2[1], need)) return 1;
-            c->partial2_cap = need;
+            hipFree(c->partial2[k]); c->partial2[k] = nullptr; c->partial2_cap[k] = 0;
+            if (dev_alloc(&c->partial2[k], need)) return 1;
+            c->partial2_cap[k] = need;
         }
         p.partial = c->partial2[k];
         p.work_counter = c->d_work2[k];
+        HIP_TRY(hipMemsetAsync(c->d_work2[k], 0, 8 * sizeof(unsigned int), ss));   // [8] (watchdog flag) is sticky
+        HIP_TRY(hipEventRecord(c->ev_sobol2[k], ss));
+        HIP_TRY(hipStreamWaitEvent(rs, c->ev_sobol2[k], 0));
         HIP_TRY(hipStreamWaitEvent(rs, c->ev_free[k], 0));   // combine of the batch that last used partial[k]
-        HIP_TRY(hipMemsetAsync(c->d_work2[k], 0, 8 * sizeof(unsigned int), rs));   // [8] (watchdog flag) is sticky
+    }
+    p.timeline = nullptr;
+    if (c->timeline && lds_kernel) {
+        const int block = c->lds_block ? c->lds_block : 1024;
+        const int waves = ((c->num_cus + c->cur_div - 1) / c->cur_div) * (block / 64);
+        if (waves != c->timeline_waves) {
+            HIP_TRY(hipDeviceSynchronize());
+            hipFree(c->d_timeline); c->d_timeline = nullptr;
+            if (dev_alloc(&c->d_timeline, (size_t)waves * 4)) return 1;
+            c->timeline_waves = waves;
+        }
+        p.timeline = c->d_timeline;
     }
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(hipEventRecord(e0, rs));
     if (!fast) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, rs));
-    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, c->num_cus, lds_bytes, c->count, rs));
-    else HIP_TRY(mpt_launch_render_fast(&p, c->num_cus, stack, c->count, rs));
+    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, (c->num_cus + c->cur_div - 1) / c->cur_div, c->lds_block ? c->lds_block : 1024, lds_bytes, c->count, rs));
+    else HIP_TRY(mpt_launch_render_fast(&p, (c->num_cus + c->cur_div - 1) / c->cur_div, stack, c->count, rs));
     c->last_kernel = lds_kernel ? 1 : 0;
     HIP_TRY(hipEventRecord(e1, rs));
     c->events.push_back({ e0, e1 });
@@ -1278,12 +1357,12 @@ extern "C" int mpt_render_preview(mpt_ctx *c, int nframes) {                   /
 
 // a persistent render kernel that had to be stopped by its watchdog leaves a flag behind
 static int check_watchdog(mpt_ctx *c) {
-    unsigned int flag = 0, f2[2] = { 0, 0 };
+    unsigned int flag = 0, f2[MPT_MAX_PIPE] = {};
     HIP_TRY(hipMemcpyAsync(&flag, c->d_work + 8, sizeof flag, hipMemcpyDeviceToHost, c->stream));
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < MPT_MAX_PIPE; k++)
         HIP_TRY(hipMemcpyAsync(&f2[k], c->d_work2[k] + 8, sizeof flag, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    flag |= f2[0] | f2[1];
+    for (int k = 0; k < MPT_MAX_PIPE; k++) flag |= f2[k];
     if (flag) return fail("render kernel stopped by its watchdog (scheduler made no progress): film is incomplete");
     return 0;
 }
@@ -1291,7 +1370,8 @@ static int check_watchdog(mpt_ctx *c) {
 extern "C" int mpt_synchronize(mpt_ctx *c) {                                   // worker.py:17-18
     if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
-    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(c->rstream[k]));
+    HIP_TRY(hipStreamSynchronize(c->aux));
+    for (int k = 0; k < MPT_MAX_PIPE; k++) HIP_TRY(hipStreamSynchronize(c->rstream[k]));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return check_watchdog(c);
 }
@@ -1359,6 +1439,18 @@ extern "C" int mpt_get_counters(mpt_ctx *c, mpt_counters *out) {
     return 0;
 }
 
+// diagnostics: out[wave][4] = {start, scene ready, queue empty, exit} of the last LDS-kernel launch, 100 MHz ticks
+extern "C" int mpt_get_timeline(mpt_ctx *c, unsigned long long *out, int cap_waves, int *nwaves) {
+    if (use_ro(c)) return 1;
+    if (mpt_synchronize(c)) return 1;
+    if (!c->d_timeline) return fail("no timeline recorded: set option 'timeline' and render with the LDS kernel");
+    int n = std::min(cap_waves, c->timeline_waves);
+    if (out && n > 0)
+        HIP_TRY(hipMemcpy(out, c->d_timeline, (size_t)n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (nwaves) *nwaves = c->timeline_waves;
+    return 0;
+}
+
 extern "C" int mpt_reset_counters(mpt_ctx *c) {
     if (use(c)) return 1;
     if (mpt_flush(c)) return 1;
@@ -1369,7 +1461,8 @@ extern "C" int mpt_reset_counters(mpt_ctx *c) {
 extern "C" int mpt_kernel_time(mpt_ctx *c, double *ms, int *launches) {
     if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
-    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(c->rstream[k]));
+    HIP_TRY(hipStreamSynchronize(c->aux));
+    for (int k = 0; k < MPT_MAX_PIPE; k++) HIP_TRY(hipStreamSynchronize(c->rstream[k]));
     HIP_TRY(hipStreamSynchronize(c->stream));
     double total = 0;
     for (auto &pr : c->events) {

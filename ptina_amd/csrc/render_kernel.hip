@@ -421,7 +421,8 @@ struct WorkQueue {
 };
 
 template <bool COUNT, class SCENE, class STACK>
-DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, WorkQueue wq, Cnt &cnt) {
+DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, WorkQueue wq, Cnt &cnt,
+                      unsigned long long *tl = nullptr) {
     // work-item tiles are 2^tw_shift x 2^th_shift pixels (8x8 by default; smaller tiles shorten the
     // end-of-launch skew between waves at the price of primary-ray coherence)
     const int tws = p.tile_w_shift, ths = p.tile_h_shift, tps = tws + ths;
@@ -470,8 +471,10 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
         if (m_new != 0ull) {
             if (next >= S && more) {                // pool drained: fetch the next work item right away,
                 int item = wq.pull();               // while the other lanes are still busy (no per-item tail)
-                if (item < 0) more = false;
-                else {
+                if (item < 0) {
+                    more = false;
+                    if (tl && (threadIdx.x & 63) == 0) tl[2] = wall_clock64();
+                } else {
                     int tile = item / p.nchunks, chunk = item - tile * p.nchunks;
                     int tx = tile / t8y, ty = tile - tx * t8y;
                     ti = p.x0 + (tx << tws); tj = ty << ths;
@@ -547,11 +550,14 @@ template <bool COUNT>
 __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRenderParams p) {
     extern __shared__ __attribute__((aligned(16))) MptVec4 smem[];
     const int nnode4 = (p.n - 1) * 4, ntri4 = p.n * 4;
+    unsigned long long *tl = p.timeline ? p.timeline + 4 * (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
+    if (tl && (threadIdx.x & 63) == 0) tl[0] = wall_clock64();
     {   // one copy of the scene per CU: coalesced 16-B loads, ds_write_b128
-        for (int k = threadIdx.x; k < nnode4; k += MPT_LDS_BLOCK) smem[k] = p.fnode[k];
-        for (int k = threadIdx.x; k < ntri4; k += MPT_LDS_BLOCK) smem[nnode4 + k] = p.tgeo[k];
+        for (int k = threadIdx.x; k < nnode4; k += blockDim.x) smem[k] = p.fnode[k];
+        for (int k = threadIdx.x; k < ntri4; k += blockDim.x) smem[nnode4 + k] = p.tgeo[k];
     }
     __syncthreads();
+    if (tl && (threadIdx.x & 63) == 0) tl[1] = wall_clock64();
 
     LdsScene sc;
     sc.fnode = (LdsVec4Ptr)(void *)smem;
@@ -561,7 +567,8 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
     stk.sp = 0;
     Cnt cnt = {};
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
-    trace_stream<COUNT>(p, sc, stk, wq, cnt);
+    trace_stream<COUNT>(p, sc, stk, wq, cnt, tl);
+    if (tl && (threadIdx.x & 63) == 0) tl[3] = wall_clock64();
     flush_counters<COUNT>(p, cnt);
 }
 #endif
@@ -635,7 +642,7 @@ extern "C" hipError_t MPT_SUFFIX(mpt_launch_render)(const MptRenderParams *p, in
 #if !MPT_STRICT
 // lds_bytes = scene records + 2 KiB per stack level; grid = one persistent workgroup per CU
 template <bool COUNT>
-static hipError_t launch_lds(const MptRenderParams *p, int grid, size_t lds_bytes, hipStream_t stream) {
+static hipError_t launch_lds(const MptRenderParams *p, int grid, int block, size_t lds_bytes, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void *)render_kernel_lds<COUNT>,
@@ -643,14 +650,14 @@ static hipError_t launch_lds(const MptRenderParams *p, int grid, size_t lds_byte
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL((render_kernel_lds<COUNT>), dim3(grid), dim3(MPT_LDS_BLOCK), lds_bytes, stream, *p);
+    hipLaunchKernelGGL((render_kernel_lds<COUNT>), dim3(grid), dim3(block), lds_bytes, stream, *p);
     return hipGetLastError();
 }
 
 // lds_bytes = scene records + 2 KiB per stack level; grid = one persistent workgroup per CU
-extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *p, int grid, size_t lds_bytes, int count,
+extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *p, int grid, int block, size_t lds_bytes, int count,
                                             hipStream_t stream) {
-    return count ? launch_lds<true>(p, grid, lds_bytes, stream) : launch_lds<false>(p, grid, lds_bytes, stream);
+    return count ? launch_lds<true>(p, grid, block, lds_bytes, stream) : launch_lds<false>(p, grid, block, lds_bytes, stream);
 }
 #endif
 

@@ -230,6 +230,101 @@ def slabs(name='s978', spp=32, n=512, steps=20, tiles=((3, 3),), lds=(1, 0)):
     return res
 
 
+def blk(name='s978', spp=32, n=512, steps=20, opt='lds_block', values=(1024, 768, 512, 256)):
+    '''an option (threads per persistent workgroup, reserved CUs) vs launch size: pipelined step and solo kernel time'''
+    res = {}
+    for parts in (1, 2, 4, 8):
+        for block in values:
+            common.reset_all()
+            r = parts // 2
+            eng = setup_engine(scenes.get_scene(name), n, n, mode='fast', slab=(r * n // parts, (r + 1) * n // parts))
+            c = ctx()
+            c.set_option('batch', spp)
+            c.set_option(opt, block)
+            eng.render(spp)
+            c.call('mpt_synchronize')
+            c.kernel_time()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.render(spp)
+                c.call('mpt_flush')
+                c.call('mpt_resolve', 0)
+            c.call('mpt_synchronize')
+            dt = (time.perf_counter() - t0) / steps * 1e3
+            c.kernel_time()
+            for _ in range(5):
+                eng.render(spp)
+                c.call('mpt_synchronize')
+            kms, nl = c.kernel_time()
+            res[f'{parts}:{block}'] = {'step_ms': round(dt, 4), 'solo_kernel_ms': round(kms / nl, 4)}
+            print(opt, parts, block, res[f'{parts}:{block}'], flush=True)
+    common.reset_all()
+    return res
+
+
+def pipe(name='s978', spp=32, n=512, steps=30):
+    '''launches of 1/G of the CUs, D batches in flight: pipelined step time per slab size'''
+    res = {}
+    for parts in (1, 2, 4, 8):
+        for depth, div in ((0, 0), (2, 1), (4, 2), (6, 4)):
+            common.reset_all()
+            r = parts // 2
+            eng = setup_engine(scenes.get_scene(name), n, n, mode='fast', slab=(r * n // parts, (r + 1) * n // parts))
+            c = ctx()
+            c.set_option('batch', spp)
+            c.set_option('pipe_depth', depth)
+            c.set_option('grid_div', div)
+            for _ in range(6):
+                eng.render(spp)
+            c.call('mpt_synchronize')
+            c.kernel_time()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.render(spp)
+                c.call('mpt_flush')
+                c.call('mpt_resolve', 0)
+            c.call('mpt_synchronize')
+            dt = (time.perf_counter() - t0) / steps * 1e3
+            kms, nl = c.kernel_time()
+            res[f'{parts}:D{depth}G{div}'] = {'step_ms': round(dt, 4), 'kernel_ms': round(kms / nl, 4)}
+            print('pipe parts', parts, 'depth', depth, 'grid_div', div, res[f'{parts}:D{depth}G{div}'], flush=True)
+    common.reset_all()
+    return res
+
+
+def timeline(name='s978', spp=32, n=512):
+    '''per-wave timestamps of one solo launch: when the queues ran dry and when waves / workgroups left'''
+    import ctypes as C
+    res = {}
+    for parts in (1, 8):
+        common.reset_all()
+        r = parts // 2
+        eng = setup_engine(scenes.get_scene(name), n, n, mode='fast', slab=(r * n // parts, (r + 1) * n // parts))
+        c = ctx()
+        c.set_option('batch', spp)
+        c.set_option('timeline', 1)
+        for kv in filter(None, os.environ.get('MIPTINA_OPTS', '').split(',')):
+            c.set_option(kv.split('=')[0], int(kv.split('=')[1]))
+        for _ in range(3):
+            eng.render(spp)
+            c.call('mpt_synchronize')
+        nw = C.c_int(0)
+        buf = (C.c_ulonglong * (4 * 4096))()
+        c.call('mpt_get_timeline', buf, 4096, C.byref(nw))
+        t = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4)[:nw.value].astype(np.int64)
+        t0 = t[:, 0].min()
+        us = (t - t0) / 100.0
+        wg_exit = us[:, 3].reshape(-1, 16).max(axis=1)
+        q = lambda a: [round(float(x), 1) for x in np.percentile(a, [0, 10, 50, 90, 100])]
+        res[str(parts)] = {'start': q(us[:, 0]), 'ready': q(us[:, 1]), 'queue_empty': q(us[:, 2]),
+                           'wave_exit': q(us[:, 3]), 'wg_exit': q(wg_exit),
+                           'wave_drain': q(us[:, 3] - us[:, 2]),
+                           'lane_time_after_empty_frac': float((us[:, 3] - us[:, 2]).sum() / (us[:, 3] - us[:, 0]).sum())}
+        print('timeline', parts, json.dumps(res[str(parts)]), flush=True)
+    common.reset_all()
+    return res
+
+
 def c3(n=2048, spp=64):
     '''config 3's film on one GPU: S978 at 2048x2048 (needs max_filmsize = 2^22)'''
     common.reset_all()
@@ -301,6 +396,15 @@ if __name__ == '__main__':
         out['slabs'] = slabs()
         for k, v in out['slabs'].items():
             print('slabs', k, json.dumps(v), flush=True)
+        save()
+    if 'blk' in what:
+        out['blk'] = blk()
+        save()
+    if 'timeline' in what:
+        out['timeline'] = timeline()
+        save()
+    if 'pipe' in what:
+        out['pipe'] = pipe()
         save()
     if 'util' in what:
         out['util'] = util()

@@ -25,6 +25,9 @@ for step in "$@"; do
     big)         run big 900 python tools/gpu_diag.py big ;;
     util)        run util 300 python tools/gpu_diag.py util ;;
     slabs)       run slabs 300 python tools/gpu_diag.py slabs ;;
+    blk)         run blk 300 python tools/gpu_diag.py blk ;;
+    pipe)        run pipe 400 python tools/gpu_diag.py pipe ;;
+    timeline)    run timeline 300 python tools/gpu_diag.py timeline ;;
     c3)          run c3 300 python tools/gpu_diag.py c3 ;;
     configs)     run configs 600 python tools/run_configs.py ;;
     c5sah)       run c5sah 600 python tools/gpu_diag.py c5sah ;;
@@ -34,6 +37,8 @@ for step in "$@"; do
     prof)        (cd /tmp; run_dir=$GRAFT_REPO_ROOT/gpurun_out/prof; rm -rf $run_dir; mkdir -p $run_dir;
                   cd $GRAFT_REPO_ROOT;
                   run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline) ;;
+    slabtrace)   (run_dir=$GRAFT_REPO_ROOT/gpurun_out/slabtrace; rm -rf $run_dir; mkdir -p $run_dir;
+                  run slabtrace 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/slabtrace -- python3 tools/slab_trace.py 8 4 20) ;;
     counters)    rocprofv3 -L > gpurun_out/counters_list.txt 2>&1; echo "counters listed" ;;
     pmc1)        run pmc1 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     pmc2)        run pmc2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
