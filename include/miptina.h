@@ -78,8 +78,12 @@ void mpt_destroy(mpt_ctx *ctx);
  * takes effect at the next mpt_build_tree), "sched_num"/"sched_den" (leave traversal mode when
  * traversing*num < waiting*den), "tile_w_shift"/"tile_h_shift" (work-item tile 2^w x 2^h pixels),
  * "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
- * walks the LBVH itself).
- * read-only: "tree_depth", "fast_depth", "pending", "last_kernel" (1 = LDS-resident), "num_cus" */
+ * walks the LBVH itself), "grid_div" (each launch takes 1/G of the CUs so that G launches are resident
+ * in different phases; 0 = choose by samples per lane, default), "pipe_depth" (batches in flight,
+ * 2..6; 0 = auto), "lds_block" (lanes per persistent workgroup of the LDS kernel, diagnostics),
+ * "timeline" (1 = record mpt_get_timeline data).
+ * read-only: "tree_depth", "fast_depth", "pending", "last_kernel" (1 = LDS-resident), "num_cus",
+ * "cur_div", "cur_depth" (what the last launch used) */
 int mpt_set_option(mpt_ctx *ctx, const char *key, int value);
 int mpt_get_option(mpt_ctx *ctx, const char *key, int *value);
 

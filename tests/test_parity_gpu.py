@@ -175,6 +175,32 @@ def test_slabs_reassemble_bit_identically(fresh):
     assert np.all(full[..., 3] == spp)
 
 
+def test_launch_pipelining_does_not_change_the_film(fresh):
+    '''G launches on 1/G of the CUs each, D batches in flight: same film bit for bit, any G and D,
+    including batches of different sizes back to back (the ring of slots is resized in between)'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    nx, ny = 96, 80
+    films = {}
+    for depth, div in ((2, 1), (0, 0), (3, 2), (6, 4), (4, 8)):
+        reset_all()
+        eng = _engine(None, scenes.scene_s978(), nx, ny, mode='fast')
+        c = ctx()
+        c.set_option('pipe_depth', depth)
+        c.set_option('grid_div', div)
+        c.set_option('batch', 8)
+        for frames in (8, 8, 3, 8, 1, 8, 8, 8):
+            eng.render(frames)
+            c.call('mpt_flush')
+        films[(depth, div)] = FilmTable().get_raw().copy()
+        assert c.get_option('cur_div') == (div if div else 4)      # tiny film: auto picks the smallest launches
+    reset_all()
+    ref = films[(2, 1)]
+    assert np.all(ref.reshape(nx, ny, 4)[..., 3] == 52)
+    for key, film in films.items():
+        assert np.array_equal(film, ref), key
+
+
 def test_lights_and_area_light_parity(fresh, oracle_mod):
     from helpers import setup_oracle, assert_parity
     from ptina_amd.things import FilmTable
