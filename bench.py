@@ -137,7 +137,7 @@ def main():
     c.set_option('batch', SPP)
     comm = RcclFilm(rank, world) if (world > 1 or args.force_comm) else None
     if comm:
-        comm.set_slab(NX)
+        comm.set_stripes(NX)                  # every world-th stripe of 16 columns: even load
 
     def step():
         eng.render(SPP)                       # 32 x (Sobol update + 1 spp), one fused launch
@@ -205,7 +205,7 @@ def main():
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.scene}: 978-tri synthetic cornell + bumpy sphere, {NX}x{NY}, {SPP} spp, '
                                    'unidirectional MIS path tracer, depth<=5', 'film': [NX, NY], 'spp': SPP,
-                       'mode': args.mode, 'parallelism': f'film column slabs x{world}' if world > 1 else 'single GPU'},
+                       'mode': args.mode, 'parallelism': f'film columns in 16-wide stripes over {world} GPUs, RCCL gather' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': measured_traffic(),
                          'kernel': ('render_kernel_lds' if c.get_option('last_kernel') else 'render_kernel_fast')

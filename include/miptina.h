@@ -92,6 +92,10 @@ int mpt_set_size(mpt_ctx *ctx, int nx, int ny);
 int mpt_get_size(mpt_ctx *ctx, int *nx, int *ny);
 /* multi-GPU: this context renders film columns x in [x0, x1) only (no reference counterpart) */
 int mpt_set_slab(mpt_ctx *ctx, int x0, int x1);
+/* Deal the film out in stripes of `width` columns (a multiple of 16): this context renders stripes index,
+ * index + modulo, ...  The multi-GPU split with even load; mpt_comm_gather_film follows it when every
+ * rank r of R called mpt_set_stripes(width, r, R).  mpt_set_slab / mpt_set_size return to one slab. */
+int mpt_set_stripes(mpt_ctx *ctx, int width, int index, int modulo);
 
 /* ModelPool.from_numpy, ptina/model.py:54-60: verts [3n][8] = pos3 nrm3 uv2, mtlids [n] or NULL (= -1) */
 int mpt_load_model(mpt_ctx *ctx, const float *verts, const int32_t *mtlids, int n);

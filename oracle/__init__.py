@@ -81,6 +81,7 @@ def load(f64=False):
     sig('orc_set_threads', None, vp, C.c_int)
     sig('orc_set_size', None, vp, C.c_int, C.c_int)
     sig('orc_set_window', None, vp, C.c_int, C.c_int)
+    sig('orc_set_stripes', None, vp, C.c_int, C.c_int, C.c_int)
     sig('orc_load_model', C.c_int, vp, fp, ip, C.c_int)
     sig('orc_load_materials', C.c_int, vp, fp, ip, C.c_int)
     sig('orc_reset_images', None, vp)
@@ -188,6 +189,9 @@ class Oracle:
 
     def set_window(self, x0, x1):
         self.lib.orc_set_window(self.ctx, x0, x1)
+
+    def set_stripes(self, width, index, modulo):
+        self.lib.orc_set_stripes(self.ctx, width, index, modulo)
 
     def load_model(self, vertices, mtlids=None):
         v = np.ascontiguousarray(vertices, np.float32)

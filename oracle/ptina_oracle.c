@@ -642,6 +642,7 @@ struct orc_ctx {
     int nthreads;
     /* film, filmtable.py:12-14 : 3 passes of float4[nx*ny], element x*ny + y */
     int nx, ny, wx0, wx1;
+    int sw, spitch;             /* striped window: columns x >= wx0 with (x - wx0) % spitch < sw; sw = 0: all */
     v4 *film[3];
     /* model, model.py:11-14 */
     int nfaces;
@@ -708,10 +709,15 @@ void orc_set_size(orc_ctx *c, int nx, int ny) {
             c->film[p] = (v4 *)calloc((size_t)nx * ny, sizeof(v4));
         }
     }
-    c->nx = nx; c->ny = ny; c->wx0 = 0; c->wx1 = nx;
+    c->nx = nx; c->ny = ny; c->wx0 = 0; c->wx1 = nx; c->sw = 0; c->spitch = 1;
 }
 
-void orc_set_window(orc_ctx *c, int x0, int x1) { c->wx0 = x0; c->wx1 = x1; }
+void orc_set_window(orc_ctx *c, int x0, int x1) { c->wx0 = x0; c->wx1 = x1; c->sw = 0; c->spitch = 1; }
+/* the share of rank `index` of `modulo` when the film is dealt out in stripes of `width` columns */
+void orc_set_stripes(orc_ctx *c, int width, int index, int modulo) {
+    c->wx0 = index * width; c->wx1 = c->nx; c->sw = width; c->spitch = width * modulo;
+}
+static int window_has(const orc_ctx *c, int i) { return c->sw == 0 || (i - c->wx0) % c->spitch < c->sw; }
 
 int orc_load_model(orc_ctx *c, const float *verts, const int32_t *mtlids, int n) {  /* model.py:54-60 */
     free(c->vertices); free(c->mtlids);
@@ -1361,6 +1367,7 @@ void orc_render(orc_ctx *c) {                                                /* 
 #pragma omp for schedule(dynamic, 1) nowait
 #endif
         for (int i = c->wx0; i < c->wx1; i++) {
+            if (!window_has(c, i)) continue;
             for (int j = 0; j < ny; j++) {
                 v3 clr = do_render_pixel(c, i, j, &local);
                 v4 *px = &c->film[0][(size_t)i * ny + j];   /* filmtable.py:37-39 */
@@ -1381,6 +1388,7 @@ void orc_render_preview(orc_ctx *c) {                                        /* 
     int ny = c->ny;
     orc_counters dummy; memset(&dummy, 0, sizeof dummy);
     for (int i = c->wx0; i < c->wx1; i++) {
+        if (!window_has(c, i)) continue;
         for (int j = 0; j < ny; j++) {
             rng_t rng; rng.c = c; rng.i = orc_wanghash2(i, j); rng.draws = 0;
             v3 albedo = V3s(0), normal = V3s(0);

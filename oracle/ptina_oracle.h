@@ -86,6 +86,7 @@ void orc_set_threads(orc_ctx *c, int nthreads);        /* OpenMP threads for ren
 
 void orc_set_size(orc_ctx *c, int nx, int ny);                         /* filmtable.py:41 */
 void orc_set_window(orc_ctx *c, int x0, int x1);       /* render only x in [x0,x1) (slab tests) */
+void orc_set_stripes(orc_ctx *c, int width, int index, int modulo);   /* ... only stripes index, index+modulo, ... */
 int  orc_load_model(orc_ctx *c, const float *verts /*[3n][8]*/, const int32_t *mtlids, int n);
 int  orc_load_materials(orc_ctx *c, const float *fac /*[m][12][4]*/, const int32_t *tex /*[m][12]*/, int m);
 void orc_reset_images(orc_ctx *c);

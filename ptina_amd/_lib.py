@@ -45,6 +45,7 @@ SIGNATURES = {
     'mpt_set_size': (_i, [_vp, _i, _i]),
     'mpt_get_size': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     'mpt_set_slab': (_i, [_vp, _i, _i]),
+    'mpt_set_stripes': (_i, [_vp, _i, _i, _i]),
     'mpt_load_model': (_i, [_vp, _fp, _ip, _i]),
     'mpt_load_materials': (_i, [_vp, _fp, _ip, _i]),
     'mpt_reset_images': (_i, [_vp]),

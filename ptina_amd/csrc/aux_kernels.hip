@@ -48,11 +48,14 @@ __global__ __launch_bounds__(256) void sobol_update_kernel(int *__restrict__ X, 
 // film[pix] += sample[0][pix], then sample[1][pix], ... : the reference's frame-by-frame
 // accumulation order (filmtable.py:37-39, path.py:93), one sample slab per frame of the batch
 __global__ __launch_bounds__(256) void combine_kernel(MptVec4 *__restrict__ film, const MptVec4 *__restrict__ partial,
-                                                      int nx, int ny, int x0, int x1, int nchunks) {
+                                                      int nx, int ny, int x0, int x1, int stripe_w,
+                                                      int stripe_pitch, int nchunks) {
     size_t npix = (size_t)nx * ny;
     size_t lo = (size_t)x0 * ny, hi = (size_t)x1 * ny;
     size_t t = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= hi) return;
+    // striped share: only the columns this context rendered carry samples
+    if (((int)(t / ny) - x0) % stripe_pitch >= stripe_w) return;
     MptVec4 a = film[t];
     for (int c = 0; c < nchunks; c++) {
         MptVec4 b = partial[(size_t)c * npix + t];
@@ -100,11 +103,11 @@ extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, in
 }
 
 extern "C" hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
-                                         int nchunks, hipStream_t stream) {
+                                         int stripe_w, int stripe_pitch, int nchunks, hipStream_t stream) {
     size_t n = (size_t)(x1 - x0) * ny;
     if (n == 0) return hipSuccess;
     int grid = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(combine_kernel, dim3(grid), dim3(256), 0, stream, film, partial, nx, ny, x0, x1, nchunks);
+    hipLaunchKernelGGL(combine_kernel, dim3(grid), dim3(256), 0, stream, film, partial, nx, ny, x0, x1, stripe_w, stripe_pitch, nchunks);
     return hipGetLastError();
 }
 

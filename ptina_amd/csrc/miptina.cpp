@@ -28,6 +28,7 @@ extern "C" hipError_t mpt_launch_preview_strict(const MptRenderParams *, int gri
 extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
                                               int keep, hipStream_t);
 extern "C" hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
+                                         int stripe_w, int stripe_pitch,
                                          int nchunks, hipStream_t);
 extern "C" hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
 extern "C" hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
@@ -145,6 +146,7 @@ struct mpt_ctx {
 
     // film
     int nx = 0, ny = 0, x0 = 0, x1 = 0;
+    int stripe_w = 0, stripe_idx = 0, stripe_mod = 1;   // stripe_w > 0: columns dealt out in stripes (mpt_set_stripes)
     MptVec4 *film[3] = { nullptr, nullptr, nullptr };
     size_t film_cap = 0;                 // pixels allocated per pass
     MptVec4 *resolved = nullptr;         // nx*ny float4 (get_image staging on device)
@@ -460,7 +462,7 @@ extern "C" int mpt_set_size(mpt_ctx *c, int nx, int ny) {
     }
     // the reference keeps one flat buffer and only changes `res` (filmtable.py:41-42): stale sums
     // of another resolution are the caller's to clear(); same here.
-    c->nx = nx; c->ny = ny; c->x0 = 0; c->x1 = nx;
+    c->nx = nx; c->ny = ny; c->x0 = 0; c->x1 = nx; c->stripe_w = 0; c->stripe_idx = 0; c->stripe_mod = 1;
     return 0;
 }
 
@@ -476,7 +478,38 @@ extern "C" int mpt_set_slab(mpt_ctx *c, int x0, int x1) {
     if (mpt_flush(c)) return 1;
     if (x0 < 0 || x1 > c->nx || x0 > x1) return fail("slab [%d,%d) outside film width %d", x0, x1, c->nx);
     c->x0 = x0; c->x1 = x1;
+    c->stripe_w = 0; c->stripe_idx = 0; c->stripe_mod = 1;
     return 0;
+}
+
+// The film dealt out in stripes of `width` columns: this context renders stripes index, index + modulo,
+// ...  A contiguous slab per GPU leaves the GPUs unevenly loaded (the centre columns of a Cornell view
+// cost 25 % more than the outer ones); interleaved stripes even that out.
+extern "C" int mpt_set_stripes(mpt_ctx *c, int width, int index, int modulo) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    if (c->nx <= 0) return fail("film size not set: call set_size() first");
+    if (width <= 0 || width % MPT_TILE != 0) return fail("stripe width must be a positive multiple of %d", MPT_TILE);
+    if (modulo < 1 || index < 0 || index >= modulo) return fail("stripe index %d outside [0, %d)", index, modulo);
+    if ((long long)width * modulo > (1 << 30)) return fail("stripe pitch too large");
+    c->stripe_w = width; c->stripe_idx = index; c->stripe_mod = modulo;
+    c->x0 = std::min((long long)index * width, (long long)c->nx); c->x1 = c->nx;
+    return 0;
+}
+
+// columns of this context's share, and its tile columns for tiles `tile` pixels wide
+static void share_extent(const mpt_ctx *c, int tile, long long *cols, int *tile_cols) {
+    long long n = 0; int t = 0;
+    if (c->stripe_w == 0) {
+        n = c->x1 - c->x0; t = (c->x1 - c->x0 + tile - 1) / tile;
+    } else {
+        for (long long x = (long long)c->stripe_idx * c->stripe_w; x < c->nx; x += (long long)c->stripe_w * c->stripe_mod) {
+            int w = (int)std::min<long long>(c->stripe_w, c->nx - x);
+            n += w; t += (w + tile - 1) / tile;
+        }
+    }
+    if (cols) *cols = n;
+    if (tile_cols) *tile_cols = t;
 }
 
 // ------------------------------------------------------------------ scene upload
@@ -1171,7 +1204,9 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     p.nx = c->nx; p.ny = c->ny; p.x0 = c->x0; p.x1 = c->x1;
     p.nframes = nframes; p.n = c->nfaces;
     p.sobol_dim = c->sdim; p.nlights = (int)c->h_lights.size(); p.world_tex = c->world_tex;
-    p.tiles_x = (c->x1 - c->x0 + MPT_TILE - 1) / MPT_TILE;
+    share_extent(c, MPT_TILE, nullptr, &p.tiles_x);
+    p.stripe_w = c->stripe_w ? c->stripe_w : (1 << 30);
+    p.stripe_pitch = c->stripe_w ? c->stripe_w * c->stripe_mod : (1 << 30);
     p.tiles_y = (c->ny + MPT_TILE - 1) / MPT_TILE;
     p.ntiles = p.tiles_x * p.tiles_y;
     memcpy(p.world_fac, c->world_fac, sizeof p.world_fac);
@@ -1210,7 +1245,9 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         // therefore take 1/G of the CUs each and G of them are resident at once, in different
         // phases: the drain then idles 1/G of the chip.  (Measured, 1/8 film slab of 512x512x32:
         // 1.03 ms per step with G=1, 0.78 with G=2, 0.73 with G=4; whole film: 4.69 / 4.62 / 4.84.)
-        const double per_lane = (double)B * (c->x1 - c->x0) * c->ny / ((double)c->num_cus * 1024.0);
+        long long cols = 0;
+        share_extent(c, 1, &cols, nullptr);
+        const double per_lane = (double)B * cols * c->ny / ((double)c->num_cus * 1024.0);
         int div = c->grid_div > 0 ? c->grid_div : (per_lane >= 24.0 ? 1 : per_lane >= 6.0 ? 2 : 4);
         int depth = c->pipe_depth > 0 ? c->pipe_depth : (div == 1 ? 2 : std::min(div + 2, (int)MPT_MAX_PIPE));
         if (depth != c->cur_depth) {
@@ -1253,7 +1290,9 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     const bool lds_kernel = fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && lds_bytes <= 160 * 1024;
     int chunk = B, nchunks = 1;
     const int tw = 1 << c->tile_w_shift, th = 1 << c->tile_h_shift;
-    const int tiles8 = ((c->x1 - c->x0 + tw - 1) / tw) * ((c->ny + th - 1) / th);
+    int tile_cols = 0;
+    share_extent(c, tw, nullptr, &tile_cols);
+    const int tiles8 = tile_cols * ((c->ny + th - 1) / th);
     if (fast) {
         chunk = c->chunk;
         if (chunk <= 0) {
@@ -1275,12 +1314,15 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     if (fast) {
         // one float4 per sample: [frame][pixel]; the combine pass sums frames in order
         size_t need = (size_t)B * c->nx * c->ny;
-        if (need > c->partial2_cap[k]) {
-            HIP_TRY(hipDeviceSynchronize());
-            hipFree(c->partial2[k]); c->partial2[k] = nullptr; c->partial2_cap[k] = 0;
-            if (dev_alloc(&c->partial2[k], need)) return 1;
-            c->partial2_cap[k] = need;
-        }
+        // every slot of the ring at once: an allocation synchronises the device, so it must not
+        // happen again on the second, third, ... batch of a run
+        for (int q = 0; q < c->cur_depth; q++)
+            if (need > c->partial2_cap[q]) {
+                HIP_TRY(hipDeviceSynchronize());
+                hipFree(c->partial2[q]); c->partial2[q] = nullptr; c->partial2_cap[q] = 0;
+                if (dev_alloc(&c->partial2[q], need)) return 1;
+                c->partial2_cap[q] = need;
+            }
         p.partial = c->partial2[k];
         p.work_counter = c->d_work2[k];
         HIP_TRY(hipMemsetAsync(c->d_work2[k], 0, 8 * sizeof(unsigned int), ss));   // [8] (watchdog flag) is sticky
@@ -1313,7 +1355,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         // ordered after this render; the next batch, on the other stream, is not
         HIP_TRY(hipEventRecord(c->ev_render[k], rs));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_render[k], 0));
-        HIP_TRY(mpt_launch_combine(c->film[0], c->partial2[k], c->nx, c->ny, c->x0, c->x1, B, c->stream));
+        HIP_TRY(mpt_launch_combine(c->film[0], c->partial2[k], c->nx, c->ny, c->x0, c->x1, p.stripe_w, p.stripe_pitch, B, c->stream));
         HIP_TRY(hipEventRecord(c->ev_free[k], c->stream));
     }
     return 0;
@@ -1509,18 +1551,36 @@ extern "C" int mpt_comm_gather_film(mpt_ctx *c, int pass, int root) {
     if (mpt_flush(c)) return 1;
     if (check_pass(c, pass)) return 1;
     if (!c->comm) return fail("communicator not initialised");
-    // slab bounds follow the same split on every rank: x in [r*nx/R, (r+1)*nx/R)
+    // every rank holds the same split: contiguous slabs x in [r*nx/R, (r+1)*nx/R), or -- after
+    // mpt_set_stripes(width, rank, R) -- stripes r, r+R, ... of `width` columns; each piece is one
+    // contiguous float4 range (film index x*ny + y) and travels as its own send/recv of one group
     const int R = c->nranks;
+    if (c->stripe_w && (c->stripe_mod != R || c->stripe_idx != c->rank))
+        return fail("stripes (index %d of %d) do not match the communicator (rank %d of %d)", c->stripe_idx,
+                    c->stripe_mod, c->rank, R);
+    auto pieces = [&](int r, std::vector<std::pair<size_t, size_t>> &out) {
+        out.clear();
+        if (c->stripe_w == 0) {
+            size_t lo = (size_t)((long long)r * c->nx / R) * c->ny, hi = (size_t)((long long)(r + 1) * c->nx / R) * c->ny;
+            if (hi > lo) out.push_back({ lo, hi - lo });
+        } else {
+            for (long long x = (long long)r * c->stripe_w; x < c->nx; x += (long long)c->stripe_w * R) {
+                long long w = std::min<long long>(c->stripe_w, c->nx - x);
+                out.push_back({ (size_t)x * c->ny, (size_t)w * c->ny });
+            }
+        }
+    };
+    std::vector<std::pair<size_t, size_t>> pc;
     NCCL_TRY(g_rccl.GroupStart());
     if (c->rank == root) {
         for (int r = 0; r < R; r++) {
             if (r == root) continue;
-            size_t lo = (size_t)((long long)r * c->nx / R) * c->ny, hi = (size_t)((long long)(r + 1) * c->nx / R) * c->ny;
-            if (hi > lo) NCCL_TRY(g_rccl.Recv(c->film[pass] + lo, (hi - lo) * 4, ncclFloat, r, c->comm, c->stream));
+            pieces(r, pc);
+            for (auto &q : pc) NCCL_TRY(g_rccl.Recv(c->film[pass] + q.first, q.second * 4, ncclFloat, r, c->comm, c->stream));
         }
     } else {
-        size_t lo = (size_t)((long long)c->rank * c->nx / R) * c->ny, hi = (size_t)((long long)(c->rank + 1) * c->nx / R) * c->ny;
-        if (hi > lo) NCCL_TRY(g_rccl.Send(c->film[pass] + lo, (hi - lo) * 4, ncclFloat, root, c->comm, c->stream));
+        pieces(c->rank, pc);
+        for (auto &q : pc) NCCL_TRY(g_rccl.Send(c->film[pass] + q.first, q.second * 4, ncclFloat, root, c->comm, c->stream));
     }
     NCCL_TRY(g_rccl.GroupEnd());
     return 0;

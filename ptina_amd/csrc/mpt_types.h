@@ -49,6 +49,8 @@ struct MptRenderParams {
     int32_t sobol_dim, nlights, world_tex, tiles_x;   // tiles_* : 16x16 tiles of the slab (strict build)
     int32_t tiles_y, ntiles, sched_num, sched_den;  // leave traversal mode when traversing*num < waiting*den
     int32_t nitems, tile_w_shift, tile_h_shift, pad2;   // fast build: (2^w x 2^h tile, chunk) work items of this launch
+    // columns rendered: x = x0 + s*stripe_pitch + w, w < stripe_w, x < x1 (one contiguous slab: stripe_w = 2^30)
+    int32_t stripe_w, stripe_pitch, pad3, pad4;
     float world_fac[4];
     float v2w[16];
     const MptVec4 *snode;

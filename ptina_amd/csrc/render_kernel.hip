@@ -477,7 +477,8 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 } else {
                     int tile = item / p.nchunks, chunk = item - tile * p.nchunks;
                     int tx = tile / t8y, ty = tile - tx * t8y;
-                    ti = p.x0 + (tx << tws); tj = ty << ths;
+                    int tps_x = p.stripe_w >> tws, st = tx / tps_x;      // stripe of this tile column
+                    ti = p.x0 + st * p.stripe_pitch + ((tx - st * tps_x) << tws); tj = ty << ths;
                     f0 = chunk * p.chunk;
                     S = (min(f0 + p.chunk, p.nframes) - f0) << tps;
                     next = 0;
@@ -513,7 +514,8 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
 DEV bool tile_pixel(const MptRenderParams &p, int tile, int *pi, int *pj) {
     int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int i = p.x0 + tx * MPT_TILE + (wave >> 1) * 8 + (lane >> 3);
+    int tps_x = p.stripe_w / MPT_TILE, st = tx / tps_x;                       // stripe of this tile column
+    int i = p.x0 + st * p.stripe_pitch + (tx - st * tps_x) * MPT_TILE + (wave >> 1) * 8 + (lane >> 3);
     int j = ty * MPT_TILE + (wave & 1) * 8 + (lane & 7);
     *pi = i; *pj = j;
     return i < p.x1 && j < p.ny;

@@ -1,7 +1,9 @@
 '''
-multi-GPU film tiling: one process per GPU, each renders a contiguous slab of film columns of
-a replicated scene; one gather of slab buffers to rank 0.  The reference has no
-multi-device code at all, so this module has no counterpart there.
+multi-GPU film tiling: one process per GPU, each renders its share of the film columns of a
+replicated scene -- one contiguous slab, or (default of bench.py) every world-th stripe of 16
+columns, which evens out the load -- and one gather of those column ranges to rank 0
+(SURVEY.md 8e).  The reference has no multi-device code at all, so this module
+has no counterpart there.
 
 Film index is x*ny + y (reference filmtable.py:38): the columns [x0, x1) of a slab are one
 contiguous float4 range, and because pixel hashes use global (i, j) and every rank advances the
@@ -23,6 +25,15 @@ import numpy as np
 def slab_bounds(nx, world, rank):
     '''columns [x0, x1) of `rank`; the same split libmiptina uses in mpt_comm_gather_film'''
     return rank * nx // world, (rank + 1) * nx // world
+
+
+STRIPE = 16     # columns per stripe: the strict build's tile width, two work-item tiles of the fast build
+
+
+def stripe_columns(nx, world, rank, width=STRIPE):
+    '''columns of `rank` when the film is dealt out in stripes (mpt_set_stripes(width, rank, world))'''
+    x = np.arange(nx)
+    return x[(x // width) % world == rank]
 
 
 def env_rank():
@@ -91,6 +102,10 @@ class RcclFilm:
         self.ctx.call('mpt_set_slab', x0, x1)
         return x0, x1
 
+    def set_stripes(self, nx, width=STRIPE):
+        self.ctx.call('mpt_set_stripes', int(width), self.rank, self.world)
+        return stripe_columns(nx, self.world, self.rank, width)
+
     def gather(self, id=0, root=0):
         if self.world > 1:
             self.ctx.call('mpt_comm_gather_film', int(id), int(root))
@@ -108,17 +123,25 @@ class RcclFilm:
         self.ctx.call('mpt_comm_destroy')
 
 
-def gather_film_torch(film_raw, nx, ny, rank, world, root=0):
+def gather_film_torch(film_raw, nx, ny, rank, world, root=0, stripe=None):
     '''host-array gather through torch.distributed: film_raw is this rank's [nx*ny, 4] raw
-    film of which only its slab is meaningful; returns the assembled film on root'''
+    film of which only its share (slab, or stripes of `stripe` columns) is meaningful; returns the
+    assembled film on root'''
     import torch
     import torch.distributed as dist
-    x0, x1 = slab_bounds(nx, world, rank)
-    mine = torch.from_numpy(np.ascontiguousarray(film_raw.reshape(nx, ny, 4)[x0:x1]))
-    sizes = [slab_bounds(nx, world, r) for r in range(world)]
+    if stripe:
+        cols = [stripe_columns(nx, world, r, stripe) for r in range(world)]
+    else:
+        cols = [np.arange(*slab_bounds(nx, world, r)) for r in range(world)]
+    most = max(len(c) for c in cols)               # gloo's gather wants equal shapes: pad
+    mine = torch.zeros((most, ny, 4), dtype=torch.float32)
+    mine[:len(cols[rank])] = torch.from_numpy(np.ascontiguousarray(film_raw.reshape(nx, ny, 4)[cols[rank]]))
     if rank == root:
-        bufs = [torch.empty((b - a, ny, 4), dtype=torch.float32) for a, b in sizes]
+        bufs = [torch.empty((most, ny, 4), dtype=torch.float32) for _ in cols]
         dist.gather(mine, bufs, dst=root)
-        return np.concatenate([b.numpy() for b in bufs], axis=0).reshape(nx * ny, 4)
+        out = np.zeros((nx, ny, 4), np.float32)
+        for c, b in zip(cols, bufs):
+            out[c] = b.numpy()[:len(c)]
+        return out.reshape(nx * ny, 4)
     dist.gather(mine, None, dst=root)
     return None

@@ -24,6 +24,16 @@ def test_slab_bounds_partition():
             assert max(x1 - x0 for x0, x1 in b) - min(x1 - x0 for x0, x1 in b) <= 1
 
 
+def test_stripe_columns_partition():
+    from ptina_amd.dist import stripe_columns
+    for nx in (1, 7, 50, 512, 2048):
+        for world in (1, 2, 3, 8):
+            cols = [stripe_columns(nx, world, r) for r in range(world)]
+            assert sorted(np.concatenate(cols).tolist()) == list(range(nx))
+            if nx >= 16 * world * 4:
+                assert max(map(len, cols)) - min(map(len, cols)) <= 16
+
+
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -39,8 +49,15 @@ def _worker(rank, world, port, out):
     o.set_window(*slab_bounds(nx, world, rank))
     o.render(spp)
     film = gather_film_torch(o.get_film_raw(), nx, ny, rank, world)
+    # the striped split of the same film (ragged: 70 columns = 4 stripes of 16 + one of 6)
+    nx2 = 70
+    o2 = setup_oracle(oracle, scenes.scene_s34(), nx2, ny, threads=1)
+    o2.set_stripes(16, rank, world)
+    o2.render(spp)
+    film2 = gather_film_torch(o2.get_film_raw(), nx2, ny, rank, world, stripe=16)
     if rank == 0:
         np.save(out, film)
+        np.save(out + '.stripes.npy', film2)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,6 +79,11 @@ def test_two_rank_slab_gather_is_bit_identical(tmp_path, oracle_mod):
     full = o.get_film_raw()
     assert np.array_equal(tiled, full)
     assert np.all(tiled[:, 3] == 2.0)
+    striped = np.load(out + '.stripes.npy')
+    o = setup_oracle(oracle_mod, scenes.scene_s34(), 70, 20, threads=1)
+    o.render(2)
+    assert np.array_equal(striped, o.get_film_raw())
+    assert np.all(striped[:, 3] == 2.0)
 
 
 def test_unique_id_file_rendezvous(tmp_path, monkeypatch):

@@ -175,6 +175,39 @@ def test_slabs_reassemble_bit_identically(fresh):
     assert np.all(full[..., 3] == spp)
 
 
+def test_stripes_reassemble_bit_identically(fresh):
+    '''the film dealt out in 16-column stripes to three contexts == the full film, fast and strict
+    build and the preview passes (the load-balanced multi-GPU split)'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd.dist import stripe_columns
+    from ptina_amd.engine.preview import PreviewEngine
+    nx, ny, spp, world = 102, 37, 3, 3        # 6 full stripes + one of 6 columns
+    for mode in ('fast', 'strict'):
+        reset_all()
+        eng = _engine(None, scenes.scene_s34(), nx, ny, mode=mode)
+        eng.render(spp)
+        PreviewEngine().render()
+        full = [FilmTable().get_raw(p).reshape(nx, ny, 4).copy() for p in range(3)]
+        parts = [np.zeros_like(f) for f in full]
+        for r in range(world):
+            reset_all()
+            eng = _engine(None, scenes.scene_s34(), nx, ny, mode=mode)
+            ctx().call('mpt_set_stripes', 16, r, world)
+            eng.render(spp)
+            PreviewEngine().render()
+            cols = stripe_columns(nx, world, r)
+            other = np.setdiff1d(np.arange(nx), cols)
+            for p in range(3):
+                got = FilmTable().get_raw(p).reshape(nx, ny, 4)
+                assert np.all(got[other] == 0), (mode, r, p)
+                parts[p][cols] = got[cols]
+        for p in range(3):
+            assert np.array_equal(parts[p], full[p]), (mode, p)
+        assert np.all(full[0][..., 3] == spp)
+    reset_all()
+
+
 def test_launch_pipelining_does_not_change_the_film(fresh):
     '''G launches on 1/G of the CUs each, D batches in flight: same film bit for bit, any G and D,
     including batches of different sizes back to back (the ring of slots is resized in between)'''

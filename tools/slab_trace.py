@@ -17,8 +17,12 @@ parts = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rank = int(sys.argv[2]) if len(sys.argv) > 2 else parts // 2
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 n, spp = 512, 32
-eng = setup_engine(scenes.get_scene('s978'), n, n, mode='fast', slab=(rank * n // parts, (rank + 1) * n // parts))
+stripe = int(os.environ.get('STRIPE', '0'))
+eng = setup_engine(scenes.get_scene('s978'), n, n, mode='fast',
+                   slab=None if stripe else (rank * n // parts, (rank + 1) * n // parts))
 c = ctx()
+if stripe:
+    c.call('mpt_set_stripes', stripe, rank, parts)
 c.set_option('batch', spp)
 for kv in filter(None, os.environ.get('MIPTINA_OPTS', '').split(',')):
     key, val = kv.split('=')
@@ -34,4 +38,4 @@ for _ in range(steps):
 c.call('mpt_synchronize')
 dt = (time.perf_counter() - t0) / steps * 1e3
 kms, nl = c.kernel_time()
-print(os.environ.get('MIPTINA_OPTS', ''), f'slab {rank}/{parts}: step {dt:.3f} ms, kernel {kms / nl:.3f} ms', flush=True)
+print(os.environ.get('MIPTINA_OPTS', ''), f'stripe {stripe} slab {rank}/{parts}: step {dt:.3f} ms, kernel {kms / nl:.3f} ms', flush=True)
