@@ -334,6 +334,22 @@ def test_errors_are_loud(fresh):
     BVHTree().build()
     eng.render()
     assert np.all(FilmTable().get_raw()[:, 3] == 1)
+    from ptina_amd.common import ctx
+    with pytest.raises(RuntimeError, match='multiple of 16'):
+        ctx().call('mpt_set_stripes', 8, 0, 2)
+    with pytest.raises(RuntimeError, match='stripe index'):
+        ctx().call('mpt_set_stripes', 16, 2, 2)
+    with pytest.raises(RuntimeError, match='slab'):
+        ctx().call('mpt_set_slab', 10, 40)
+    with pytest.raises(RuntimeError, match='unknown option'):
+        ctx().set_option('no_such_option', 1)
+    with pytest.raises(RuntimeError, match='grid_div'):
+        ctx().set_option('grid_div', 9)
+    ctx().call('mpt_set_stripes', 16, 1, 2)       # a share of [16, 32)
+    FilmTable().clear()
+    eng.render()
+    w = FilmTable().get_raw().reshape(32, 32, 4)[..., 3]
+    assert np.all(w[16:] == 1) and np.all(w[:16] == 0)
 
 
 def test_full_size_properties_and_window_parity(fresh, oracle_mod):

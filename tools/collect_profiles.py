@@ -58,6 +58,29 @@ if summary:
     with open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w') as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)
     print('pmc summary ->', f'{tag}_pmc_summary.json')
+# big scenes (`tools/gpu_round.sh pmcbig1..4` = `run_configs.py C4 C5` under --pmc): the production gather
+# kernel is dispatched as [C4 1-spp, C4 x6 (32 frames of 1024^2), C5 1-spp, C5 x3 (16 frames of 1024^2)]
+big = {}
+for d in ('pmcbig1', 'pmcbig2', 'pmcbig3', 'pmcbig4'):
+    f = newest(f'{d}/*/*counter_collection.csv')
+    if not f:
+        continue
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        if 'render_kernel_fast<32, false>' in r['Kernel_Name']:
+            per[r['Counter_Name']][int(r['Dispatch_Id'])] += float(r['Counter_Value'])
+    for cn, byd in per.items():
+        vals = [byd[k] for k in sorted(byd)]
+        if len(vals) != 11:
+            continue
+        for name, sl in (('C4 99k tris, 32 frames x 1024x1024 per launch', vals[1:7]),
+                         ('C5 1M tris, 16 frames x 1024x1024 per launch', vals[8:11])):
+            sl = sorted(sl)
+            big.setdefault(name, {})[cn] = sl[len(sl) // 2]
+if big:
+    with open(os.path.join(dst, f'{tag}_pmc_big_summary.json'), 'w') as fh:
+        json.dump(big, fh, indent=1, sort_keys=True)
+    print('big-scene pmc summary ->', f'{tag}_pmc_big_summary.json')
 for name in ('bench.log', 'diag.json'):
     src = os.path.join(ROOT, 'gpurun_out', name)
     if os.path.exists(src):

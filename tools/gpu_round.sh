@@ -44,6 +44,10 @@ for step in "$@"; do
     pmc2)        run pmc2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     pmc3)        run pmc3 400 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     pmc4)        run pmc4 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc4 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
+    pmcbig1)     run pmcbig1 500 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcbig1 -- python3 tools/run_configs.py C4 C5 ;;
+    pmcbig2)     run pmcbig2 500 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmcbig2 -- python3 tools/run_configs.py C4 C5 ;;
+    pmcbig3)     run pmcbig3 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcbig3 -- python3 tools/run_configs.py C4 C5 ;;
+    pmcbig4)     run pmcbig4 500 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM --output-format csv -d gpurun_out/pmcbig4 -- python3 tools/run_configs.py C4 C5 ;;
     torchrun1)   run torchrun1 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --force-comm --no-cpu-baseline ;;
     *) echo "unknown step $step" ;;
   esac

@@ -23,6 +23,9 @@ CONFIGS = [
     ('C4 99k-tri blob + env light 1024x1024x64', 'c4', {}, 1024, 64, ([1.0, 1.0, 1.0, 1.0], 0)),
     ('C5 1M random tris 1024x1024x16', 'c5', {'n': 1000000}, 1024, 16, None),
 ]
+only = sys.argv[1:]          # e.g. `run_configs.py C4 C5`
+if only:
+    CONFIGS = [c for c in CONFIGS if any(c[0].startswith(o) for o in only)]
 out = {}
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 for title, name, kw, n, spp, world in CONFIGS:
