@@ -11,12 +11,14 @@ def _transform(p, n, t, world, mtl):
     assert world is not None and p is not None and n is not None
     p = np.asarray(p, np.float64).reshape(-1, 3)
     n = np.asarray(n, np.float64).reshape(-1, 3)
+    # (the reference's t = None branch builds one row per face and then fails its own reshape,
+    #  multimesh.py:47-54; here missing texcoords are zeros per corner)
     t = np.zeros((p.shape[0], 2)) if t is None else np.asarray(t, np.float64).reshape(-1, 2)
     assert p.shape[0] == n.shape[0] == t.shape[0] and p.shape[0] % 3 == 0
     w = np.asarray(world, np.float64)
     ph = np.concatenate([p, np.ones((p.shape[0], 1))], axis=1) @ w.T
     p = ph[:, :3] / ph[:, 3:4]
-    n = n @ w[:3, :3].T                                   # direction: w component 0
+    n = (np.concatenate([n, np.zeros((n.shape[0], 1))], axis=1) @ w.T)[:, :3]   # direction: w component 0
     n = n / np.linalg.norm(n, axis=1, keepdims=True)
     return np.concatenate([p, n, t], axis=1), np.full(p.shape[0] // 3, -1 if mtl is None else mtl)
 

@@ -75,23 +75,92 @@ def readobj(path, orient='xyz', scale=None, simple=False, usemtl=True, quadok=Fa
 
 
 def objorient(obj, orient):
-    '''axis permutation / flips, e.g. 'xyz' (identity), 'xzy', '-xyz' (reference readobj.py:177-206)'''
-    flip = orient.startswith('-')
-    axes = orient.lstrip('-+').lower()
-    order = ['xyz'.index(ch) for ch in axes]
+    '''reference readobj.py:177-208: `orient` names, for output axes x, y, z in turn, the input axis
+    each one is taken from; an upper-case letter also negates that output axis (positions and
+    normals); a leading '-' reverses the corner order of every face'''
+    reverse = orient.startswith('-')
+    letters = orient[1:] if reverse else orient
+    src = ['xyz'.index(ch.lower()) for ch in letters]
     for key in ('v', 'vn'):
-        if key in obj:
-            obj[key] = np.ascontiguousarray(obj[key][:, order])
-    if flip:
+        a = obj[key][:, src].copy()
+        for axis, ch in enumerate(letters):
+            if ch.isupper():
+                a[:, axis] = -a[:, axis]
+        obj[key] = np.ascontiguousarray(a)
+    if reverse:
         obj['f'] = np.ascontiguousarray(obj['f'][:, ::-1, :])
-        if 'vn' in obj:
-            obj['vn'] = -obj['vn']
 
 
 def objautoscale(obj):
-    v = obj['v']
-    lo, hi = v.min(axis=0), v.max(axis=0)
-    obj['v'] = (v - (lo + hi) / 2) / max(float((hi - lo).max()) / 2, 1e-30)
+    '''reference readobj.py:172-174: centre on the mean vertex, then scale the largest |coordinate| to 1'''
+    v = obj['v'] - np.average(obj['v'], axis=0)
+    obj['v'] = (v / np.max(np.abs(v))).astype(obj['v'].dtype)
+
+
+def objverts(obj):
+    '''[nf, 3, 3] corner positions (reference readobj.py:160-161)'''
+    return obj['v'][obj['f'][:, :, 0]]
+
+
+def objcoors(obj):
+    '''[nf, 3, 2] corner texture coordinates (readobj.py:168-169)'''
+    return obj['vt'][obj['f'][:, :, 1]]
+
+
+def objnorms(obj):
+    '''[nf, 3, 3] corner normals (readobj.py:164-165)'''
+    return obj['vn'][obj['f'][:, :, 2]]
+
+
+def _usemtl_ranges(obj):
+    starts = [g[0] for g in obj['usemtl']]
+    stops = starts[1:] + [len(obj['f'])]
+    return [(b, e, g[1]) for b, e, g in zip(starts, stops, obj['usemtl'])]
+
+
+def objmtlids(obj):
+    '''material id per face from the usemtl groups: ids are 1-based in order of first appearance of
+    a name, faces before the first usemtl keep 0 (reference readobj.py:141-157)'''
+    ids = np.zeros(len(obj['f']), np.int32)
+    seen = []
+    for beg, end, name in _usemtl_ranges(obj):
+        if name not in seen:
+            seen.append(name)
+        ids[beg:end] = seen.index(name) + 1
+    return ids
+
+
+def objunpackmtls(obj):
+    '''one sub-object per material name, sharing the vertex pools (reference readobj.py:117-138)'''
+    faces = {}
+    for beg, end, name in _usemtl_ranges(obj):
+        chunk = obj['f'][beg:end]
+        faces[name] = np.concatenate([faces[name], chunk], axis=0) if name in faces else chunk
+    return {name: {'f': f, 'v': obj['v'], 'vn': obj['vn'], 'vt': obj['vt']} for name, f in faces.items()}
+
+
+def objmknorm(obj):
+    '''replace the normals by one flat normal per face, cross(p2 - p0, p1 - p0) normalised
+    (reference readobj.py:211-222)'''
+    ip, it = obj['f'][:, :, 0], obj['f'][:, :, 1]
+    p = obj['v'][ip]
+    nrm = np.cross(p[:, 2] - p[:, 0], p[:, 1] - p[:, 0])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    own = np.repeat(np.arange(len(ip))[:, None], 3, axis=1)
+    obj['vn'] = nrm
+    obj['f'] = np.stack([ip, it, own], axis=2)
+
+
+def readply(path):
+    '''(vertices f32 [nv,3], faces i32 [nf,k]) through the optional `plyfile` package (reference readobj.py:225-234)'''
+    try:
+        from plyfile import PlyData
+    except ImportError as e:
+        raise ImportError('readply needs the `plyfile` package') from e
+    ply = PlyData.read(path)
+    verts = np.array([list(v)[:3] for v in ply.elements[0]], np.float32)
+    faces = np.array([list(f[0]) for f in ply.elements[1]], np.int32)
+    return verts, faces
 
 
 def writeobj(path, obj):
@@ -100,7 +169,11 @@ def writeobj(path, obj):
     for key in ('v', 'vt', 'vn'):
         for row in obj.get(key, []):
             fh.write(key + ' ' + ' '.join(repr(float(x)) for x in row) + '\n')
-    for face in obj['f']:
-        fh.write('f ' + ' '.join('/'.join(str(int(i) + 1) for i in corner) for corner in face) + '\n')
+    faces = obj['f']
+    for face in faces:
+        if faces.ndim >= 3:
+            fh.write('f ' + ' '.join('/'.join(str(int(i) + 1) for i in corner) for corner in face) + '\n')
+        else:                     # 'simple' faces: one index per corner, used for all three fields
+            fh.write('f ' + ' '.join('/'.join([str(int(i) + 1)] * 3) for i in face) + '\n')
     if close:
         fh.close()

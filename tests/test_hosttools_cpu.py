@@ -2,6 +2,7 @@
 the worker-thread proxy.  No GPU.'''
 
 import base64
+import os
 import io
 import json
 import threading
@@ -40,6 +41,58 @@ f 1 2 3 4 5
     writeobj(out, obj)
     again = readobj(io.BytesIO(out.getvalue().encode()))
     assert np.array_equal(again['f'], obj['f']) and np.allclose(again['v'], obj['v'])
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_hosttools.npz')
+
+
+def test_readobj_matches_reference_golden():
+    '''outputs of the reference's own ptina.tools.readobj on the committed OBJ text
+    (tests/golden/make_reference_golden.py ran the reference module in the build container)'''
+    from ptina_amd.tools import readobj as R
+    g = np.load(GOLDEN)
+    text = g['obj_text'].tobytes()
+    for tag, kw in (('default', {}), ('zxy', {'orient': 'zxy'}), ('flipped', {'orient': '-xZy'}), ('scaled', {'scale': 2.5}),
+                    ('auto', {'scale': 'auto'}), ('nomtl', {'usemtl': False})):
+        obj = R.readobj(io.BytesIO(text), **kw)
+        for k in ('v', 'vt', 'vn', 'f'):
+            want = g[f'readobj_{tag}_{k}']
+            assert obj[k].shape == want.shape and obj[k].dtype == want.dtype, (tag, k)
+            assert np.array_equal(obj[k], want) if k == 'f' else np.allclose(obj[k], want, rtol=1e-6, atol=1e-7), (tag, k)
+        if tag != 'nomtl':
+            assert [u[0] for u in obj['usemtl']] == g[f'readobj_{tag}_usemtl_start'].tolist()
+            assert [bytes(u[1]) for u in obj['usemtl']] == g[f'readobj_{tag}_usemtl_name'].tolist()
+        else:
+            assert 'usemtl' not in obj
+    v, tri = R.readobj(io.BytesIO(text), simple=True)
+    assert np.array_equal(v, g['readobj_simple_v']) and np.array_equal(tri, g['readobj_simple_f'])
+    obj = R.readobj(io.BytesIO(text))
+    assert np.array_equal(R.objverts(obj), g['objverts'])
+    assert np.array_equal(R.objnorms(obj), g['objnorms'])
+    assert np.array_equal(R.objcoors(obj), g['objcoors'])
+    assert np.array_equal(R.objmtlids(obj), g['objmtlids']) and R.objmtlids(obj).dtype == np.int32
+    parts = R.objunpackmtls(obj)
+    assert [bytes(k) for k in parts] == g['objunpackmtls_names'].tolist()
+    for k, part in parts.items():
+        assert np.array_equal(part['f'], g['objunpackmtls_f_' + k.decode()])
+        assert part['v'] is obj['v']
+    R.objmknorm(obj)
+    assert np.allclose(obj['vn'], g['objmknorm_vn'], rtol=1e-6, atol=1e-7) and np.array_equal(obj['f'], g['objmknorm_f'])
+    obj2 = R.readobj(io.BytesIO(g['obj2_text'].tobytes()))
+    assert np.array_equal(R.objmtlids(obj2), g['obj2_mtlids'])
+
+
+def test_compose_multiple_meshes_matches_reference_golden():
+    from ptina_amd.multimesh import compose_multiple_meshes
+    g = np.load(GOLDEN)
+    prims = []
+    for i in range(3):
+        prims.append((g[f'compose_in{i}_p'], g[f'compose_in{i}_n'], g[f'compose_in{i}_t'], g[f'compose_in{i}_world'],
+                      int(g[f'compose_in{i}_mtl']) if f'compose_in{i}_mtl' in g else None))
+    verts, mtlids = compose_multiple_meshes(prims)
+    assert verts.shape == g['compose_out0'].shape and verts.dtype == np.float64
+    assert np.allclose(verts, g['compose_out0'], rtol=1e-13, atol=1e-14)
+    assert np.array_equal(mtlids, g['compose_out1'])
 
 
 def test_modelpool_dict_packing_matches_reference_indexing():

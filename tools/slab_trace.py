@@ -35,7 +35,8 @@ for _ in range(steps):
     eng.render(spp)
     c.call('mpt_flush')
     c.call('mpt_resolve', 0)
+host = (time.perf_counter() - t0) / steps * 1e3
 c.call('mpt_synchronize')
 dt = (time.perf_counter() - t0) / steps * 1e3
 kms, nl = c.kernel_time()
-print(os.environ.get('MIPTINA_OPTS', ''), f'stripe {stripe} slab {rank}/{parts}: step {dt:.3f} ms, kernel {kms / nl:.3f} ms', flush=True)
+print(os.environ.get('MIPTINA_OPTS', ''), f'stripe {stripe} slab {rank}/{parts}: step {dt:.3f} ms (host issue {host:.3f}), kernel {kms / nl:.3f} ms', flush=True)
