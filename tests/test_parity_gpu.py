@@ -352,6 +352,37 @@ def test_errors_are_loud(fresh):
     assert np.all(w[16:] == 1) and np.all(w[:16] == 0)
 
 
+def test_config3_film_size_and_a_stripe_share(fresh, oracle_mod):
+    '''BASELINE configs[2]'s film (2048x2048, needs max_filmsize = 2^22): every pixel gets its
+    samples, the share of one rank of eight is exactly its stripes, and a window agrees with the oracle'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd.dist import stripe_columns
+    n, spp = 2048, 2
+    scene = scenes.scene_s978()
+    eng = _engine(None, scene, n, n, mode='fast', max_filmsize=n * n)
+    eng.render(spp)
+    raw = FilmTable().get_raw().reshape(n, n, 4)
+    assert np.all(raw[..., 3] == spp) and np.isfinite(raw).all() and raw[..., :3].min() >= 0
+    img = FilmTable().get_image()
+    x0, x1 = 1000, 1004
+    ref = setup_oracle(oracle_mod, scene, n, n)
+    ref.set_window(x0, x1)
+    ref.render(spp)
+    assert_parity(img[x0:x1], ref.get_image()[x0:x1], 1e-3, 0.02, 2e-2, what='2048x2048 window')
+    reset_all()
+    eng = _engine(None, scene, n, n, mode='fast', max_filmsize=n * n)
+    ctx().call('mpt_set_stripes', 16, 5, 8)
+    eng.render(spp)
+    part = FilmTable().get_raw().reshape(n, n, 4)
+    cols = stripe_columns(n, 8, 5)
+    assert len(cols) == n // 8
+    assert np.array_equal(part[cols], raw[cols])
+    assert np.all(part[np.setdiff1d(np.arange(n), cols)] == 0)
+    reset_all()
+
+
 def test_full_size_properties_and_window_parity(fresh, oracle_mod):
     '''BASELINE configs[1] at full size (512x512x32, S978): size-independent properties, run-to-run
     bit reproducibility, fast-vs-strict agreement, and oracle parity on a window of columns'''
