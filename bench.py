@@ -8,10 +8,10 @@ One "step" = the timed region of the reference's exams/benchmark.py:29-35: 32 x 
 scene, BVH, Sobol tables and film are resident in HBM before the timed region starts; `value`
 stops at the resolved image in HBM, the D2H-inclusive rate is reported beside it.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the film is split into N column
-slabs, each rank renders its slab of the replicated scene and the slabs are gathered to rank 0
-with grouped ncclSend/ncclRecv (RCCL over xGMI) before the resolve -- strong scaling of the same
-512x512x32 job.  No PyTorch anywhere in the process: rendezvous of the RCCL unique id is a file,
+N > 1 (launched by torch.distributed.run, one rank per GPU): the film columns are dealt out in
+stripes of 16, rank r renders stripes r, r+N, ... of the replicated scene and the stripes are
+gathered to rank 0 with grouped ncclSend/ncclRecv (RCCL over xGMI) before the resolve -- strong
+scaling of the same 512x512x32 job.  No PyTorch anywhere in the process: rendezvous of the RCCL unique id is a file,
 barriers and the max-over-ranks are RCCL all-reduces.
 '''
 
@@ -49,6 +49,23 @@ def measured_traffic():
         for k, v in d.items():
             if 'render_kernel_lds<false' in k:
                 return int((v['FETCH_SIZE']['median'] + v['WRITE_SIZE']['median']) * 1024)
+    except Exception:
+        pass
+    return None
+
+
+def measured_valu(avg_kernel_s, n_simd=1024, clock_hz=2.4e9):
+    '''what actually bounds the LDS kernel, from the same committed PMC passes: the fraction of SIMD
+    cycles with a VALU instruction in flight (SQ_ACTIVE_INST_VALU counts 4-cycle issue slots) and the
+    fraction of lanes those instructions had switched on'''
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
+        for k, v in d.items():
+            if 'render_kernel_lds<false' in k:
+                active = v['SQ_ACTIVE_INST_VALU']['median']
+                return {'valu_busy_frac': round(active * 4.0 / (n_simd * clock_hz * avg_kernel_s), 3),
+                        'lane_utilisation': round(v['SQ_THREAD_CYCLES_VALU']['median'] / (64.0 * active), 3),
+                        'valu_insts_per_launch': int(v['SQ_INSTS_VALU']['median'])}
     except Exception:
         pass
     return None
@@ -219,6 +236,7 @@ def main():
                          'note': 'algorithmic bytes (SURVEY 8d) over kernel time; the 125 KB of nodes+triangles are '
                                  'served from LDS, so this exceeds what HBM could deliver and HBM is not the binding '
                                  'limit: the kernel is VALU-issue bound (profiles/, DESIGN.md)'},
+            'valu': measured_valu(avg_kernel_s) if (world == 1 and args.mode == 'fast' and args.scene == 's978') else None,
             'counters_per_sample': {k: round(v / max(cnt['samples'], 1), 3) for k, v in cnt.items() if k != 'samples'},
             'mrays_per_s': round(cnt['rays'] / W / avg_kernel_s / 1e6, 1),
         }
