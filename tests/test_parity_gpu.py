@@ -573,6 +573,71 @@ def test_gltf_compat_materials_parity(fresh, oracle_mod):
     reset_all()
 
 
+LOBE_MATERIALS = {
+    'glass': dict(basecolor=(0.9, 0.95, 1.0), roughness=0.08, transmission=0.9, ior=1.5, specular=0.5),
+    'rough_glass': dict(basecolor=(0.8, 0.9, 0.8), roughness=0.45, transmission=0.6, ior=1.33, metallic=0.1),
+    'clearcoat': dict(basecolor=(0.7, 0.1, 0.1), roughness=0.5, clearcoat=1.0, clearcoatGloss=0.9),
+    'coat_on_metal': dict(basecolor=(0.9, 0.7, 0.3), roughness=0.3, metallic=0.9, clearcoat=0.5, clearcoatGloss=0.2),
+    'cloth': dict(basecolor=(0.3, 0.2, 0.7), roughness=0.9, sheen=1.0, sheenTint=0.8, subsurface=0.7, specular=0.1),
+    'tinted_spec': dict(basecolor=(0.1, 0.6, 0.2), roughness=0.2, specular=1.0, specularTint=1.0),
+    'mirror': dict(basecolor=(0.95, 0.95, 0.95), roughness=0.0, metallic=1.0),
+    'black': dict(basecolor=(0.0, 0.0, 0.0), roughness=0.5),
+}
+
+
+@pytest.mark.parametrize('name', sorted(LOBE_MATERIALS))
+def test_disney_lobes_parity(fresh, oracle_mod, name):
+    '''every branch of Disney.brdf / Disney.bounce (disney.py:53-233): transmission + refraction, the
+    clearcoat lobe (whose GTR1 sample is NaN in the reference for alpha < 1 -- the path must die the
+    same way), sheen / subsurface, tinted specular, a perfect mirror (alpha clamped to 0.001) and a
+    black body, on both boxes of the 34-triangle scene.
+
+    Transmission is ill-conditioned in the reference's own algorithm: its f32 and f64 evaluations
+    (the oracle's two builds) already disagree on 5-11 % of the pixels at 16 spp (a refracted path
+    flips between lobes on the last bit of a re-used sample), with equal means.  For those two
+    materials the bound is therefore calibrated against that spread instead of a fixed tolerance.'''
+    from helpers import setup_oracle, assert_parity, image_stats
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
+    v, m, mats, _ = scenes.scene_s34()
+    mats = list(mats)
+    mats[3] = scenes.material(**LOBE_MATERIALS[name])
+    mats[4] = scenes.material(**LOBE_MATERIALS[name])
+    scene = (v, m, mats, [])
+    ref = setup_oracle(oracle_mod, scene, 64, 64)
+    ref.render(16)
+    want = ref.get_image()
+    assert np.isfinite(want).all()
+    chaotic = LOBE_MATERIALS[name].get('transmission', 0.0) > 0.0
+    if chaotic:
+        ref64 = setup_oracle(oracle_mod, scene, 64, 64, f64=True)
+        ref64.render(16)
+        d, refn, spread_rmse = image_stats(ref64.get_image(), want)
+        spread_out = float((d > 1e-3 * (1 + refn)).mean())
+        assert spread_out > 0.02, 'calibration: f32 and f64 oracle unexpectedly agree'
+    for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
+        reset_all()
+        eng = _engine(None, scene, 64, 64, mode=mode)
+        eng.render(16)
+        got = FilmTable().get_image()
+        assert np.isfinite(got).all()
+        if not chaotic:
+            assert_parity(got, want, tol, 0.02, 2e-2, what=f'{name} {mode}')
+            continue
+        d, refn, rel = image_stats(got, want)
+        out = float((d > tol * (1 + refn)).mean())
+        mean_err = abs(float(got[..., :3].mean()) / float(want[..., :3].mean()) - 1.0)
+        print(f'{name} {mode}: outliers {out:.3%} rel-RMSE {rel:.2e} mean error {mean_err:.2%} '
+              f'(f64-vs-f32 oracle: {spread_out:.3%}, {spread_rmse:.2e})')
+        assert mean_err < 0.01, f'{name} {mode}: mean radiance off by {mean_err:.2%}'
+        if mode == 'strict':       # same arithmetic as the f32 oracle up to libm: only a few flips
+            assert out < 0.03 and rel < 1e-2, f'{name} strict: {out:.3%} outliers, rel-RMSE {rel:.2e}'
+        else:                      # within twice the spread the reference algorithm shows itself
+            assert out < 2 * spread_out + 0.02 and rel < 2 * spread_rmse + 1e-2, \
+                f'{name} fast: {out:.3%} outliers (spread {spread_out:.3%}), rel-RMSE {rel:.2e} (spread {spread_rmse:.2e})'
+    reset_all()
+
+
 def test_many_lights(fresh, oracle_mod):
     '''a full light pool (64 lights, alternating POINT / AREA): first-hit-in-index-order semantics of
     LightPool.hit and the samp.z light pick of LightPool._sample'''
