@@ -573,6 +573,36 @@ def test_gltf_compat_materials_parity(fresh, oracle_mod):
     reset_all()
 
 
+def test_other_cameras_and_aspect_parity(fresh, oracle_mod):
+    '''Camera.set_perspective / generate (camera.py:19-39) beyond the benchmark matrix: an off-axis
+    perspective view built with tools.matrix on a non-square film, a view from inside the box towards
+    a side wall, and an orthographic projection (w = 1 everywhere, parallel rays)'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
+    from ptina_amd.tools.matrix import perspective, lookat, orthogonal
+    scene = scenes.scene_s978()
+    cams = {
+        'offaxis 96x56': (perspective(fov=45, aspect=96 / 56, near=0.1, far=100) @
+                          lookat(pos=(0.3, 1.6, 0.0), back=(2.5, 1.2, 5.0), up=(0.1, 1.0, 0.0)), 96, 56),
+        'inside 64x64': (perspective(fov=80, aspect=1, near=0.05, far=50) @
+                         lookat(pos=(-2.0, 2.0, 0.0), back=(2.9, 0.3, 1.0)), 64, 64),
+        'ortho 72x64': (orthogonal(size=2.4, aspect=72 / 64, near=-10, far=10) @
+                        lookat(pos=(0.0, 2.0, 0.0), back=(0.5, 0.4, 3.0)), 72, 64),
+    }
+    for what, (cam, nx, ny) in cams.items():
+        ref = setup_oracle(oracle_mod, scene, nx, ny, camera=cam)
+        ref.render(8)
+        want = ref.get_image()
+        assert np.isfinite(want).all() and want[..., :3].max() > 0.05, what
+        for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
+            reset_all()
+            eng = _engine(None, scene, nx, ny, mode=mode, camera=cam)
+            eng.render(8)
+            assert_parity(FilmTable().get_image(), want, tol, 0.02, 2e-2, what=f'{what} {mode}')
+    reset_all()
+
+
 LOBE_MATERIALS = {
     'glass': dict(basecolor=(0.9, 0.95, 1.0), roughness=0.08, transmission=0.9, ior=1.5, specular=0.5),
     'rough_glass': dict(basecolor=(0.8, 0.9, 0.8), roughness=0.45, transmission=0.6, ior=1.33, metallic=0.1),
