@@ -277,6 +277,33 @@ def test_textures_and_environment_parity(fresh, oracle_mod):
         assert_parity(FilmTable().get_image(), ref.get_image(), tol, 0.03, 3e-2, what=f'textures {mode}')
 
 
+def test_every_material_parameter_textured(fresh, oracle_mod):
+    '''ParameterPair.get (mtllib.py:30-38) for each of the twelve parameters: factor x bilinear texel of
+    its own image (wrap-around addressing, image.py:137-148), scalar parameters taking .x'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
+    v, m, mats, _ = scenes.scene_s34()
+    rng = np.random.default_rng(77)
+    images = [rng.uniform(0.2, 1.0, (4 + k, 9 - (k % 5), 3 if k % 3 == 0 else 1)).astype(np.float32) for k in range(12)]
+    fac = scenes.material(basecolor=(0.9, 0.8, 0.7), metallic=0.6, roughness=0.8, specular=0.9, specularTint=0.9,
+                          subsurface=0.8, sheen=0.9, sheenTint=0.9, clearcoat=0.0, clearcoatGloss=0.9,
+                          transmission=0.0, ior=1.6)
+    textured = [(f, k) for k, (f, _) in enumerate(fac)]
+    mats = list(mats)
+    mats[0] = textured            # white walls
+    mats[3] = textured            # tall box
+    scene = (v, m, mats, images)
+    ref = setup_oracle(oracle_mod, scene, 64, 64)
+    ref.render(16)
+    for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
+        reset_all()
+        eng = _engine(None, scene, 64, 64, mode=mode)
+        eng.render(16)
+        assert_parity(FilmTable().get_image(), ref.get_image(), tol, 0.02, 2e-2, what=f'12 textured parameters {mode}')
+    reset_all()
+
+
 def test_preview_aov_parity(fresh, oracle_mod):
     from helpers import setup_oracle
     from ptina_amd.things import FilmTable
