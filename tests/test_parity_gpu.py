@@ -304,22 +304,56 @@ def test_every_material_parameter_textured(fresh, oracle_mod):
     reset_all()
 
 
+def test_no_lights_default_material_world_only(fresh, oracle_mod):
+    '''LightPool().clear() (count 0: the light triple is still drawn, path.py:48, light/__init__.py:117-121),
+    ModelPool.load(vertices) without material ids (-1: the default material of mtllib.py:82-93) and a
+    bright constant world light as the only source'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
+    v, m, mats, _ = scenes.scene_s978()
+    scene = (v, None, mats, [])
+    world = ([0.9, 1.0, 1.1, 1.0], -1)
+    ref = setup_oracle(oracle_mod, scene, 64, 64, lights=[], world=world)
+    ref.render(16)
+    want = ref.get_image()
+    assert want[..., :3].mean() > 0.05
+    for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
+        reset_all()
+        eng = _engine(None, scene, 64, 64, mode=mode, lights=[], world=world)
+        eng.render(16)
+        assert_parity(FilmTable().get_image(), want, tol, 0.02, 2e-2, what=f'world only {mode}')
+    reset_all()
+
+
 def test_preview_aov_parity(fresh, oracle_mod):
+    '''PreviewEngine (engine/preview.py:18-41): albedo (textured base colour) and shading normal of the
+    primary hit into passes 1 and 2, both builds'''
     from helpers import setup_oracle
     from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
     from ptina_amd.engine.preview import PreviewEngine
-    scene = scenes.scene_s978()
+    v, m, mats, _ = scenes.scene_s978()
+    checker = np.ones((8, 8, 3), np.float32)
+    checker[::2, 1::2] = 0.2
+    checker[1::2, ::2] = 0.2
+    mats = [list(x) for x in mats]
+    mats[3][0] = ([1.0, 0.9, 0.8], 0)
+    scene = (v, m, mats, [checker])
     ref = setup_oracle(oracle_mod, scene, 48, 48)
     ref.render_preview()
     ref.render_preview()
-    _engine(fresh, scene, 48, 48, mode='strict')
-    PreviewEngine().render()
-    PreviewEngine().render()
-    for p in (1, 2):
-        a, b = FilmTable().get_image(p), ref.get_image(p)
-        close = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(axis=-1)
-        assert close.mean() > 0.99, (p, close.mean())
-    assert np.all(FilmTable().get_raw(0) == 0)             # path pass untouched
+    for mode in ('strict', 'fast'):
+        reset_all()
+        _engine(None, scene, 48, 48, mode=mode)
+        PreviewEngine().render()
+        PreviewEngine().render()
+        for p in (1, 2):
+            a, b = FilmTable().get_image(p), ref.get_image(p)
+            close = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(axis=-1)
+            assert close.mean() > 0.99, (mode, p, close.mean())
+        assert np.all(FilmTable().get_raw(0) == 0)             # path pass untouched
+    reset_all()
 
 
 def test_edge_cases_empty_and_single_triangle(fresh, oracle_mod):
