@@ -279,11 +279,14 @@ def test_textures_and_environment_parity(fresh, oracle_mod):
 
 def test_every_material_parameter_textured(fresh, oracle_mod):
     '''ParameterPair.get (mtllib.py:30-38) for each of the twelve parameters: factor x bilinear texel of
-    its own image (wrap-around addressing, image.py:137-148), scalar parameters taking .x'''
+    its own image, scalar parameters taking .x; texture coordinates run from -1.3 to 2.4 so the
+    wrap-around addressing of image.py:137-148 (Python floor-mod on negative texel indices) is used'''
     from helpers import setup_oracle, assert_parity
     from ptina_amd.things import FilmTable
     from ptina_amd.common import reset_all
     v, m, mats, _ = scenes.scene_s34()
+    v = v.copy()
+    v[:, 6:8] = v[:, 6:8] * 3.7 - 1.3
     rng = np.random.default_rng(77)
     images = [rng.uniform(0.2, 1.0, (4 + k, 9 - (k % 5), 3 if k % 3 == 0 else 1)).astype(np.float32) for k in range(12)]
     fac = scenes.material(basecolor=(0.9, 0.8, 0.7), metallic=0.6, roughness=0.8, specular=0.9, specularTint=0.9,
