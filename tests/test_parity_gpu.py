@@ -380,6 +380,69 @@ def test_edge_cases_empty_and_single_triangle(fresh, oracle_mod):
     reset_all()
 
 
+def test_worker_facade_through_the_thread_proxy(fresh):
+    '''the Blender add-on's view of the engine: every function of worker.py:11-87 called through
+    tools.mtworker's daemon thread (blender.py:565-580), against the same scene driven directly'''
+    import threading
+    from ptina_amd.tools.mtworker import DaemonModule, OnDemandProxy
+    from ptina_amd.tools.matrix import translate
+    from ptina_amd.common import reset_all
+    from ptina_amd.things import FilmTable
+    v, m, mats, _ = scenes.scene_s34()
+    checker = np.ones((4, 4, 3), np.float32)
+    checker[::2, 1::2] = 0.3
+    mats = [list(x) for x in mats]
+    mats[3][0] = ([1.0, 1.0, 1.0], 0)
+    light = (translate([0.5, 3.2, 0.5]), np.array([20.0, 18.0, 16.0]), 0.3, 'POINT')
+    world = ([0.2, 0.2, 0.3, 1.0], -1)
+    nx, ny, spp = 40, 28, 3
+
+    eng = _engine(None, (v, m, mats, [checker]), nx, ny, mode='fast', lights=[light], world=world)
+    eng.render(spp)
+    from ptina_amd.engine.preview import PreviewEngine
+    PreviewEngine().render()
+    direct = [FilmTable().get_raw(p).copy() for p in range(3)]
+    reset_all()
+
+    seen = []
+
+    def module():
+        seen.append(threading.get_ident())
+        from ptina_amd import worker
+        return worker
+    w = OnDemandProxy(lambda: DaemonModule(module))
+    w.init()
+    w.set_size(nx, ny)
+    assert w.get_size() == (nx, ny)
+    w.load_model(v, m)
+    w.load_materials(mats)
+    w.load_images([checker])
+    w.build_tree()
+    w.set_camera(scenes.BENCH_CAMERA)
+    w.clear_lights()
+    w.add_light(*light)
+    w.set_world_light(*world)
+    w.set_mlt_param(0.3, 0.03)                       # accepted, no effect on the path engine (worker.py:45-49)
+    for _ in range(spp):
+        w.render()
+    w.render_preview()
+    w.synchronize()
+    img = w.get_image()
+    assert img.shape == (nx, ny, 4) and seen and seen[0] != threading.get_ident()
+    flat = np.zeros(nx * ny * 3, np.float32)
+    w.fast_export_image(flat, 0)
+    assert np.allclose(flat.reshape(ny, nx, 3), np.swapaxes(img[..., :3], 0, 1), rtol=1e-6, atol=1e-7)
+    got = [w.get_image(p) for p in range(3)]
+    for p in range(3):
+        want = direct[p].reshape(nx, ny, 4)
+        res = np.where(want[..., 3:] != 0, want / np.where(want[..., 3:] != 0, want[..., 3:], 1), [0.9, 0.4, 0.9, 0.0])
+        assert np.allclose(got[p][..., :3], res[..., :3], rtol=1e-6, atol=1e-7), p
+    w.clear()
+    assert np.all(w.get_image()[..., 3] == 0)        # FilmTable.clear: every pass (filmtable.py:44-45)
+    assert np.all(w.get_image(1)[..., 3] == 0)
+    reset_all()
+
+
 def test_errors_are_loud(fresh):
     from ptina_amd.things import init_things, FilmTable, ModelPool, BVHTree
     from ptina_amd.engine.path import PathEngine
