@@ -1,57 +1,16 @@
 // miptina.cpp -- host runtime behind the C ABI of include/miptina.h.
 //
 // Owns the device state of one PTina "scene" (the singletons of ptina/things.py:20-28 collapsed
-// into one context), builds the LBVH, batches enqueued frames into single launches, and gathers
-// film slabs across GPUs with RCCL.  No PyTorch, no Python: plain HIP runtime calls.
+// into one context), uploads the scene, advances the Sobol sampler, batches enqueued frames into
+// single launches and reads the film back.  The BVH builders are in tree_build.cpp, the RCCL film
+// gather in comm.cpp.  No PyTorch, no Python: plain HIP runtime calls.
 
-#include "../../include/miptina.h"
-#include "mpt_types.h"
-
-#include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
-#include <dlfcn.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <vector>
-
-// kernel launchers (render_kernel.hip x2, aux_kernels.hip)
-extern "C" hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
-extern "C" hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
-extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
-extern "C" hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
-extern "C" hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
-extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
-                                              int keep, hipStream_t);
-extern "C" hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
-                                         int stripe_w, int stripe_pitch,
-                                         int nchunks, hipStream_t);
-extern "C" hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
-extern "C" hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
-
-// on-GPU LBVH build (lbvh_build.hip)
-struct MptLbvhBuffers {
-    const float *verts; const int *mtlids; int n;
-    float *cen; int *bounds;
-    unsigned long long *keys_in, *keys_out;
-    void *sort_tmp; size_t sort_tmp_bytes;
-    int *child, *parent, *leaf, *mc;
-    float *bmin, *bmax;
-    unsigned *arrive;
-    int *depth;
-    MptVec4 *snode, *fnode, *tgeo, *tshade;
-};
-extern "C" hipError_t mpt_lbvh_sort_bytes(int n, size_t *bytes);
-extern "C" hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t stream);
+#include "miptina_ctx.h"
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 
-static int fail(const char *fmt, ...) {
+int fail(const char *fmt, ...) {
     char buf[1024];
     va_list ap;
     va_start(ap, fmt);
@@ -61,11 +20,6 @@ static int fail(const char *fmt, ...) {
     return 1;
 }
 
-#define HIP_TRY(expr)                                                                     \
-    do {                                                                                  \
-        hipError_t e_ = (expr);                                                           \
-        if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
 
 extern "C" const char *mpt_last_error(void) { return g_err.c_str(); }
 extern "C" int mpt_version(void) { return 100; }
@@ -76,178 +30,18 @@ extern "C" int mpt_device_count(void) {
     return n;
 }
 
-// ------------------------------------------------------------------ RCCL, bound lazily
-struct Rccl {
-    void *h = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-};
-static Rccl g_rccl;
-
-static int rccl_load() {
-    if (g_rccl.h) return 0;
-    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-    void *h = nullptr;
-    for (const char *nm : names) {
-        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
-    }
-    if (!h) return fail("cannot load librccl: %s", dlerror());
-#define SYM(field, name)                                                        \
-    *(void **)(&g_rccl.field) = dlsym(h, name);                                 \
-    if (!g_rccl.field) return fail("librccl lacks symbol %s", name);
-    SYM(GetUniqueId, "ncclGetUniqueId");
-    SYM(CommInitRank, "ncclCommInitRank");
-    SYM(CommDestroy, "ncclCommDestroy");
-    SYM(Send, "ncclSend");
-    SYM(Recv, "ncclRecv");
-    SYM(GroupStart, "ncclGroupStart");
-    SYM(GroupEnd, "ncclGroupEnd");
-    SYM(AllReduce, "ncclAllReduce");
-    SYM(GetErrorString, "ncclGetErrorString");
-#undef SYM
-    g_rccl.h = h;
-    return 0;
-}
-
-#define NCCL_TRY(expr)                                                                          \
-    do {                                                                                        \
-        ncclResult_t r_ = (expr);                                                               \
-        if (r_ != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(r_));  \
-    } while (0)
-
-// Up to MPT_MAX_PIPE render streams, the main stream and the aux stream carry work at the same time.
-// The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told
-// otherwise) and streams that share one are serialised, so ask for more before the runtime starts --
-// unless the user has chosen a value.
-__attribute__((constructor)) static void mpt_want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-
-// ------------------------------------------------------------------ context
-enum { MPT_MAX_PIPE = 6 };
-
-struct mpt_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    mpt_caps caps{};
-
-    // options
-    int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1, lds_block = 0;
-    int num_cus = 256;
-    int tile_w_shift = 3, tile_h_shift = 3;   // work-item tile 2^w x 2^h pixels
-    int sched_num = 2, sched_den = 1;    // scheduler: stay in traversal mode while traversing*num >= waiting*den (tuned on MI355X)
-    int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
-
-    // film
-    int nx = 0, ny = 0, x0 = 0, x1 = 0;
-    int stripe_w = 0, stripe_idx = 0, stripe_mod = 1;   // stripe_w > 0: columns dealt out in stripes (mpt_set_stripes)
-    MptVec4 *film[3] = { nullptr, nullptr, nullptr };
-    size_t film_cap = 0;                 // pixels allocated per pass
-    MptVec4 *resolved = nullptr;         // nx*ny float4 (get_image staging on device)
-    float *exported = nullptr;           // nx*ny*3
-
-    // model (host copy kept for the tree build)
-    int nfaces = 0;
-    std::vector<float> verts;            // [3n][8]
-    std::vector<int32_t> mtlids;
-    bool tree_valid = false;
-    int tree_depth = 0;                  // reference LBVH (strict build)
-    int fast_depth = 0;                  // tree the fast build walks (SAH or LBVH)
-    int tree_kind = 1;                   // fast build: 1 = SAH re-partition of the LBVH's leaves, 0 = the LBVH itself
-    int gpu_build = 1;                   // 1 = LBVH built on the device (lbvh_build.hip), 0 = host build
-    int sah_max = 1 << 18;               // above this many faces the fast build walks the LBVH itself
-    bool host_tree_valid = false;        // h_child/h_leaf/... mirror the device tree (lazily downloaded)
-    // device-side build workspace
-    float *d_verts = nullptr; int *d_mtlids = nullptr; size_t d_model_cap = 0;
-    float *d_cen = nullptr; int *d_bounds = nullptr; int *d_depth = nullptr;
-    unsigned long long *d_keys_in = nullptr, *d_keys_out = nullptr;
-    void *d_sort_tmp = nullptr; size_t d_sort_bytes = 0;
-    int *d_child = nullptr, *d_parent = nullptr, *d_leaf = nullptr, *d_mc = nullptr;
-    float *d_bmin = nullptr, *d_bmax = nullptr;
-    unsigned *d_arrive = nullptr;
-    size_t d_build_cap = 0;
-    std::vector<int32_t> h_child, h_leaf, h_mc;
-    std::vector<float> h_bmin, h_bmax;
-    MptVec4 *snode = nullptr, *fnode = nullptr, *tgeo = nullptr, *tshade = nullptr;
-    size_t node_cap = 0, tri_cap = 0;
-
-    // materials / images / lights / world / camera
-    MptMaterial *mats = nullptr;
-    MptImage *images = nullptr;
-    std::vector<MptImage> h_images;
-    MptVec4 *texels = nullptr;
-    size_t texels_used = 0;
-    MptLight *lights = nullptr;
-    std::vector<MptLight> h_lights;
-    float world_fac[4] = { 0.1f, 0.1f, 0.1f, 0.1f };   // light/world.py:14-16
-    int world_tex = -1;                                 // documented deviation Q6 (reference default 0)
-    float v2w[16], w2v[16];
-
-    // sobol
-    int sdim = 0, srows = 0;
-    int32_t stime = 0;
-    int *sV = nullptr, *sX = nullptr;
-    float *sP = nullptr;                 // [MPT_MAX_BATCH][sdim]
-
-    // command batching
-    int pending = 0;
-
-    // launch pipelining (fast build): batch i renders on rstream[i & 1] into partial[i & 1] while the main
-    // stream still combines / gathers / resolves batch i-1, so one launch's tail overlaps the next one's head
-    hipStream_t rstream[MPT_MAX_PIPE] = {};
-    hipEvent_t ev_render[MPT_MAX_PIPE] = {};          // render of the batch on rstream[k] finished
-    hipEvent_t ev_free[MPT_MAX_PIPE] = {};            // combine has consumed partial[k]
-    hipStream_t aux = nullptr;                        // Sobol advances + queue resets of the pipelined batches
-    hipEvent_t ev_sobol2[MPT_MAX_PIPE] = {};          // Sobol points + zeroed queue heads of the batch on rstream[k] ready
-    int pipe_depth = 0;                               // batches in flight (slots of P / partial / queue heads); 0 = auto
-    int grid_div = 0;                                 // each launch takes 1/grid_div of the CUs; 0 = auto
-    int cur_depth = 2, cur_div = 1;                   // what the last launch used
-    hipEvent_t ev_main = nullptr;                     // main-stream work a render must see (uploads, resets, ...)
-    bool main_dirty = true;
-    int flip = 0;
-    MptVec4 *partial2[MPT_MAX_PIPE] = {};
-    size_t partial2_cap[MPT_MAX_PIPE] = {};           // float4 elements per buffer
-    float *sP2[MPT_MAX_PIPE] = {};
-    unsigned int *d_work2[MPT_MAX_PIPE] = {};
-
-    // measurement
-    int timeline = 0;                    // 1: the LDS kernel records per-wave timestamps of its last launch
-    unsigned long long *d_timeline = nullptr;
-    int timeline_waves = 0;
-    unsigned long long *d_counters = nullptr;
-    unsigned int *d_work = nullptr;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    std::vector<hipEvent_t> event_pool;
-
-    // comm
-    ncclComm_t comm = nullptr;
-    int nranks = 1, rank = 0;
-    double *d_scratch = nullptr;
-};
-
-static int use_ro(mpt_ctx *c) {   // entry of calls that only read results
+int use_ro(mpt_ctx *c) {   // entry of calls that only read results
     if (!c) return fail("null context");
     HIP_TRY(hipSetDevice(c->device));
     return 0;
 }
 
-static int use(mpt_ctx *c) {      // entry of calls that may change what the next render launch reads
+int use(mpt_ctx *c) {      // entry of calls that may change what the next render launch reads
     if (use_ro(c)) return 1;
     c->main_dirty = true;
     return 0;
 }
 
-template <class T>
-static int dev_alloc(T **p, size_t count) {
-    HIP_TRY(hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
-    return 0;
-}
 
 static void default_light(mpt_ctx *c) {
     // light/__init__.py:22-28: one POINT light at (1,2,3), radius 0.5, colour 32
@@ -337,7 +131,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     for (int k = 0; k < MPT_MAX_PIPE; k++) if (c->rstream[k]) hipStreamSynchronize(c->rstream[k]);
     if (c->aux) { hipStreamSynchronize(c->aux); }
     hipStreamSynchronize(c->stream);
-    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    mpt_comm_release(c);
     if (c->aux) hipStreamDestroy(c->aux);
     for (int k = 0; k < MPT_MAX_PIPE; k++) {
         if (c->rstream[k]) hipStreamDestroy(c->rstream[k]);
@@ -617,511 +411,6 @@ extern "C" int mpt_set_world_light(mpt_ctx *c, const float fac[4], int tex) {
     if (mpt_flush(c)) return 1;
     memcpy(c->world_fac, fac, sizeof c->world_fac);
     c->world_tex = tex;
-    return 0;
-}
-
-// ------------------------------------------------------------------ LBVH build (tree/lbvh.py:169-305)
-// Same algorithm as the reference (30-bit Morton codes of centroids, sorted, Karras hierarchy,
-// bottom-up boxes) with two robustness changes: the sort key is (code << 32 | index), so equal
-// codes cannot corrupt the hierarchy, and the boxes are fitted in one post-order
-// pass instead of <=64 level-synchronous launches with a read-back each (lbvh.py:251-261).
-// With distinct codes the tree is node-for-node the reference's.
-
-static inline uint32_t expand_bits(uint32_t v) {                               // lbvh.py:13-17
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
-
-static inline int quant1024(float x) {                                         // clamp(ifloor(v * 1024), 0, 1023), lbvh.py:29
-    float f = floorf(x * 1024.0f);
-    if (!(f == f) || f < 0.f) return 0;
-    if (f > 1023.f) return 1023;
-    return (int)f;
-}
-
-static inline int delta(const std::vector<uint64_t> &key, int n, int i, int j) {
-    if (j < 0 || j >= n) return -1;
-    return __builtin_clzll(key[i] ^ key[j]);
-}
-
-// ------------------------------------------------------------------ SAH re-partition (fast build only)
-// The image does not depend on the tree's shape (only on which of two equal-depth hits wins), so the
-// production traversal is free to walk a better tree over the SAME leaf slots: measured on the
-// 978-triangle benchmark scene a full-sweep SAH partition needs 11.0 node fetches per ray where the
-// LBVH needs 23.7.  Leaves stay single triangles (the node record is unchanged); nodes are numbered
-// in DFS pre-order, root 0.  Exact sweep for ranges <= 8192 leaves, 32-bin SAH above.
-struct SahBuild {
-    int n = 0;
-    std::vector<float> lo, hi, ctr;            // per leaf slot [n][3]
-    std::vector<int> idx;                      // leaf slots, partitioned in place
-    std::vector<int32_t> child;                // [n-1][2]: >= 0 internal, ~slot leaf
-    std::vector<float> blo, bhi;               // per internal node [n-1][3]: its own box
-    int depth = 0;
-
-    static float half_area(const float *l, const float *h) {
-        float dx = std::max(h[0] - l[0], 0.f), dy = std::max(h[1] - l[1], 0.f), dz = std::max(h[2] - l[2], 0.f);
-        return dx * dy + dy * dz + dz * dx;
-    }
-
-    int split(int b, int e) {                  // returns m in (b, e): [b, m) | [m, e)
-        const int cnt = e - b;
-        float best = INFINITY;
-        int best_axis = -1, best_k = -1;
-        float best_pos = 0.f;
-        bool binned = cnt > 8192;
-        std::vector<std::pair<float, int>> key(binned ? 0 : cnt);
-        std::vector<float> rarea(binned ? 0 : cnt);
-        float cl[3] = { INFINITY, INFINITY, INFINITY }, ch[3] = { -INFINITY, -INFINITY, -INFINITY };
-        for (int t = b; t < e; t++)
-            for (int a = 0; a < 3; a++) {
-                cl[a] = std::min(cl[a], ctr[(size_t)idx[t] * 3 + a]);
-                ch[a] = std::max(ch[a], ctr[(size_t)idx[t] * 3 + a]);
-            }
-        for (int a = 0; a < 3; a++) {
-            if (!(ch[a] > cl[a])) continue;
-            if (!binned) {
-                for (int t = 0; t < cnt; t++) key[t] = { ctr[(size_t)idx[b + t] * 3 + a], idx[b + t] };
-                std::sort(key.begin(), key.end());
-                float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
-                for (int t = cnt - 1; t > 0; t--) {
-                    int s = key[t].second;
-                    for (int q = 0; q < 3; q++) { l[q] = std::min(l[q], lo[(size_t)s * 3 + q]); h[q] = std::max(h[q], hi[(size_t)s * 3 + q]); }
-                    rarea[t] = half_area(l, h);
-                }
-                for (int q = 0; q < 3; q++) { l[q] = INFINITY; h[q] = -INFINITY; }
-                for (int k = 1; k < cnt; k++) {
-                    int s = key[k - 1].second;
-                    for (int q = 0; q < 3; q++) { l[q] = std::min(l[q], lo[(size_t)s * 3 + q]); h[q] = std::max(h[q], hi[(size_t)s * 3 + q]); }
-                    float cost = half_area(l, h) * k + rarea[k] * (cnt - k);
-                    if (cost < best) { best = cost; best_axis = a; best_k = k; }
-                }
-            } else {
-                const int NB = 32;
-                float bl[NB][3], bh[NB][3];
-                int bc[NB];
-                for (int q = 0; q < NB; q++) { bc[q] = 0; for (int r = 0; r < 3; r++) { bl[q][r] = INFINITY; bh[q][r] = -INFINITY; } }
-                float scale = NB / (ch[a] - cl[a]);
-                for (int t = b; t < e; t++) {
-                    int s = idx[t];
-                    int q = std::min(NB - 1, std::max(0, (int)((ctr[(size_t)s * 3 + a] - cl[a]) * scale)));
-                    bc[q]++;
-                    for (int r = 0; r < 3; r++) { bl[q][r] = std::min(bl[q][r], lo[(size_t)s * 3 + r]); bh[q][r] = std::max(bh[q][r], hi[(size_t)s * 3 + r]); }
-                }
-                float ra[NB]; int rc[NB];
-                float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
-                int c2 = 0;
-                for (int q = NB - 1; q > 0; q--) {
-                    c2 += bc[q];
-                    for (int r = 0; r < 3; r++) { l[r] = std::min(l[r], bl[q][r]); h[r] = std::max(h[r], bh[q][r]); }
-                    ra[q] = half_area(l, h); rc[q] = c2;
-                }
-                for (int r = 0; r < 3; r++) { l[r] = INFINITY; h[r] = -INFINITY; }
-                int c1 = 0;
-                for (int q = 1; q < NB; q++) {
-                    c1 += bc[q - 1];
-                    for (int r = 0; r < 3; r++) { l[r] = std::min(l[r], bl[q - 1][r]); h[r] = std::max(h[r], bh[q - 1][r]); }
-                    if (c1 == 0 || rc[q] == 0) continue;
-                    float cost = half_area(l, h) * c1 + ra[q] * rc[q];
-                    if (cost < best) { best = cost; best_axis = a; best_k = c1; best_pos = cl[a] + q / scale; }
-                }
-            }
-        }
-        if (best_axis < 0) return b + cnt / 2;                 // all centroids equal: split the range in half
-        if (!binned) {
-            for (int t = 0; t < cnt; t++) key[t] = { ctr[(size_t)idx[b + t] * 3 + best_axis], idx[b + t] };
-            std::sort(key.begin(), key.end());
-            for (int t = 0; t < cnt; t++) idx[b + t] = key[t].second;
-            return b + best_k;
-        }
-        int a = best_axis;
-        const int NB = 32;
-        float scale = NB / (ch[a] - cl[a]);
-        int qsplit = (int)std::lround((best_pos - cl[a]) * scale);
-        int m = (int)(std::partition(idx.begin() + b, idx.begin() + e, [&](int s) {
-                          int q = std::min(NB - 1, std::max(0, (int)((ctr[(size_t)s * 3 + a] - cl[a]) * scale)));
-                          return q < qsplit;
-                      }) - idx.begin());
-        if (m <= b || m >= e) m = b + cnt / 2;
-        return m;
-    }
-
-    void run() {
-        const int ni = n > 1 ? n - 1 : 0;
-        child.assign((size_t)std::max(ni, 1) * 2, 0);
-        blo.assign((size_t)std::max(ni, 1) * 3, 0.f);
-        bhi.assign((size_t)std::max(ni, 1) * 3, 0.f);
-        idx.resize(n);
-        for (int i = 0; i < n; i++) idx[i] = i;
-        depth = 0;
-        if (ni == 0) return;
-        struct Item { int b, e, parent, which, depth; };
-        std::vector<Item> st;
-        st.push_back({ 0, n, -1, 0, 1 });
-        int next_node = 0;
-        while (!st.empty()) {
-            Item it = st.back(); st.pop_back();
-            int me = next_node++;
-            if (it.parent >= 0) child[(size_t)it.parent * 2 + it.which] = me;
-            depth = std::max(depth, it.depth);
-            float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
-            for (int t = it.b; t < it.e; t++)
-                for (int q = 0; q < 3; q++) { l[q] = std::min(l[q], lo[(size_t)idx[t] * 3 + q]); h[q] = std::max(h[q], hi[(size_t)idx[t] * 3 + q]); }
-            for (int q = 0; q < 3; q++) { blo[(size_t)me * 3 + q] = l[q]; bhi[(size_t)me * 3 + q] = h[q]; }
-            int m = split(it.b, it.e);
-            // right first on the stack so the left subtree gets the next indices (pre-order)
-            if (it.e - m == 1) child[(size_t)me * 2 + 1] = ~idx[m];
-            else st.push_back({ m, it.e, me, 1, it.depth + 1 });
-            if (m - it.b == 1) child[(size_t)me * 2 + 0] = ~idx[it.b];
-            else st.push_back({ it.b, m, me, 0, it.depth + 1 });
-        }
-    }
-};
-
-static int build_tree_host(mpt_ctx *c) {
-    const int n = c->nfaces;
-    const float *V = c->verts.data();
-    auto pos = [&](int f, int k) { return V + ((size_t)f * 3 + k) * 8; };
-
-    // genMortonCodes, lbvh.py:169-183
-    float bmin[3] = { 1e6f, 1e6f, 1e6f }, bmax[3] = { -1e6f, -1e6f, -1e6f };
-    std::vector<float> cen((size_t)n * 3);
-    for (int f = 0; f < n; f++)
-        for (int a = 0; a < 3; a++) {
-            float ctr = ((pos(f, 0)[a] + pos(f, 1)[a]) + pos(f, 2)[a]) / 3.0f;   // lbvh.py:164
-            cen[(size_t)f * 3 + a] = ctr;
-            bmin[a] = fminf(bmin[a], ctr);
-            bmax[a] = fmaxf(bmax[a], ctr);
-        }
-    std::vector<uint64_t> key(n);
-    for (int f = 0; f < n; f++) {
-        uint32_t w[3];
-        for (int a = 0; a < 3; a++) w[a] = expand_bits((uint32_t)quant1024((cen[(size_t)f * 3 + a] - bmin[a]) / (bmax[a] - bmin[a])));
-        uint32_t code = w[0] * 4 + w[1] * 2 + w[2];
-        key[f] = ((uint64_t)code << 32) | (uint32_t)f;
-    }
-    std::sort(key.begin(), key.end());                                          // lbvh.py:204-208
-
-    c->h_leaf.resize(n); c->h_mc.resize(n);
-    for (int i = 0; i < n; i++) { c->h_leaf[i] = (int32_t)(key[i] & 0xffffffffu); c->h_mc[i] = (int32_t)(key[i] >> 32); }
-
-    const int ni = n > 1 ? n - 1 : 0;
-    c->h_child.assign((size_t)std::max(ni, 1) * 2, 0);
-    c->h_bmin.assign((size_t)std::max(ni, 1) * 3, 0.f);
-    c->h_bmax.assign((size_t)std::max(ni, 1) * 3, 0.f);
-
-    // genHierarchy, lbvh.py:212-231 (determineRange :93-146, findSplit :62-89)
-    for (int i = 0; i < ni; i++) {
-        int l, r;
-        if (i == 0) { l = 0; r = n - 1; }
-        else {
-            int d = delta(key, n, i, i + 1) > delta(key, n, i, i - 1) ? 1 : -1;
-            int dmin = delta(key, n, i, i - d);
-            int lmax = 2;
-            while (delta(key, n, i, i + lmax * d) > dmin) lmax <<= 1;
-            int s = 0;
-            for (int t = lmax >> 1; t > 0; t >>= 1)
-                if (delta(key, n, i, i + (s + t) * d) > dmin) s += t;
-            l = i; r = i + s * d;
-            if (d < 0) std::swap(l, r);
-        }
-        int cp = delta(key, n, l, r);
-        int m = l, s = r - l;
-        for (;;) {
-            s = (s + 1) >> 1;
-            int q = m + s;
-            if (q < r && delta(key, n, l, q) > cp) m = q;
-            if (s <= 1) break;
-        }
-        c->h_child[(size_t)i * 2 + 0] = (m == l) ? m : m + n;
-        c->h_child[(size_t)i * 2 + 1] = (m + 1 == r) ? m + 1 : m + 1 + n;
-    }
-
-    // boxes: iterative post-order from the root (also yields the depth the LDS stack must hold)
-    auto leaf_box = [&](int slot, float *lo, float *hi) {                       // lbvh.py:155-158
-        int f = c->h_leaf[slot];
-        for (int a = 0; a < 3; a++) {
-            lo[a] = fminf(fminf(pos(f, 0)[a], pos(f, 1)[a]), pos(f, 2)[a]);
-            hi[a] = fmaxf(fmaxf(pos(f, 0)[a], pos(f, 1)[a]), pos(f, 2)[a]);
-        }
-    };
-    int depth = 0;
-    if (ni > 0) {
-        std::vector<int> order; order.reserve(ni);
-        std::vector<std::pair<int, int>> st; st.push_back({ 0, 1 });
-        std::vector<char> seen(ni, 0);
-        while (!st.empty()) {
-            auto [i, dpt] = st.back(); st.pop_back();
-            if (i < 0 || i >= ni || seen[i]) return fail("AABB step never stop! hierarchy corrupted?");   // lbvh.py:259
-            seen[i] = 1;
-            order.push_back(i);
-            depth = std::max(depth, dpt);
-            for (int k = 0; k < 2; k++) {
-                int ch = c->h_child[(size_t)i * 2 + k];
-                if (ch >= n) st.push_back({ ch - n, dpt + 1 });
-            }
-        }
-        if ((int)order.size() != ni) return fail("AABB step never stop! hierarchy corrupted?");
-        for (int t = ni - 1; t >= 0; t--) {                                     // children before parents
-            int i = order[t];
-            float lo[2][3], hi[2][3];
-            for (int k = 0; k < 2; k++) {
-                int ch = c->h_child[(size_t)i * 2 + k];
-                if (ch < n) leaf_box(ch, lo[k], hi[k]);
-                else for (int a = 0; a < 3; a++) { lo[k][a] = c->h_bmin[(size_t)(ch - n) * 3 + a]; hi[k][a] = c->h_bmax[(size_t)(ch - n) * 3 + a]; }
-            }
-            for (int a = 0; a < 3; a++) {
-                c->h_bmin[(size_t)i * 3 + a] = fminf(lo[0][a], lo[1][a]);
-                c->h_bmax[(size_t)i * 3 + a] = fmaxf(hi[0][a], hi[1][a]);
-            }
-        }
-    }
-    c->tree_depth = depth;
-    if (depth + 2 > 64) return fail("LBVH depth %d exceeds the 64-entry traversal stack", depth);
-
-    // pack device records
-    std::vector<MptVec4> snode((size_t)std::max(ni, 1) * 2), fnode((size_t)std::max(ni, 1) * 4);
-    std::vector<MptVec4> tgeo((size_t)std::max(n, 1) * 4), tshade((size_t)std::max(n, 1) * 4);
-    auto asf = [](int32_t v) { float f; memcpy(&f, &v, 4); return f; };
-    for (int i = 0; i < ni; i++) {
-        const float *lo = &c->h_bmin[(size_t)i * 3], *hi = &c->h_bmax[(size_t)i * 3];
-        int c0 = c->h_child[(size_t)i * 2], c1 = c->h_child[(size_t)i * 2 + 1];
-        snode[(size_t)i * 2 + 0] = { lo[0], lo[1], lo[2], asf(c0) };
-        snode[(size_t)i * 2 + 1] = { hi[0], hi[1], hi[2], asf(c1) };
-    }
-    // the tree the fast build walks: child ids >= 0 internal, ~slot leaf; a node record holds its
-    // two children's boxes
-    std::vector<int32_t> fchild((size_t)std::max(ni, 1) * 2, 0);
-    std::vector<float> flo((size_t)std::max(ni, 1) * 3, 0.f), fhi((size_t)std::max(ni, 1) * 3, 0.f);
-    if (c->tree_kind == 1 && ni > 0) {
-        SahBuild sb;
-        sb.n = n;
-        sb.lo.resize((size_t)n * 3); sb.hi.resize((size_t)n * 3); sb.ctr.resize((size_t)n * 3);
-        for (int slot = 0; slot < n; slot++) {
-            float l[3], h[3];
-            leaf_box(slot, l, h);
-            for (int a = 0; a < 3; a++) {
-                sb.lo[(size_t)slot * 3 + a] = l[a]; sb.hi[(size_t)slot * 3 + a] = h[a];
-                sb.ctr[(size_t)slot * 3 + a] = 0.5f * (l[a] + h[a]);
-            }
-        }
-        sb.run();
-        fchild = sb.child; flo = sb.blo; fhi = sb.bhi;
-        c->fast_depth = sb.depth;
-    } else {
-        for (int i = 0; i < ni; i++) {
-            for (int k = 0; k < 2; k++) {
-                int ch = c->h_child[(size_t)i * 2 + k];
-                fchild[(size_t)i * 2 + k] = ch < n ? ~ch : ch - n;
-            }
-            for (int a = 0; a < 3; a++) { flo[(size_t)i * 3 + a] = c->h_bmin[(size_t)i * 3 + a]; fhi[(size_t)i * 3 + a] = c->h_bmax[(size_t)i * 3 + a]; }
-        }
-        c->fast_depth = depth;
-    }
-    if (c->fast_depth + 2 > 64) return fail("BVH depth %d exceeds the 64-entry traversal stack", c->fast_depth);
-    for (int i = 0; i < ni; i++) {
-        float l[2][3], h[2][3];
-        int id[2];
-        for (int k = 0; k < 2; k++) {
-            id[k] = fchild[(size_t)i * 2 + k];
-            if (id[k] < 0) leaf_box(~id[k], l[k], h[k]);
-            else for (int a = 0; a < 3; a++) { l[k][a] = flo[(size_t)id[k] * 3 + a]; h[k][a] = fhi[(size_t)id[k] * 3 + a]; }
-        }
-        for (int a = 0; a < 3; a++) fnode[(size_t)i * 4 + a] = { l[0][a], l[1][a], h[0][a], h[1][a] };
-        fnode[(size_t)i * 4 + 3] = { asf(id[0]), asf(id[1]), 0.f, 0.f };
-    }
-    for (int slot = 0; slot < n; slot++) {
-        int f = c->h_leaf[slot];
-        const float *p0 = pos(f, 0), *p1 = pos(f, 1), *p2 = pos(f, 2);
-        // hoisted terms of Face.intersect, geometries.py:120-122,134-136,140 (same f32 operations)
-        float u[3], v[3], nn[3];
-        for (int a = 0; a < 3; a++) { u[a] = p1[a] - p0[a]; v[a] = p2[a] - p0[a]; }
-        nn[0] = u[1] * v[2] - u[2] * v[1];
-        nn[1] = u[2] * v[0] - u[0] * v[2];
-        nn[2] = u[0] * v[1] - u[1] * v[0];
-        float uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
-        float uv = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
-        float vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-        float D = uv * uv - uu * vv;
-        tgeo[(size_t)slot * 4 + 0] = { p0[0], p0[1], p0[2], D };
-        tgeo[(size_t)slot * 4 + 1] = { u[0], u[1], u[2], uu };
-        tgeo[(size_t)slot * 4 + 2] = { v[0], v[1], v[2], uv };
-        tgeo[(size_t)slot * 4 + 3] = { nn[0], nn[1], nn[2], vv };
-        tshade[(size_t)slot * 4 + 0] = { p0[3], p0[4], p0[5], p1[3] };
-        tshade[(size_t)slot * 4 + 1] = { p1[4], p1[5], p2[3], p2[4] };
-        tshade[(size_t)slot * 4 + 2] = { p2[5], p0[6], p0[7], p1[6] };
-        tshade[(size_t)slot * 4 + 3] = { p1[7], p2[6], p2[7], asf(c->mtlids[f]) };
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((size_t)std::max(ni, 1) > c->node_cap) {
-        hipFree(c->snode); hipFree(c->fnode); c->snode = c->fnode = nullptr;
-        if (dev_alloc(&c->snode, snode.size()) || dev_alloc(&c->fnode, fnode.size())) return 1;
-        c->node_cap = std::max(ni, 1);
-    }
-    if ((size_t)std::max(n, 1) > c->tri_cap) {
-        hipFree(c->tgeo); hipFree(c->tshade); c->tgeo = c->tshade = nullptr;
-        if (dev_alloc(&c->tgeo, tgeo.size()) || dev_alloc(&c->tshade, tshade.size())) return 1;
-        c->tri_cap = std::max(n, 1);
-    }
-    HIP_TRY(hipMemcpyAsync(c->snode, snode.data(), snode.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->fnode, fnode.data(), fnode.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->tgeo, tgeo.data(), tgeo.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->tshade, tshade.data(), tshade.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->tree_valid = true;
-    c->host_tree_valid = true;
-    return 0;
-}
-
-// fnode records for the fast build from a (child, box) description over leaf slots
-static void pack_fnode(mpt_ctx *c, int n, const std::vector<int32_t> &fchild, const std::vector<float> &flo,
-                       const std::vector<float> &fhi, std::vector<MptVec4> &fnode) {
-    const int ni = n > 1 ? n - 1 : 0;
-    const float *V = c->verts.data();
-    auto asf = [](int32_t v) { float f; memcpy(&f, &v, 4); return f; };
-    fnode.assign((size_t)std::max(ni, 1) * 4, MptVec4{ 0, 0, 0, 0 });
-    for (int i = 0; i < ni; i++) {
-        float l[2][3], h[2][3];
-        int id[2];
-        for (int k = 0; k < 2; k++) {
-            id[k] = fchild[(size_t)i * 2 + k];
-            if (id[k] < 0) {
-                int f = c->h_leaf[~id[k]];
-                for (int a = 0; a < 3; a++) {
-                    const float *p0 = V + ((size_t)f * 3) * 8, *p1 = p0 + 8, *p2 = p0 + 16;
-                    l[k][a] = fminf(fminf(p0[a], p1[a]), p2[a]);
-                    h[k][a] = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
-                }
-            } else for (int a = 0; a < 3; a++) { l[k][a] = flo[(size_t)id[k] * 3 + a]; h[k][a] = fhi[(size_t)id[k] * 3 + a]; }
-        }
-        for (int a = 0; a < 3; a++) fnode[(size_t)i * 4 + a] = { l[0][a], l[1][a], h[0][a], h[1][a] };
-        fnode[(size_t)i * 4 + 3] = { asf(id[0]), asf(id[1]), 0.f, 0.f };
-    }
-}
-
-// lbvh.py:297-305 entirely on the device (lbvh_build.hip); only the depth (4 bytes) comes back,
-// plus the leaf order when the fast build wants its SAH re-partition (a host pass today)
-static int build_tree_gpu(mpt_ctx *c) {
-    const int n = c->nfaces;
-    const int ni = n > 1 ? n - 1 : 0;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((size_t)std::max(n, 1) > c->d_model_cap) {
-        hipFree(c->d_verts); hipFree(c->d_mtlids); c->d_verts = nullptr; c->d_mtlids = nullptr;
-        if (dev_alloc(&c->d_verts, (size_t)std::max(n, 1) * 24) || dev_alloc(&c->d_mtlids, (size_t)std::max(n, 1))) return 1;
-        c->d_model_cap = std::max(n, 1);
-    }
-    if ((size_t)std::max(n, 1) > c->d_build_cap) {
-        hipFree(c->d_cen); hipFree(c->d_bounds); hipFree(c->d_depth); hipFree(c->d_keys_in); hipFree(c->d_keys_out);
-        hipFree(c->d_sort_tmp); hipFree(c->d_child); hipFree(c->d_parent); hipFree(c->d_leaf); hipFree(c->d_mc);
-        hipFree(c->d_bmin); hipFree(c->d_bmax); hipFree(c->d_arrive);
-        c->d_cen = nullptr; c->d_bounds = nullptr; c->d_depth = nullptr; c->d_keys_in = c->d_keys_out = nullptr;
-        c->d_sort_tmp = nullptr; c->d_child = c->d_parent = c->d_leaf = c->d_mc = nullptr;
-        c->d_bmin = c->d_bmax = nullptr; c->d_arrive = nullptr;
-        size_t m = std::max(n, 1);
-        HIP_TRY(mpt_lbvh_sort_bytes((int)m, &c->d_sort_bytes));
-        if (dev_alloc(&c->d_cen, m * 3) || dev_alloc(&c->d_bounds, 6) || dev_alloc(&c->d_depth, 1) ||
-            dev_alloc(&c->d_keys_in, m) || dev_alloc(&c->d_keys_out, m) ||
-            dev_alloc((char **)&c->d_sort_tmp, std::max<size_t>(c->d_sort_bytes, 16)) ||
-            dev_alloc(&c->d_child, m * 2) || dev_alloc(&c->d_parent, m * 2) || dev_alloc(&c->d_leaf, m) ||
-            dev_alloc(&c->d_mc, m) || dev_alloc(&c->d_bmin, m * 3) || dev_alloc(&c->d_bmax, m * 3) ||
-            dev_alloc(&c->d_arrive, m)) return 1;
-        c->d_build_cap = m;
-    }
-    if ((size_t)std::max(ni, 1) > c->node_cap) {
-        hipFree(c->snode); hipFree(c->fnode); c->snode = c->fnode = nullptr;
-        if (dev_alloc(&c->snode, (size_t)std::max(ni, 1) * 2) || dev_alloc(&c->fnode, (size_t)std::max(ni, 1) * 4)) return 1;
-        c->node_cap = std::max(ni, 1);
-    }
-    if ((size_t)std::max(n, 1) > c->tri_cap) {
-        hipFree(c->tgeo); hipFree(c->tshade); c->tgeo = c->tshade = nullptr;
-        if (dev_alloc(&c->tgeo, (size_t)std::max(n, 1) * 4) || dev_alloc(&c->tshade, (size_t)std::max(n, 1) * 4)) return 1;
-        c->tri_cap = std::max(n, 1);
-    }
-    if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(c->d_verts, c->verts.data(), (size_t)n * 24 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_mtlids, c->mtlids.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    }
-    MptLbvhBuffers b{};
-    b.verts = c->d_verts; b.mtlids = c->d_mtlids; b.n = n;
-    b.cen = c->d_cen; b.bounds = c->d_bounds; b.keys_in = c->d_keys_in; b.keys_out = c->d_keys_out;
-    b.sort_tmp = c->d_sort_tmp; b.sort_tmp_bytes = c->d_sort_bytes;
-    b.child = c->d_child; b.parent = c->d_parent; b.leaf = c->d_leaf; b.mc = c->d_mc;
-    b.bmin = c->d_bmin; b.bmax = c->d_bmax; b.arrive = c->d_arrive; b.depth = c->d_depth;
-    b.snode = c->snode; b.fnode = c->fnode; b.tgeo = c->tgeo; b.tshade = c->tshade;
-    HIP_TRY(mpt_lbvh_build(&b, c->stream));
-    int depth = 0;
-    if (ni > 0) HIP_TRY(hipMemcpyAsync(&depth, c->d_depth, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (depth + 2 > 64) return fail("LBVH depth %d exceeds the 64-entry traversal stack", depth);
-    c->tree_depth = depth;
-    c->fast_depth = depth;
-    c->host_tree_valid = false;
-    if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max) {
-        // SAH re-partition of the leaves for the fast build (host pass over the leaf order)
-        c->h_leaf.resize(n);
-        HIP_TRY(hipMemcpy(c->h_leaf.data(), c->d_leaf, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-        SahBuild sb;
-        sb.n = n;
-        sb.lo.resize((size_t)n * 3); sb.hi.resize((size_t)n * 3); sb.ctr.resize((size_t)n * 3);
-        const float *V = c->verts.data();
-        for (int slot = 0; slot < n; slot++) {
-            int f = c->h_leaf[slot];
-            const float *p0 = V + ((size_t)f * 3) * 8, *p1 = p0 + 8, *p2 = p0 + 16;
-            for (int a = 0; a < 3; a++) {
-                float l = fminf(fminf(p0[a], p1[a]), p2[a]), h = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
-                sb.lo[(size_t)slot * 3 + a] = l; sb.hi[(size_t)slot * 3 + a] = h; sb.ctr[(size_t)slot * 3 + a] = 0.5f * (l + h);
-            }
-        }
-        sb.run();
-        if (sb.depth + 2 > 64) return fail("BVH depth %d exceeds the 64-entry traversal stack", sb.depth);
-        std::vector<MptVec4> fnode;
-        pack_fnode(c, n, sb.child, sb.blo, sb.bhi, fnode);
-        HIP_TRY(hipMemcpy(c->fnode, fnode.data(), (size_t)ni * 4 * sizeof(MptVec4), hipMemcpyHostToDevice));
-        c->fast_depth = sb.depth;
-    }
-    c->tree_valid = true;
-    return 0;
-}
-
-extern "C" int mpt_build_tree(mpt_ctx *c) {
-    if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
-    return c->gpu_build ? build_tree_gpu(c) : build_tree_host(c);
-}
-
-static int download_tree(mpt_ctx *c) {
-    if (c->host_tree_valid) return 0;
-    const int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
-    c->h_child.assign((size_t)std::max(ni, 1) * 2, 0); c->h_leaf.assign(std::max(n, 1), 0); c->h_mc.assign(std::max(n, 1), 0);
-    c->h_bmin.assign((size_t)std::max(ni, 1) * 3, 0.f); c->h_bmax.assign((size_t)std::max(ni, 1) * 3, 0.f);
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n > 0) {
-        HIP_TRY(hipMemcpy(c->h_leaf.data(), c->d_leaf, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(c->h_mc.data(), c->d_mc, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    }
-    if (ni > 0) {
-        HIP_TRY(hipMemcpy(c->h_child.data(), c->d_child, (size_t)ni * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(c->h_bmin.data(), c->d_bmin, (size_t)ni * 3 * sizeof(float), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(c->h_bmax.data(), c->d_bmax, (size_t)ni * 3 * sizeof(float), hipMemcpyDeviceToHost));
-    }
-    c->host_tree_valid = true;
-    return 0;
-}
-
-extern "C" int mpt_get_tree(mpt_ctx *c, int32_t *child, int32_t *leaf, float *bmin, float *bmax, int32_t *mc,
-                            int32_t *depth) {
-    if (!c) return fail("null context");
-    if (!c->tree_valid) return fail("BVH not built: call build_tree() after load_model()");
-    if (download_tree(c)) return 1;
-    int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
-    if (child) memcpy(child, c->h_child.data(), (size_t)ni * 2 * sizeof(int32_t));
-    if (leaf) memcpy(leaf, c->h_leaf.data(), (size_t)n * sizeof(int32_t));
-    if (bmin) memcpy(bmin, c->h_bmin.data(), (size_t)ni * 3 * sizeof(float));
-    if (bmax) memcpy(bmax, c->h_bmax.data(), (size_t)ni * 3 * sizeof(float));
-    if (mc) memcpy(mc, c->h_mc.data(), (size_t)n * sizeof(int32_t));
-    if (depth) *depth = c->tree_depth;
     return 0;
 }
 
@@ -1428,7 +717,7 @@ extern "C" int mpt_clear(mpt_ctx *c, int pass) {                               /
     return 0;
 }
 
-static int check_pass(mpt_ctx *c, int pass) {
+int check_pass(mpt_ctx *c, int pass) {
     if (pass < 0 || pass >= 3) return fail("film pass %d out of range", pass);
     if (!c->film[pass]) return fail("film size not set: call set_size() first");
     return 0;
@@ -1517,102 +806,5 @@ extern "C" int mpt_kernel_time(mpt_ctx *c, double *ms, int *launches) {
     if (ms) *ms = total;
     if (launches) *launches = (int)c->events.size();
     c->events.clear();
-    return 0;
-}
-
-// ------------------------------------------------------------------ multi-GPU film gather (RCCL over xGMI)
-// One process per GPU; each renders the slab [x0,x1) of a replicated scene.  Film index is
-// x*ny + y (filmtable.py:38), so a slab is ONE contiguous float4 range: every rank sends its
-// range straight into the same range of the root's film -- a one-shot gather on the
-// point-to-point xGMI links, no ring, no reduction.
-
-extern "C" int mpt_comm_unique_id(char uid[128]) {
-    if (rccl_load()) return 1;
-    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
-    ncclUniqueId id;
-    NCCL_TRY(g_rccl.GetUniqueId(&id));
-    memcpy(uid, &id, 128);
-    return 0;
-}
-
-extern "C" int mpt_comm_init(mpt_ctx *c, const char uid[128], int nranks, int rank) {
-    if (use(c)) return 1;
-    if (rccl_load()) return 1;
-    if (c->comm) return fail("communicator already initialised");
-    ncclUniqueId id;
-    memcpy(&id, uid, 128);
-    NCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
-    c->nranks = nranks; c->rank = rank;
-    return 0;
-}
-
-extern "C" int mpt_comm_gather_film(mpt_ctx *c, int pass, int root) {
-    if (use_ro(c)) return 1;
-    if (mpt_flush(c)) return 1;
-    if (check_pass(c, pass)) return 1;
-    if (!c->comm) return fail("communicator not initialised");
-    // every rank holds the same split: contiguous slabs x in [r*nx/R, (r+1)*nx/R), or -- after
-    // mpt_set_stripes(width, rank, R) -- stripes r, r+R, ... of `width` columns; each piece is one
-    // contiguous float4 range (film index x*ny + y) and travels as its own send/recv of one group
-    const int R = c->nranks;
-    if (c->stripe_w && (c->stripe_mod != R || c->stripe_idx != c->rank))
-        return fail("stripes (index %d of %d) do not match the communicator (rank %d of %d)", c->stripe_idx,
-                    c->stripe_mod, c->rank, R);
-    auto pieces = [&](int r, std::vector<std::pair<size_t, size_t>> &out) {
-        out.clear();
-        if (c->stripe_w == 0) {
-            size_t lo = (size_t)((long long)r * c->nx / R) * c->ny, hi = (size_t)((long long)(r + 1) * c->nx / R) * c->ny;
-            if (hi > lo) out.push_back({ lo, hi - lo });
-        } else {
-            for (long long x = (long long)r * c->stripe_w; x < c->nx; x += (long long)c->stripe_w * R) {
-                long long w = std::min<long long>(c->stripe_w, c->nx - x);
-                out.push_back({ (size_t)x * c->ny, (size_t)w * c->ny });
-            }
-        }
-    };
-    std::vector<std::pair<size_t, size_t>> pc;
-    NCCL_TRY(g_rccl.GroupStart());
-    if (c->rank == root) {
-        for (int r = 0; r < R; r++) {
-            if (r == root) continue;
-            pieces(r, pc);
-            for (auto &q : pc) NCCL_TRY(g_rccl.Recv(c->film[pass] + q.first, q.second * 4, ncclFloat, r, c->comm, c->stream));
-        }
-    } else {
-        pieces(c->rank, pc);
-        for (auto &q : pc) NCCL_TRY(g_rccl.Send(c->film[pass] + q.first, q.second * 4, ncclFloat, root, c->comm, c->stream));
-    }
-    NCCL_TRY(g_rccl.GroupEnd());
-    return 0;
-}
-
-extern "C" int mpt_comm_barrier(mpt_ctx *c) {
-    if (use_ro(c)) return 1;
-    if (mpt_flush(c)) return 1;
-    if (!c->comm) return fail("communicator not initialised");
-    HIP_TRY(hipMemsetAsync(c->d_scratch, 0, sizeof(double), c->stream));
-    NCCL_TRY(g_rccl.AllReduce(c->d_scratch, c->d_scratch, 1, ncclDouble, ncclSum, c->comm, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-extern "C" int mpt_comm_allreduce_max(mpt_ctx *c, double *value) {
-    if (use_ro(c)) return 1;
-    if (!c->comm) return fail("communicator not initialised");
-    HIP_TRY(hipMemcpyAsync(c->d_scratch, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
-    NCCL_TRY(g_rccl.AllReduce(c->d_scratch, c->d_scratch, 1, ncclDouble, ncclMax, c->comm, c->stream));
-    HIP_TRY(hipMemcpyAsync(value, c->d_scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-extern "C" int mpt_comm_destroy(mpt_ctx *c) {
-    if (use(c)) return 1;
-    if (c->comm) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        NCCL_TRY(g_rccl.CommDestroy(c->comm));
-        c->comm = nullptr;
-    }
-    c->nranks = 1; c->rank = 0;
     return 0;
 }

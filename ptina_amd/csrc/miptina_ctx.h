@@ -1,0 +1,172 @@
+// miptina_ctx.h -- what the translation units of the host runtime share: the context, the error
+// plumbing and the launchers of the kernels.  Internal; the public surface is include/miptina.h.
+#pragma once
+
+#include "../../include/miptina.h"
+#include "mpt_types.h"
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// kernel launchers (render_kernel.hip x2, aux_kernels.hip)
+extern "C" hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
+extern "C" hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
+extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
+extern "C" hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
+extern "C" hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
+extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
+                                              int keep, hipStream_t);
+extern "C" hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
+                                         int stripe_w, int stripe_pitch,
+                                         int nchunks, hipStream_t);
+extern "C" hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
+extern "C" hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
+
+// on-GPU LBVH build (lbvh_build.hip)
+struct MptLbvhBuffers {
+    const float *verts; const int *mtlids; int n;
+    float *cen; int *bounds;
+    unsigned long long *keys_in, *keys_out;
+    void *sort_tmp; size_t sort_tmp_bytes;
+    int *child, *parent, *leaf, *mc;
+    float *bmin, *bmax;
+    unsigned *arrive;
+    int *depth;
+    MptVec4 *snode, *fnode, *tgeo, *tshade;
+};
+extern "C" hipError_t mpt_lbvh_sort_bytes(int n, size_t *bytes);
+extern "C" hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t stream);
+
+// ------------------------------------------------------------------ errors (miptina.cpp)
+#define MPT_INTERNAL __attribute__((visibility("hidden")))   // shared between the .cpp files, not exported
+MPT_INTERNAL int fail(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------ context
+enum { MPT_MAX_PIPE = 6 };
+
+struct mpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mpt_caps caps{};
+
+    // options
+    int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1, lds_block = 0;
+    int num_cus = 256;
+    int tile_w_shift = 3, tile_h_shift = 3;   // work-item tile 2^w x 2^h pixels
+    int sched_num = 2, sched_den = 1;    // scheduler: stay in traversal mode while traversing*num >= waiting*den (tuned on MI355X)
+    int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
+
+    // film
+    int nx = 0, ny = 0, x0 = 0, x1 = 0;
+    int stripe_w = 0, stripe_idx = 0, stripe_mod = 1;   // stripe_w > 0: columns dealt out in stripes (mpt_set_stripes)
+    MptVec4 *film[3] = { nullptr, nullptr, nullptr };
+    size_t film_cap = 0;                 // pixels allocated per pass
+    MptVec4 *resolved = nullptr;         // nx*ny float4 (get_image staging on device)
+    float *exported = nullptr;           // nx*ny*3
+
+    // model (host copy kept for the tree build)
+    int nfaces = 0;
+    std::vector<float> verts;            // [3n][8]
+    std::vector<int32_t> mtlids;
+    bool tree_valid = false;
+    int tree_depth = 0;                  // reference LBVH (strict build)
+    int fast_depth = 0;                  // tree the fast build walks (SAH or LBVH)
+    int tree_kind = 1;                   // fast build: 1 = SAH re-partition of the LBVH's leaves, 0 = the LBVH itself
+    int gpu_build = 1;                   // 1 = LBVH built on the device (lbvh_build.hip), 0 = host build
+    int sah_max = 1 << 18;               // above this many faces the fast build walks the LBVH itself
+    bool host_tree_valid = false;        // h_child/h_leaf/... mirror the device tree (lazily downloaded)
+    // device-side build workspace
+    float *d_verts = nullptr; int *d_mtlids = nullptr; size_t d_model_cap = 0;
+    float *d_cen = nullptr; int *d_bounds = nullptr; int *d_depth = nullptr;
+    unsigned long long *d_keys_in = nullptr, *d_keys_out = nullptr;
+    void *d_sort_tmp = nullptr; size_t d_sort_bytes = 0;
+    int *d_child = nullptr, *d_parent = nullptr, *d_leaf = nullptr, *d_mc = nullptr;
+    float *d_bmin = nullptr, *d_bmax = nullptr;
+    unsigned *d_arrive = nullptr;
+    size_t d_build_cap = 0;
+    std::vector<int32_t> h_child, h_leaf, h_mc;
+    std::vector<float> h_bmin, h_bmax;
+    MptVec4 *snode = nullptr, *fnode = nullptr, *tgeo = nullptr, *tshade = nullptr;
+    size_t node_cap = 0, tri_cap = 0;
+
+    // materials / images / lights / world / camera
+    MptMaterial *mats = nullptr;
+    MptImage *images = nullptr;
+    std::vector<MptImage> h_images;
+    MptVec4 *texels = nullptr;
+    size_t texels_used = 0;
+    MptLight *lights = nullptr;
+    std::vector<MptLight> h_lights;
+    float world_fac[4] = { 0.1f, 0.1f, 0.1f, 0.1f };   // light/world.py:14-16
+    int world_tex = -1;                                 // documented deviation Q6 (reference default 0)
+    float v2w[16], w2v[16];
+
+    // sobol
+    int sdim = 0, srows = 0;
+    int32_t stime = 0;
+    int *sV = nullptr, *sX = nullptr;
+    float *sP = nullptr;                 // [MPT_MAX_BATCH][sdim]
+
+    // command batching
+    int pending = 0;
+
+    // launch pipelining (fast build): batch i renders on rstream[i & 1] into partial[i & 1] while the main
+    // stream still combines / gathers / resolves batch i-1, so one launch's tail overlaps the next one's head
+    hipStream_t rstream[MPT_MAX_PIPE] = {};
+    hipEvent_t ev_render[MPT_MAX_PIPE] = {};          // render of the batch on rstream[k] finished
+    hipEvent_t ev_free[MPT_MAX_PIPE] = {};            // combine has consumed partial[k]
+    hipStream_t aux = nullptr;                        // Sobol advances + queue resets of the pipelined batches
+    hipEvent_t ev_sobol2[MPT_MAX_PIPE] = {};          // Sobol points + zeroed queue heads of the batch on rstream[k] ready
+    int pipe_depth = 0;                               // batches in flight (slots of P / partial / queue heads); 0 = auto
+    int grid_div = 0;                                 // each launch takes 1/grid_div of the CUs; 0 = auto
+    int cur_depth = 2, cur_div = 1;                   // what the last launch used
+    hipEvent_t ev_main = nullptr;                     // main-stream work a render must see (uploads, resets, ...)
+    bool main_dirty = true;
+    int flip = 0;
+    MptVec4 *partial2[MPT_MAX_PIPE] = {};
+    size_t partial2_cap[MPT_MAX_PIPE] = {};           // float4 elements per buffer
+    float *sP2[MPT_MAX_PIPE] = {};
+    unsigned int *d_work2[MPT_MAX_PIPE] = {};
+
+    // measurement
+    int timeline = 0;                    // 1: the LDS kernel records per-wave timestamps of its last launch
+    unsigned long long *d_timeline = nullptr;
+    int timeline_waves = 0;
+    unsigned long long *d_counters = nullptr;
+    unsigned int *d_work = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<hipEvent_t> event_pool;
+
+    // comm
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    double *d_scratch = nullptr;
+};
+
+// entry checks of the API calls (miptina.cpp)
+MPT_INTERNAL int use_ro(mpt_ctx *c);   // calls that only read results
+MPT_INTERNAL int use(mpt_ctx *c);      // calls that may change what the next render launch reads
+MPT_INTERNAL int check_pass(mpt_ctx *c, int pass);
+
+template <class T>
+static int dev_alloc(T **p, size_t count) {
+    HIP_TRY(hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return 0;
+}
+
+// comm.cpp
+MPT_INTERNAL void mpt_comm_release(mpt_ctx *c);   // mpt_destroy: drop the communicator, if any
+

@@ -1,0 +1,509 @@
+// tree_build.cpp -- BVH construction behind mpt_build_tree: the reference LBVH on the host, its
+// SAH re-partition for the fast build, and the glue around the device build (lbvh_build.hip).
+
+#include "miptina_ctx.h"
+
+// ------------------------------------------------------------------ LBVH build (tree/lbvh.py:169-305)
+// Same algorithm as the reference (30-bit Morton codes of centroids, sorted, Karras hierarchy,
+// bottom-up boxes) with two robustness changes: the sort key is (code << 32 | index), so equal
+// codes cannot corrupt the hierarchy, and the boxes are fitted in one post-order
+// pass instead of <=64 level-synchronous launches with a read-back each (lbvh.py:251-261).
+// With distinct codes the tree is node-for-node the reference's.
+
+static inline uint32_t expand_bits(uint32_t v) {                               // lbvh.py:13-17
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+static inline int quant1024(float x) {                                         // clamp(ifloor(v * 1024), 0, 1023), lbvh.py:29
+    float f = floorf(x * 1024.0f);
+    if (!(f == f) || f < 0.f) return 0;
+    if (f > 1023.f) return 1023;
+    return (int)f;
+}
+
+static inline int delta(const std::vector<uint64_t> &key, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __builtin_clzll(key[i] ^ key[j]);
+}
+
+// ------------------------------------------------------------------ SAH re-partition (fast build only)
+// The image does not depend on the tree's shape (only on which of two equal-depth hits wins), so the
+// production traversal is free to walk a better tree over the SAME leaf slots: measured on the
+// 978-triangle benchmark scene a full-sweep SAH partition needs 11.0 node fetches per ray where the
+// LBVH needs 23.7.  Leaves stay single triangles (the node record is unchanged); nodes are numbered
+// in DFS pre-order, root 0.  Exact sweep for ranges <= 8192 leaves, 32-bin SAH above.
+struct SahBuild {
+    int n = 0;
+    std::vector<float> lo, hi, ctr;            // per leaf slot [n][3]
+    std::vector<int> idx;                      // leaf slots, partitioned in place
+    std::vector<int32_t> child;                // [n-1][2]: >= 0 internal, ~slot leaf
+    std::vector<float> blo, bhi;               // per internal node [n-1][3]: its own box
+    int depth = 0;
+
+    static float half_area(const float *l, const float *h) {
+        float dx = std::max(h[0] - l[0], 0.f), dy = std::max(h[1] - l[1], 0.f), dz = std::max(h[2] - l[2], 0.f);
+        return dx * dy + dy * dz + dz * dx;
+    }
+
+    int split(int b, int e) {                  // returns m in (b, e): [b, m) | [m, e)
+        const int cnt = e - b;
+        float best = INFINITY;
+        int best_axis = -1, best_k = -1;
+        float best_pos = 0.f;
+        bool binned = cnt > 8192;
+        std::vector<std::pair<float, int>> key(binned ? 0 : cnt);
+        std::vector<float> rarea(binned ? 0 : cnt);
+        float cl[3] = { INFINITY, INFINITY, INFINITY }, ch[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (int t = b; t < e; t++)
+            for (int a = 0; a < 3; a++) {
+                cl[a] = std::min(cl[a], ctr[(size_t)idx[t] * 3 + a]);
+                ch[a] = std::max(ch[a], ctr[(size_t)idx[t] * 3 + a]);
+            }
+        for (int a = 0; a < 3; a++) {
+            if (!(ch[a] > cl[a])) continue;
+            if (!binned) {
+                for (int t = 0; t < cnt; t++) key[t] = { ctr[(size_t)idx[b + t] * 3 + a], idx[b + t] };
+                std::sort(key.begin(), key.end());
+                float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
+                for (int t = cnt - 1; t > 0; t--) {
+                    int s = key[t].second;
+                    for (int q = 0; q < 3; q++) { l[q] = std::min(l[q], lo[(size_t)s * 3 + q]); h[q] = std::max(h[q], hi[(size_t)s * 3 + q]); }
+                    rarea[t] = half_area(l, h);
+                }
+                for (int q = 0; q < 3; q++) { l[q] = INFINITY; h[q] = -INFINITY; }
+                for (int k = 1; k < cnt; k++) {
+                    int s = key[k - 1].second;
+                    for (int q = 0; q < 3; q++) { l[q] = std::min(l[q], lo[(size_t)s * 3 + q]); h[q] = std::max(h[q], hi[(size_t)s * 3 + q]); }
+                    float cost = half_area(l, h) * k + rarea[k] * (cnt - k);
+                    if (cost < best) { best = cost; best_axis = a; best_k = k; }
+                }
+            } else {
+                const int NB = 32;
+                float bl[NB][3], bh[NB][3];
+                int bc[NB];
+                for (int q = 0; q < NB; q++) { bc[q] = 0; for (int r = 0; r < 3; r++) { bl[q][r] = INFINITY; bh[q][r] = -INFINITY; } }
+                float scale = NB / (ch[a] - cl[a]);
+                for (int t = b; t < e; t++) {
+                    int s = idx[t];
+                    int q = std::min(NB - 1, std::max(0, (int)((ctr[(size_t)s * 3 + a] - cl[a]) * scale)));
+                    bc[q]++;
+                    for (int r = 0; r < 3; r++) { bl[q][r] = std::min(bl[q][r], lo[(size_t)s * 3 + r]); bh[q][r] = std::max(bh[q][r], hi[(size_t)s * 3 + r]); }
+                }
+                float ra[NB]; int rc[NB];
+                float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
+                int c2 = 0;
+                for (int q = NB - 1; q > 0; q--) {
+                    c2 += bc[q];
+                    for (int r = 0; r < 3; r++) { l[r] = std::min(l[r], bl[q][r]); h[r] = std::max(h[r], bh[q][r]); }
+                    ra[q] = half_area(l, h); rc[q] = c2;
+                }
+                for (int r = 0; r < 3; r++) { l[r] = INFINITY; h[r] = -INFINITY; }
+                int c1 = 0;
+                for (int q = 1; q < NB; q++) {
+                    c1 += bc[q - 1];
+                    for (int r = 0; r < 3; r++) { l[r] = std::min(l[r], bl[q - 1][r]); h[r] = std::max(h[r], bh[q - 1][r]); }
+                    if (c1 == 0 || rc[q] == 0) continue;
+                    float cost = half_area(l, h) * c1 + ra[q] * rc[q];
+                    if (cost < best) { best = cost; best_axis = a; best_k = c1; best_pos = cl[a] + q / scale; }
+                }
+            }
+        }
+        if (best_axis < 0) return b + cnt / 2;                 // all centroids equal: split the range in half
+        if (!binned) {
+            for (int t = 0; t < cnt; t++) key[t] = { ctr[(size_t)idx[b + t] * 3 + best_axis], idx[b + t] };
+            std::sort(key.begin(), key.end());
+            for (int t = 0; t < cnt; t++) idx[b + t] = key[t].second;
+            return b + best_k;
+        }
+        int a = best_axis;
+        const int NB = 32;
+        float scale = NB / (ch[a] - cl[a]);
+        int qsplit = (int)std::lround((best_pos - cl[a]) * scale);
+        int m = (int)(std::partition(idx.begin() + b, idx.begin() + e, [&](int s) {
+                          int q = std::min(NB - 1, std::max(0, (int)((ctr[(size_t)s * 3 + a] - cl[a]) * scale)));
+                          return q < qsplit;
+                      }) - idx.begin());
+        if (m <= b || m >= e) m = b + cnt / 2;
+        return m;
+    }
+
+    void run() {
+        const int ni = n > 1 ? n - 1 : 0;
+        child.assign((size_t)std::max(ni, 1) * 2, 0);
+        blo.assign((size_t)std::max(ni, 1) * 3, 0.f);
+        bhi.assign((size_t)std::max(ni, 1) * 3, 0.f);
+        idx.resize(n);
+        for (int i = 0; i < n; i++) idx[i] = i;
+        depth = 0;
+        if (ni == 0) return;
+        struct Item { int b, e, parent, which, depth; };
+        std::vector<Item> st;
+        st.push_back({ 0, n, -1, 0, 1 });
+        int next_node = 0;
+        while (!st.empty()) {
+            Item it = st.back(); st.pop_back();
+            int me = next_node++;
+            if (it.parent >= 0) child[(size_t)it.parent * 2 + it.which] = me;
+            depth = std::max(depth, it.depth);
+            float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (int t = it.b; t < it.e; t++)
+                for (int q = 0; q < 3; q++) { l[q] = std::min(l[q], lo[(size_t)idx[t] * 3 + q]); h[q] = std::max(h[q], hi[(size_t)idx[t] * 3 + q]); }
+            for (int q = 0; q < 3; q++) { blo[(size_t)me * 3 + q] = l[q]; bhi[(size_t)me * 3 + q] = h[q]; }
+            int m = split(it.b, it.e);
+            // right first on the stack so the left subtree gets the next indices (pre-order)
+            if (it.e - m == 1) child[(size_t)me * 2 + 1] = ~idx[m];
+            else st.push_back({ m, it.e, me, 1, it.depth + 1 });
+            if (m - it.b == 1) child[(size_t)me * 2 + 0] = ~idx[it.b];
+            else st.push_back({ it.b, m, me, 0, it.depth + 1 });
+        }
+    }
+};
+
+static int build_tree_host(mpt_ctx *c) {
+    const int n = c->nfaces;
+    const float *V = c->verts.data();
+    auto pos = [&](int f, int k) { return V + ((size_t)f * 3 + k) * 8; };
+
+    // genMortonCodes, lbvh.py:169-183
+    float bmin[3] = { 1e6f, 1e6f, 1e6f }, bmax[3] = { -1e6f, -1e6f, -1e6f };
+    std::vector<float> cen((size_t)n * 3);
+    for (int f = 0; f < n; f++)
+        for (int a = 0; a < 3; a++) {
+            float ctr = ((pos(f, 0)[a] + pos(f, 1)[a]) + pos(f, 2)[a]) / 3.0f;   // lbvh.py:164
+            cen[(size_t)f * 3 + a] = ctr;
+            bmin[a] = fminf(bmin[a], ctr);
+            bmax[a] = fmaxf(bmax[a], ctr);
+        }
+    std::vector<uint64_t> key(n);
+    for (int f = 0; f < n; f++) {
+        uint32_t w[3];
+        for (int a = 0; a < 3; a++) w[a] = expand_bits((uint32_t)quant1024((cen[(size_t)f * 3 + a] - bmin[a]) / (bmax[a] - bmin[a])));
+        uint32_t code = w[0] * 4 + w[1] * 2 + w[2];
+        key[f] = ((uint64_t)code << 32) | (uint32_t)f;
+    }
+    std::sort(key.begin(), key.end());                                          // lbvh.py:204-208
+
+    c->h_leaf.resize(n); c->h_mc.resize(n);
+    for (int i = 0; i < n; i++) { c->h_leaf[i] = (int32_t)(key[i] & 0xffffffffu); c->h_mc[i] = (int32_t)(key[i] >> 32); }
+
+    const int ni = n > 1 ? n - 1 : 0;
+    c->h_child.assign((size_t)std::max(ni, 1) * 2, 0);
+    c->h_bmin.assign((size_t)std::max(ni, 1) * 3, 0.f);
+    c->h_bmax.assign((size_t)std::max(ni, 1) * 3, 0.f);
+
+    // genHierarchy, lbvh.py:212-231 (determineRange :93-146, findSplit :62-89)
+    for (int i = 0; i < ni; i++) {
+        int l, r;
+        if (i == 0) { l = 0; r = n - 1; }
+        else {
+            int d = delta(key, n, i, i + 1) > delta(key, n, i, i - 1) ? 1 : -1;
+            int dmin = delta(key, n, i, i - d);
+            int lmax = 2;
+            while (delta(key, n, i, i + lmax * d) > dmin) lmax <<= 1;
+            int s = 0;
+            for (int t = lmax >> 1; t > 0; t >>= 1)
+                if (delta(key, n, i, i + (s + t) * d) > dmin) s += t;
+            l = i; r = i + s * d;
+            if (d < 0) std::swap(l, r);
+        }
+        int cp = delta(key, n, l, r);
+        int m = l, s = r - l;
+        for (;;) {
+            s = (s + 1) >> 1;
+            int q = m + s;
+            if (q < r && delta(key, n, l, q) > cp) m = q;
+            if (s <= 1) break;
+        }
+        c->h_child[(size_t)i * 2 + 0] = (m == l) ? m : m + n;
+        c->h_child[(size_t)i * 2 + 1] = (m + 1 == r) ? m + 1 : m + 1 + n;
+    }
+
+    // boxes: iterative post-order from the root (also yields the depth the LDS stack must hold)
+    auto leaf_box = [&](int slot, float *lo, float *hi) {                       // lbvh.py:155-158
+        int f = c->h_leaf[slot];
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(fminf(pos(f, 0)[a], pos(f, 1)[a]), pos(f, 2)[a]);
+            hi[a] = fmaxf(fmaxf(pos(f, 0)[a], pos(f, 1)[a]), pos(f, 2)[a]);
+        }
+    };
+    int depth = 0;
+    if (ni > 0) {
+        std::vector<int> order; order.reserve(ni);
+        std::vector<std::pair<int, int>> st; st.push_back({ 0, 1 });
+        std::vector<char> seen(ni, 0);
+        while (!st.empty()) {
+            auto [i, dpt] = st.back(); st.pop_back();
+            if (i < 0 || i >= ni || seen[i]) return fail("AABB step never stop! hierarchy corrupted?");   // lbvh.py:259
+            seen[i] = 1;
+            order.push_back(i);
+            depth = std::max(depth, dpt);
+            for (int k = 0; k < 2; k++) {
+                int ch = c->h_child[(size_t)i * 2 + k];
+                if (ch >= n) st.push_back({ ch - n, dpt + 1 });
+            }
+        }
+        if ((int)order.size() != ni) return fail("AABB step never stop! hierarchy corrupted?");
+        for (int t = ni - 1; t >= 0; t--) {                                     // children before parents
+            int i = order[t];
+            float lo[2][3], hi[2][3];
+            for (int k = 0; k < 2; k++) {
+                int ch = c->h_child[(size_t)i * 2 + k];
+                if (ch < n) leaf_box(ch, lo[k], hi[k]);
+                else for (int a = 0; a < 3; a++) { lo[k][a] = c->h_bmin[(size_t)(ch - n) * 3 + a]; hi[k][a] = c->h_bmax[(size_t)(ch - n) * 3 + a]; }
+            }
+            for (int a = 0; a < 3; a++) {
+                c->h_bmin[(size_t)i * 3 + a] = fminf(lo[0][a], lo[1][a]);
+                c->h_bmax[(size_t)i * 3 + a] = fmaxf(hi[0][a], hi[1][a]);
+            }
+        }
+    }
+    c->tree_depth = depth;
+    if (depth + 2 > 64) return fail("LBVH depth %d exceeds the 64-entry traversal stack", depth);
+
+    // pack device records
+    std::vector<MptVec4> snode((size_t)std::max(ni, 1) * 2), fnode((size_t)std::max(ni, 1) * 4);
+    std::vector<MptVec4> tgeo((size_t)std::max(n, 1) * 4), tshade((size_t)std::max(n, 1) * 4);
+    auto asf = [](int32_t v) { float f; memcpy(&f, &v, 4); return f; };
+    for (int i = 0; i < ni; i++) {
+        const float *lo = &c->h_bmin[(size_t)i * 3], *hi = &c->h_bmax[(size_t)i * 3];
+        int c0 = c->h_child[(size_t)i * 2], c1 = c->h_child[(size_t)i * 2 + 1];
+        snode[(size_t)i * 2 + 0] = { lo[0], lo[1], lo[2], asf(c0) };
+        snode[(size_t)i * 2 + 1] = { hi[0], hi[1], hi[2], asf(c1) };
+    }
+    // the tree the fast build walks: child ids >= 0 internal, ~slot leaf; a node record holds its
+    // two children's boxes
+    std::vector<int32_t> fchild((size_t)std::max(ni, 1) * 2, 0);
+    std::vector<float> flo((size_t)std::max(ni, 1) * 3, 0.f), fhi((size_t)std::max(ni, 1) * 3, 0.f);
+    if (c->tree_kind == 1 && ni > 0) {
+        SahBuild sb;
+        sb.n = n;
+        sb.lo.resize((size_t)n * 3); sb.hi.resize((size_t)n * 3); sb.ctr.resize((size_t)n * 3);
+        for (int slot = 0; slot < n; slot++) {
+            float l[3], h[3];
+            leaf_box(slot, l, h);
+            for (int a = 0; a < 3; a++) {
+                sb.lo[(size_t)slot * 3 + a] = l[a]; sb.hi[(size_t)slot * 3 + a] = h[a];
+                sb.ctr[(size_t)slot * 3 + a] = 0.5f * (l[a] + h[a]);
+            }
+        }
+        sb.run();
+        fchild = sb.child; flo = sb.blo; fhi = sb.bhi;
+        c->fast_depth = sb.depth;
+    } else {
+        for (int i = 0; i < ni; i++) {
+            for (int k = 0; k < 2; k++) {
+                int ch = c->h_child[(size_t)i * 2 + k];
+                fchild[(size_t)i * 2 + k] = ch < n ? ~ch : ch - n;
+            }
+            for (int a = 0; a < 3; a++) { flo[(size_t)i * 3 + a] = c->h_bmin[(size_t)i * 3 + a]; fhi[(size_t)i * 3 + a] = c->h_bmax[(size_t)i * 3 + a]; }
+        }
+        c->fast_depth = depth;
+    }
+    if (c->fast_depth + 2 > 64) return fail("BVH depth %d exceeds the 64-entry traversal stack", c->fast_depth);
+    for (int i = 0; i < ni; i++) {
+        float l[2][3], h[2][3];
+        int id[2];
+        for (int k = 0; k < 2; k++) {
+            id[k] = fchild[(size_t)i * 2 + k];
+            if (id[k] < 0) leaf_box(~id[k], l[k], h[k]);
+            else for (int a = 0; a < 3; a++) { l[k][a] = flo[(size_t)id[k] * 3 + a]; h[k][a] = fhi[(size_t)id[k] * 3 + a]; }
+        }
+        for (int a = 0; a < 3; a++) fnode[(size_t)i * 4 + a] = { l[0][a], l[1][a], h[0][a], h[1][a] };
+        fnode[(size_t)i * 4 + 3] = { asf(id[0]), asf(id[1]), 0.f, 0.f };
+    }
+    for (int slot = 0; slot < n; slot++) {
+        int f = c->h_leaf[slot];
+        const float *p0 = pos(f, 0), *p1 = pos(f, 1), *p2 = pos(f, 2);
+        // hoisted terms of Face.intersect, geometries.py:120-122,134-136,140 (same f32 operations)
+        float u[3], v[3], nn[3];
+        for (int a = 0; a < 3; a++) { u[a] = p1[a] - p0[a]; v[a] = p2[a] - p0[a]; }
+        nn[0] = u[1] * v[2] - u[2] * v[1];
+        nn[1] = u[2] * v[0] - u[0] * v[2];
+        nn[2] = u[0] * v[1] - u[1] * v[0];
+        float uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+        float uv = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
+        float vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        float D = uv * uv - uu * vv;
+        tgeo[(size_t)slot * 4 + 0] = { p0[0], p0[1], p0[2], D };
+        tgeo[(size_t)slot * 4 + 1] = { u[0], u[1], u[2], uu };
+        tgeo[(size_t)slot * 4 + 2] = { v[0], v[1], v[2], uv };
+        tgeo[(size_t)slot * 4 + 3] = { nn[0], nn[1], nn[2], vv };
+        tshade[(size_t)slot * 4 + 0] = { p0[3], p0[4], p0[5], p1[3] };
+        tshade[(size_t)slot * 4 + 1] = { p1[4], p1[5], p2[3], p2[4] };
+        tshade[(size_t)slot * 4 + 2] = { p2[5], p0[6], p0[7], p1[6] };
+        tshade[(size_t)slot * 4 + 3] = { p1[7], p2[6], p2[7], asf(c->mtlids[f]) };
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((size_t)std::max(ni, 1) > c->node_cap) {
+        hipFree(c->snode); hipFree(c->fnode); c->snode = c->fnode = nullptr;
+        if (dev_alloc(&c->snode, snode.size()) || dev_alloc(&c->fnode, fnode.size())) return 1;
+        c->node_cap = std::max(ni, 1);
+    }
+    if ((size_t)std::max(n, 1) > c->tri_cap) {
+        hipFree(c->tgeo); hipFree(c->tshade); c->tgeo = c->tshade = nullptr;
+        if (dev_alloc(&c->tgeo, tgeo.size()) || dev_alloc(&c->tshade, tshade.size())) return 1;
+        c->tri_cap = std::max(n, 1);
+    }
+    HIP_TRY(hipMemcpyAsync(c->snode, snode.data(), snode.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->fnode, fnode.data(), fnode.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tgeo, tgeo.data(), tgeo.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tshade, tshade.data(), tshade.size() * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->tree_valid = true;
+    c->host_tree_valid = true;
+    return 0;
+}
+
+// fnode records for the fast build from a (child, box) description over leaf slots
+static void pack_fnode(mpt_ctx *c, int n, const std::vector<int32_t> &fchild, const std::vector<float> &flo,
+                       const std::vector<float> &fhi, std::vector<MptVec4> &fnode) {
+    const int ni = n > 1 ? n - 1 : 0;
+    const float *V = c->verts.data();
+    auto asf = [](int32_t v) { float f; memcpy(&f, &v, 4); return f; };
+    fnode.assign((size_t)std::max(ni, 1) * 4, MptVec4{ 0, 0, 0, 0 });
+    for (int i = 0; i < ni; i++) {
+        float l[2][3], h[2][3];
+        int id[2];
+        for (int k = 0; k < 2; k++) {
+            id[k] = fchild[(size_t)i * 2 + k];
+            if (id[k] < 0) {
+                int f = c->h_leaf[~id[k]];
+                for (int a = 0; a < 3; a++) {
+                    const float *p0 = V + ((size_t)f * 3) * 8, *p1 = p0 + 8, *p2 = p0 + 16;
+                    l[k][a] = fminf(fminf(p0[a], p1[a]), p2[a]);
+                    h[k][a] = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
+                }
+            } else for (int a = 0; a < 3; a++) { l[k][a] = flo[(size_t)id[k] * 3 + a]; h[k][a] = fhi[(size_t)id[k] * 3 + a]; }
+        }
+        for (int a = 0; a < 3; a++) fnode[(size_t)i * 4 + a] = { l[0][a], l[1][a], h[0][a], h[1][a] };
+        fnode[(size_t)i * 4 + 3] = { asf(id[0]), asf(id[1]), 0.f, 0.f };
+    }
+}
+
+// lbvh.py:297-305 entirely on the device (lbvh_build.hip); only the depth (4 bytes) comes back,
+// plus the leaf order when the fast build wants its SAH re-partition (a host pass today)
+static int build_tree_gpu(mpt_ctx *c) {
+    const int n = c->nfaces;
+    const int ni = n > 1 ? n - 1 : 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((size_t)std::max(n, 1) > c->d_model_cap) {
+        hipFree(c->d_verts); hipFree(c->d_mtlids); c->d_verts = nullptr; c->d_mtlids = nullptr;
+        if (dev_alloc(&c->d_verts, (size_t)std::max(n, 1) * 24) || dev_alloc(&c->d_mtlids, (size_t)std::max(n, 1))) return 1;
+        c->d_model_cap = std::max(n, 1);
+    }
+    if ((size_t)std::max(n, 1) > c->d_build_cap) {
+        hipFree(c->d_cen); hipFree(c->d_bounds); hipFree(c->d_depth); hipFree(c->d_keys_in); hipFree(c->d_keys_out);
+        hipFree(c->d_sort_tmp); hipFree(c->d_child); hipFree(c->d_parent); hipFree(c->d_leaf); hipFree(c->d_mc);
+        hipFree(c->d_bmin); hipFree(c->d_bmax); hipFree(c->d_arrive);
+        c->d_cen = nullptr; c->d_bounds = nullptr; c->d_depth = nullptr; c->d_keys_in = c->d_keys_out = nullptr;
+        c->d_sort_tmp = nullptr; c->d_child = c->d_parent = c->d_leaf = c->d_mc = nullptr;
+        c->d_bmin = c->d_bmax = nullptr; c->d_arrive = nullptr;
+        size_t m = std::max(n, 1);
+        HIP_TRY(mpt_lbvh_sort_bytes((int)m, &c->d_sort_bytes));
+        if (dev_alloc(&c->d_cen, m * 3) || dev_alloc(&c->d_bounds, 6) || dev_alloc(&c->d_depth, 1) ||
+            dev_alloc(&c->d_keys_in, m) || dev_alloc(&c->d_keys_out, m) ||
+            dev_alloc((char **)&c->d_sort_tmp, std::max<size_t>(c->d_sort_bytes, 16)) ||
+            dev_alloc(&c->d_child, m * 2) || dev_alloc(&c->d_parent, m * 2) || dev_alloc(&c->d_leaf, m) ||
+            dev_alloc(&c->d_mc, m) || dev_alloc(&c->d_bmin, m * 3) || dev_alloc(&c->d_bmax, m * 3) ||
+            dev_alloc(&c->d_arrive, m)) return 1;
+        c->d_build_cap = m;
+    }
+    if ((size_t)std::max(ni, 1) > c->node_cap) {
+        hipFree(c->snode); hipFree(c->fnode); c->snode = c->fnode = nullptr;
+        if (dev_alloc(&c->snode, (size_t)std::max(ni, 1) * 2) || dev_alloc(&c->fnode, (size_t)std::max(ni, 1) * 4)) return 1;
+        c->node_cap = std::max(ni, 1);
+    }
+    if ((size_t)std::max(n, 1) > c->tri_cap) {
+        hipFree(c->tgeo); hipFree(c->tshade); c->tgeo = c->tshade = nullptr;
+        if (dev_alloc(&c->tgeo, (size_t)std::max(n, 1) * 4) || dev_alloc(&c->tshade, (size_t)std::max(n, 1) * 4)) return 1;
+        c->tri_cap = std::max(n, 1);
+    }
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(c->d_verts, c->verts.data(), (size_t)n * 24 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_mtlids, c->mtlids.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    MptLbvhBuffers b{};
+    b.verts = c->d_verts; b.mtlids = c->d_mtlids; b.n = n;
+    b.cen = c->d_cen; b.bounds = c->d_bounds; b.keys_in = c->d_keys_in; b.keys_out = c->d_keys_out;
+    b.sort_tmp = c->d_sort_tmp; b.sort_tmp_bytes = c->d_sort_bytes;
+    b.child = c->d_child; b.parent = c->d_parent; b.leaf = c->d_leaf; b.mc = c->d_mc;
+    b.bmin = c->d_bmin; b.bmax = c->d_bmax; b.arrive = c->d_arrive; b.depth = c->d_depth;
+    b.snode = c->snode; b.fnode = c->fnode; b.tgeo = c->tgeo; b.tshade = c->tshade;
+    HIP_TRY(mpt_lbvh_build(&b, c->stream));
+    int depth = 0;
+    if (ni > 0) HIP_TRY(hipMemcpyAsync(&depth, c->d_depth, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (depth + 2 > 64) return fail("LBVH depth %d exceeds the 64-entry traversal stack", depth);
+    c->tree_depth = depth;
+    c->fast_depth = depth;
+    c->host_tree_valid = false;
+    if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max) {
+        // SAH re-partition of the leaves for the fast build (host pass over the leaf order)
+        c->h_leaf.resize(n);
+        HIP_TRY(hipMemcpy(c->h_leaf.data(), c->d_leaf, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        SahBuild sb;
+        sb.n = n;
+        sb.lo.resize((size_t)n * 3); sb.hi.resize((size_t)n * 3); sb.ctr.resize((size_t)n * 3);
+        const float *V = c->verts.data();
+        for (int slot = 0; slot < n; slot++) {
+            int f = c->h_leaf[slot];
+            const float *p0 = V + ((size_t)f * 3) * 8, *p1 = p0 + 8, *p2 = p0 + 16;
+            for (int a = 0; a < 3; a++) {
+                float l = fminf(fminf(p0[a], p1[a]), p2[a]), h = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
+                sb.lo[(size_t)slot * 3 + a] = l; sb.hi[(size_t)slot * 3 + a] = h; sb.ctr[(size_t)slot * 3 + a] = 0.5f * (l + h);
+            }
+        }
+        sb.run();
+        if (sb.depth + 2 > 64) return fail("BVH depth %d exceeds the 64-entry traversal stack", sb.depth);
+        std::vector<MptVec4> fnode;
+        pack_fnode(c, n, sb.child, sb.blo, sb.bhi, fnode);
+        HIP_TRY(hipMemcpy(c->fnode, fnode.data(), (size_t)ni * 4 * sizeof(MptVec4), hipMemcpyHostToDevice));
+        c->fast_depth = sb.depth;
+    }
+    c->tree_valid = true;
+    return 0;
+}
+
+extern "C" int mpt_build_tree(mpt_ctx *c) {
+    if (use(c)) return 1;
+    if (mpt_flush(c)) return 1;
+    return c->gpu_build ? build_tree_gpu(c) : build_tree_host(c);
+}
+
+static int download_tree(mpt_ctx *c) {
+    if (c->host_tree_valid) return 0;
+    const int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
+    c->h_child.assign((size_t)std::max(ni, 1) * 2, 0); c->h_leaf.assign(std::max(n, 1), 0); c->h_mc.assign(std::max(n, 1), 0);
+    c->h_bmin.assign((size_t)std::max(ni, 1) * 3, 0.f); c->h_bmax.assign((size_t)std::max(ni, 1) * 3, 0.f);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n > 0) {
+        HIP_TRY(hipMemcpy(c->h_leaf.data(), c->d_leaf, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c->h_mc.data(), c->d_mc, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    if (ni > 0) {
+        HIP_TRY(hipMemcpy(c->h_child.data(), c->d_child, (size_t)ni * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c->h_bmin.data(), c->d_bmin, (size_t)ni * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c->h_bmax.data(), c->d_bmax, (size_t)ni * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    c->host_tree_valid = true;
+    return 0;
+}
+
+extern "C" int mpt_get_tree(mpt_ctx *c, int32_t *child, int32_t *leaf, float *bmin, float *bmax, int32_t *mc,
+                            int32_t *depth) {
+    if (!c) return fail("null context");
+    if (!c->tree_valid) return fail("BVH not built: call build_tree() after load_model()");
+    if (download_tree(c)) return 1;
+    int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
+    if (child) memcpy(child, c->h_child.data(), (size_t)ni * 2 * sizeof(int32_t));
+    if (leaf) memcpy(leaf, c->h_leaf.data(), (size_t)n * sizeof(int32_t));
+    if (bmin) memcpy(bmin, c->h_bmin.data(), (size_t)ni * 3 * sizeof(float));
+    if (bmax) memcpy(bmax, c->h_bmax.data(), (size_t)ni * 3 * sizeof(float));
+    if (mc) memcpy(mc, c->h_mc.data(), (size_t)n * sizeof(int32_t));
+    if (depth) *depth = c->tree_depth;
+    return 0;
+}
