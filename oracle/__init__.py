@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-BUILD = os.path.join(HERE, '_build')
+BUILD = os.environ.get('ORACLE_BUILD_DIR') or os.path.join(HERE, '_build')    # _build_san: sanitizer build
 JOE_KUO = os.path.join(os.path.dirname(HERE), 'ptina_amd', 'data', 'joe_kuo_21201.npz')
 
 LIGHT_TYPES = {'POINT': 1, 'AREA': 2}
