@@ -380,6 +380,39 @@ def test_edge_cases_empty_and_single_triangle(fresh, oracle_mod):
     reset_all()
 
 
+@pytest.mark.parametrize('k', [0.002, 50.0])
+def test_scene_scale_dependence_is_the_references(fresh, oracle_mod, k):
+    '''eps = 1e-6 and inf = 1e6 are absolute (common.py:32-33) and Face.intersect tests |n.d| against eps
+    with the UNNORMALISED normal (geometries.py:123-129): the same scene scaled by k is not
+    the same image.  Both builds must follow the oracle at either end; a degenerate (zero-area) and a
+    needle triangle ride along.'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
+    from ptina_amd.tools.matrix import translate, scale
+    v, m, mats, _ = scenes.scene_s34()
+    extra = np.zeros((6, 8), np.float32)
+    extra[0:3, :3] = [[0.5, 1.0, 0.5], [0.5, 1.0, 0.5], [0.9, 1.4, 0.5]]            # two coincident vertices
+    extra[3:6, :3] = [[-1.5, 0.5, 1.0], [-1.5, 3.5, 1.0], [-1.5 + 1e-4, 2.0, 1.0]]   # needle
+    extra[:, 3:6] = [0, 0, 1]
+    v = np.concatenate([v, extra]).astype(np.float32)
+    m = np.concatenate([m, [1, 2]]).astype(np.int32)
+    v[:, :3] *= k
+    cam = scenes.BENCH_CAMERA @ scale(1.0 / k)
+    lights = [(translate([1.0 * k, 2.0 * k, 3.0 * k]), np.array([32.0, 32.0, 32.0]), 0.5 * k, 'POINT')]
+    scene = (v, m, mats, [])
+    ref = setup_oracle(oracle_mod, scene, 64, 64, camera=cam, lights=lights)
+    ref.render(8)
+    want = ref.get_image()
+    assert np.isfinite(want).all() and want[..., :3].mean() > 0.1
+    for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
+        reset_all()
+        eng = _engine(None, scene, 64, 64, mode=mode, camera=cam, lights=lights)
+        eng.render(8)
+        assert_parity(FilmTable().get_image(), want, tol, 0.02, 2e-2, what=f'scale {k} {mode}')
+    reset_all()
+
+
 def test_worker_facade_through_the_thread_proxy(fresh):
     '''the Blender add-on's view of the engine: every function of worker.py:11-87 called through
     tools.mtworker's daemon thread (blender.py:565-580), against the same scene driven directly'''
