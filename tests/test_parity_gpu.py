@@ -208,6 +208,30 @@ def test_stripes_reassemble_bit_identically(fresh):
     reset_all()
 
 
+def test_lds_and_gather_kernels_agree_bit_for_bit(fresh):
+    '''the LDS-resident kernel and the gather kernel run the same state machine on the same tree: one
+    film, whichever serves the scene; so do the SAH and the plain-LBVH tree up to equal-depth ties'''
+    from helpers import assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    films = {}
+    for lds, tree in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        reset_all()
+        eng = _engine(None, scenes.scene_s978(), 96, 80, mode='fast')
+        c = ctx()
+        c.set_option('lds', lds)
+        c.set_option('tree', tree)
+        from ptina_amd.things import BVHTree
+        BVHTree().build()
+        eng.render(6)
+        films[(lds, tree)] = (FilmTable().get_raw().copy(), FilmTable().get_image().copy(), c.get_option('last_kernel'))
+    reset_all()
+    assert films[(1, 1)][2] == 1 and films[(0, 1)][2] == 0
+    assert np.array_equal(films[(1, 1)][0], films[(0, 1)][0])
+    assert np.array_equal(films[(1, 0)][0], films[(0, 0)][0])
+    assert_parity(films[(1, 1)][1], films[(1, 0)][1], 1e-3, 0.01, 1e-2, what='SAH tree vs LBVH')
+
+
 def test_launch_pipelining_does_not_change_the_film(fresh):
     '''G launches on 1/G of the CUs each, D batches in flight: same film bit for bit, any G and D,
     including batches of different sizes back to back (the ring of slots is resized in between)'''
