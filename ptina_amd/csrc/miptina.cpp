@@ -639,6 +639,12 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     c->last_kernel = lds_kernel ? 1 : 0;
     HIP_TRY(hipEventRecord(e1, rs));
     c->events.push_back({ e0, e1 });
+    if (c->events.size() > 4096) {
+        // nobody has asked for kernel times for a long while (an interactive session renders frame after
+        // frame): keep the newest half.  The dropped pairs were recorded at least 2048 launches ago.
+        for (size_t q = 0; q < 2048; q++) { c->event_pool.push_back(c->events[q].first); c->event_pool.push_back(c->events[q].second); }
+        c->events.erase(c->events.begin(), c->events.begin() + 2048);
+    }
     if (fast) {
         // everything later on the main stream (combine, gather, resolve, read-backs, scene changes) is
         // ordered after this render; the next batch, on the other stream, is not
