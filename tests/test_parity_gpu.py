@@ -208,6 +208,29 @@ def test_stripes_reassemble_bit_identically(fresh):
     reset_all()
 
 
+def test_long_interactive_session(fresh):
+    '''a viewport-style session: thousands of one-frame launches with a read-back now and then (the
+    launch-timing bookkeeping must stay bounded); the film ends up with every frame, bit-identical to
+    the same frames rendered in batches'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    nx, ny, frames = 24, 16, 4500
+    eng = _engine(None, scenes.scene_s34(), nx, ny, mode='fast')
+    ctx().set_option('batch', 1)
+    for f in range(frames):
+        eng.render()
+        if f % 1000 == 999:
+            assert np.all(FilmTable().get_raw()[:, 3] == f + 1)
+    one = FilmTable().get_raw().copy()
+    ms, launches = ctx().kernel_time()
+    assert 0 < launches <= 4096 and ms > 0
+    reset_all()
+    eng = _engine(None, scenes.scene_s34(), nx, ny, mode='fast')
+    eng.render(frames)
+    assert np.array_equal(FilmTable().get_raw(), one)
+    reset_all()
+
+
 def test_lds_and_gather_kernels_agree_bit_for_bit(fresh):
     '''the LDS-resident kernel and the gather kernel run the same state machine on the same tree: one
     film, whichever serves the scene; so do the SAH and the plain-LBVH tree up to equal-depth ties'''
