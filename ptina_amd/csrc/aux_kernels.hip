@@ -95,14 +95,14 @@ __global__ __launch_bounds__(256) void export_kernel(const MptVec4 *__restrict__
     out[o * 3 + 0] = v.x; out[o * 3 + 1] = v.y; out[o * 3 + 2] = v.z;
 }
 
-extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0,
+MPT_KERNEL_API hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0,
                                               int count, int keep, hipStream_t stream) {
     int grid = (dim + 255) / 256;
     hipLaunchKernelGGL(sobol_update_kernel, dim3(grid), dim3(256), 0, stream, X, V, P, dim, rows, time0, count, keep);
     return hipGetLastError();
 }
 
-extern "C" hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
+MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
                                          int stripe_w, int stripe_pitch, int nchunks, hipStream_t stream) {
     size_t n = (size_t)(x1 - x0) * ny;
     if (n == 0) return hipSuccess;
@@ -111,14 +111,14 @@ extern "C" hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, 
     return hipGetLastError();
 }
 
-extern "C" hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t stream) {
+MPT_KERNEL_API hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t stream) {
     if (npix == 0) return hipSuccess;
     int grid = (int)((npix + 255) / 256);
     hipLaunchKernelGGL(resolve_kernel, dim3(grid), dim3(256), 0, stream, film, out, npix);
     return hipGetLastError();
 }
 
-extern "C" hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t stream) {
+MPT_KERNEL_API hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t stream) {
     size_t n = (size_t)nx * ny;
     if (n == 0) return hipSuccess;
     int grid = (int)((n + 255) / 256);

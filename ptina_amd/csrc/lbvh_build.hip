@@ -275,12 +275,12 @@ struct MptLbvhBuffers {
     MptVec4 *snode, *fnode, *tgeo, *tshade;
 };
 
-extern "C" hipError_t mpt_lbvh_sort_bytes(int n, size_t *bytes) {
+MPT_KERNEL_API hipError_t mpt_lbvh_sort_bytes(int n, size_t *bytes) {
     unsigned long long *p = nullptr;
     return rocprim::radix_sort_keys(nullptr, *bytes, p, p, (size_t)n, 0, 62, (hipStream_t)0);
 }
 
-extern "C" hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t stream) {
+MPT_KERNEL_API hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t stream) {
     const int n = b->n;
     if (n <= 0) return hipSuccess;
     const int gl = (n + LB_BLOCK - 1) / LB_BLOCK;

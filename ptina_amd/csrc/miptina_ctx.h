@@ -16,18 +16,18 @@
 #include <vector>
 
 // kernel launchers (render_kernel.hip x2, aux_kernels.hip)
-extern "C" hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
-extern "C" hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
-extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
-extern "C" hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
-extern "C" hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
-extern "C" hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
+MPT_KERNEL_API hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
                                               int keep, hipStream_t);
-extern "C" hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
+MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
                                          int stripe_w, int stripe_pitch,
                                          int nchunks, hipStream_t);
-extern "C" hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
-extern "C" hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
 
 // on-GPU LBVH build (lbvh_build.hip)
 struct MptLbvhBuffers {
@@ -41,8 +41,8 @@ struct MptLbvhBuffers {
     int *depth;
     MptVec4 *snode, *fnode, *tgeo, *tshade;
 };
-extern "C" hipError_t mpt_lbvh_sort_bytes(int n, size_t *bytes);
-extern "C" hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t stream);
+MPT_KERNEL_API hipError_t mpt_lbvh_sort_bytes(int n, size_t *bytes);
+MPT_KERNEL_API hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t stream);
 
 // ------------------------------------------------------------------ errors (miptina.cpp)
 #define MPT_INTERNAL __attribute__((visibility("hidden")))   // shared between the .cpp files, not exported

@@ -26,6 +26,9 @@
 
 struct MptVec4 { float x, y, z, w; };
 
+// kernel launchers: C linkage between the objects of libmiptina.so, not part of its ABI
+#define MPT_KERNEL_API extern "C" __attribute__((visibility("hidden")))
+
 struct MptMaterial {
     float p[16];               // [0..2] basecolor, [3] metallic, [4] roughness, [5] specular, [6] specularTint,
                                // [7] subsurface, [8] sheen, [9] sheenTint, [10] clearcoat, [11] clearcoatGloss,

@@ -618,7 +618,7 @@ static int blocks_per_cu(K kernel) {
 
 // strict build: grid = number of 16x16 tiles.  fast build: persistent workgroups, `grid` = number of CUs
 // (scaled here by the blocks each CU can hold); the work items come from p->work_counter.
-extern "C" hipError_t MPT_SUFFIX(mpt_launch_render)(const MptRenderParams *p, int grid, int stack, int count,
+MPT_KERNEL_API hipError_t MPT_SUFFIX(mpt_launch_render)(const MptRenderParams *p, int grid, int stack, int count,
                                                      hipStream_t stream) {
 #if !MPT_STRICT
     static int occ[4] = { 0, 0, 0, 0 };
@@ -657,13 +657,13 @@ static hipError_t launch_lds(const MptRenderParams *p, int grid, int block, size
 }
 
 // lds_bytes = scene records + 2 KiB per stack level; grid = one persistent workgroup per CU
-extern "C" hipError_t mpt_launch_render_lds(const MptRenderParams *p, int grid, int block, size_t lds_bytes, int count,
+MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *p, int grid, int block, size_t lds_bytes, int count,
                                             hipStream_t stream) {
     return count ? launch_lds<true>(p, grid, block, lds_bytes, stream) : launch_lds<false>(p, grid, block, lds_bytes, stream);
 }
 #endif
 
-extern "C" hipError_t MPT_SUFFIX(mpt_launch_preview)(const MptRenderParams *p, int grid, int stack,
+MPT_KERNEL_API hipError_t MPT_SUFFIX(mpt_launch_preview)(const MptRenderParams *p, int grid, int stack,
                                                       hipStream_t stream) {
     if (stack <= 32) hipLaunchKernelGGL((MPT_SUFFIX(preview_kernel)<32>), dim3(grid), dim3(MPT_BLOCK), 0, stream, *p);
     else hipLaunchKernelGGL((MPT_SUFFIX(preview_kernel)<64>), dim3(grid), dim3(MPT_BLOCK), 0, stream, *p);
