@@ -30,6 +30,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.mpt_version() >= 100
 
 
+def test_library_exports_nothing_else_under_its_prefix():
+    '''the ABI is the header: kernel launchers and helpers shared between the objects stay internal'''
+    import shutil
+    import subprocess
+    from ptina_amd import _lib
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    if not os.path.exists(nm):
+        pytest.skip('no nm')
+    out = subprocess.run([nm, '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith('mpt_'))
+    assert exported == header_symbols()
+
+
 def test_no_cpu_fallback():
     from ptina_amd import _lib
     lib = _lib.load_library()
