@@ -590,9 +590,11 @@ def test_config3_film_size_and_a_stripe_share(fresh, oracle_mod):
     reset_all()
 
 
-def test_full_size_properties_and_window_parity(fresh, oracle_mod):
+def test_full_size_properties_and_oracle_parity(fresh, oracle_mod):
     '''BASELINE configs[1] at full size (512x512x32, S978): size-independent properties, run-to-run
-    bit reproducibility, fast-vs-strict agreement, and oracle parity on a window of columns'''
+    bit reproducibility, fast-vs-strict agreement, and oracle parity on the WHOLE film (the oracle does
+    the 8.4 M samples in a few seconds on the GPU box's host cores; on fewer than 8 cores it falls back
+    to a window of columns)'''
     from helpers import setup_oracle, assert_parity
     from ptina_amd.things import FilmTable
     from ptina_amd.common import reset_all
@@ -610,15 +612,19 @@ def test_full_size_properties_and_window_parity(fresh, oracle_mod):
     reset_all()
     assert np.array_equal(imgs['fast'], imgs['fast2']), 'render is not run-to-run deterministic'
     assert_parity(imgs['fast'], imgs['strict'], 1e-3, 0.01, 5e-3, what='full-size fast vs strict')
-    x0, x1 = 250, 258
-    ref = setup_oracle(oracle_mod, scene, nx, ny)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    x0, x1 = (0, nx) if cores >= 8 else (250, 258)
+    ref = setup_oracle(oracle_mod, scene, nx, ny, threads=min(cores, 16))
     ref.set_window(x0, x1)
     ref.render(1)
     ref.clear()
     ref.render(spp)
     want = ref.get_image()[x0:x1]
-    assert_parity(imgs['strict'][x0:x1], want, 1e-4, 0.01, 1e-2, what='full-size strict window')
-    assert_parity(imgs['fast'][x0:x1], want, 1e-3, 0.02, 1e-2, what='full-size fast window')
+    assert_parity(imgs['strict'][x0:x1], want, 1e-4, 0.01, 1e-2, what=f'full-size strict, columns [{x0},{x1})')
+    assert_parity(imgs['fast'][x0:x1], want, 1e-3, 0.02, 1e-2, what=f'full-size fast, columns [{x0},{x1})')
 
 
 def test_rccl_film_gather_single_rank(fresh):
