@@ -590,15 +590,16 @@ def test_config3_film_size_and_a_stripe_share(fresh, oracle_mod):
     reset_all()
 
 
-def test_full_size_properties_and_oracle_parity(fresh, oracle_mod):
-    '''BASELINE configs[1] at full size (512x512x32, S978): size-independent properties, run-to-run
+@pytest.mark.parametrize('name', ['s978', 's34'])
+def test_full_size_properties_and_oracle_parity(fresh, oracle_mod, name):
+    '''BASELINE configs[1] and configs[0] at full size (512x512x32, S978 / S34): size-independent properties, run-to-run
     bit reproducibility, fast-vs-strict agreement, and oracle parity on the WHOLE film (the oracle does
     the 8.4 M samples in a few seconds on the GPU box's host cores; on fewer than 8 cores it falls back
     to a window of columns)'''
     from helpers import setup_oracle, assert_parity
     from ptina_amd.things import FilmTable
     from ptina_amd.common import reset_all
-    scene = scenes.scene_s978()
+    scene = scenes.get_scene(name)
     nx = ny = 512
     spp = 32
     imgs = {}
