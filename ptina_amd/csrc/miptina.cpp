@@ -95,7 +95,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (dev_alloc(&c->lights, MPT_MAX_LIGHTS)) return bail("lights");
     if (dev_alloc(&c->d_counters, 12)) return bail("counters");
     if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
-    if (dev_alloc(&c->d_work, 16)) return bail("work counters");   // 8 queue heads + [8] watchdog flag
+    if (dev_alloc(&c->d_work, 16)) return bail("work counters");   // 8 queue heads
     for (int k = 0; k < MPT_MAX_PIPE; k++) {
         if (hipEventCreateWithFlags(&c->ev_sobol2[k], hipEventDisableTiming) != hipSuccess) return bail("event");
         if (hipEventCreateWithFlags(&c->ev_render[k], hipEventDisableTiming) != hipSuccess) return bail("event");
@@ -111,6 +111,13 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
             c->num_cus = prop.multiProcessorCount;
     }
     if (make_render_streams(c)) return bail("render streams");
+    {
+        void *dp = nullptr;
+        if (hipHostMalloc((void **)&c->h_watchdog, sizeof(unsigned int), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&dp, c->h_watchdog, 0) != hipSuccess) return bail("pinned watchdog flag");
+        *c->h_watchdog = 0;
+        c->d_watchdog = (unsigned int *)dp;
+    }
     hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), c->stream);
     hipMemsetAsync(c->d_work, 0, 16 * sizeof(unsigned int), c->stream);
     {   // unset materials: factor 0 (field-zero, mtllib.py:12-13), texture -1 (deviation Q6)
@@ -149,6 +156,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
+    if (c->h_watchdog) hipHostFree(c->h_watchdog);
     hipFree(c->d_verts); hipFree(c->d_mtlids); hipFree(c->d_cen); hipFree(c->d_bounds); hipFree(c->d_depth);
     hipFree(c->d_keys_in); hipFree(c->d_keys_out); hipFree(c->d_sort_tmp);
     hipFree(c->d_child); hipFree(c->d_parent); hipFree(c->d_leaf); hipFree(c->d_mc);
@@ -505,6 +513,7 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     p.P = c->sP;
     p.film0 = c->film[0]; p.film1 = c->film[1]; p.film2 = c->film[2];
     p.counters = c->d_counters;
+    p.watchdog = c->d_watchdog;
     if (p.world_tex != -1 && (p.world_tex < 0 || p.world_tex >= (int)c->h_images.size()))
         return fail("world light texture %d is not a loaded image", p.world_tex);
     return 0;
@@ -614,7 +623,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
             }
         p.partial = c->partial2[k];
         p.work_counter = c->d_work2[k];
-        HIP_TRY(hipMemsetAsync(c->d_work2[k], 0, 8 * sizeof(unsigned int), ss));   // [8] (watchdog flag) is sticky
+        HIP_TRY(hipMemsetAsync(c->d_work2[k], 0, 8 * sizeof(unsigned int), ss));
         HIP_TRY(hipEventRecord(c->ev_sobol2[k], ss));
         HIP_TRY(hipStreamWaitEvent(rs, c->ev_sobol2[k], 0));
         HIP_TRY(hipStreamWaitEvent(rs, c->ev_free[k], 0));   // combine of the batch that last used partial[k]
@@ -692,15 +701,11 @@ extern "C" int mpt_render_preview(mpt_ctx *c, int nframes) {                   /
     return 0;
 }
 
-// a persistent render kernel that had to be stopped by its watchdog leaves a flag behind
+// a persistent render kernel that had to be stopped by its watchdog leaves a flag behind (in host-pinned
+// memory: no copy to read it); call after the streams have been synchronised
 static int check_watchdog(mpt_ctx *c) {
-    unsigned int flag = 0, f2[MPT_MAX_PIPE] = {};
-    HIP_TRY(hipMemcpyAsync(&flag, c->d_work + 8, sizeof flag, hipMemcpyDeviceToHost, c->stream));
-    for (int k = 0; k < MPT_MAX_PIPE; k++)
-        HIP_TRY(hipMemcpyAsync(&f2[k], c->d_work2[k] + 8, sizeof flag, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < MPT_MAX_PIPE; k++) flag |= f2[k];
-    if (flag) return fail("render kernel stopped by its watchdog (scheduler made no progress): film is incomplete");
+    if (__atomic_load_n(c->h_watchdog, __ATOMIC_ACQUIRE))
+        return fail("render kernel stopped by its watchdog (scheduler made no progress): film is incomplete");
     return 0;
 }
 

@@ -147,6 +147,7 @@ struct mpt_ctx {
     int timeline_waves = 0;
     unsigned long long *d_counters = nullptr;
     unsigned int *d_work = nullptr;
+    unsigned int *h_watchdog = nullptr, *d_watchdog = nullptr;   // host-pinned, device-mapped: raised by a render kernel's watchdog
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
 

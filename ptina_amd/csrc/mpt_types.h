@@ -70,7 +70,8 @@ struct MptRenderParams {
     MptVec4 *film2;                          // pass 2 (normal)
     MptVec4 *partial;                        // fast build: per-sample radiance [nframes][nx*ny]
     unsigned long long *counters;            // mpt_counters when counting, else unused
-    unsigned int *work_counter;              // persistent kernels: 8 per-range item counters, [8] watchdog flag
+    unsigned int *work_counter;              // persistent kernels: 8 per-range item counters
+    unsigned int *watchdog;                  // host-pinned flag a persistent wave raises when it gives up
     unsigned long long *timeline;            // diagnostics: per wave {start, scene ready, queue empty, exit} in
                                              // 100 MHz ticks, or null
 };

@@ -442,7 +442,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     // a persistent wave (and with it the GPU) spinning -- the host turns the flag into an error.
     for (unsigned guard = 0;; guard++) {
         if (guard > (1u << 26)) {
-            if ((threadIdx.x & 63) == 0) atomicExch(p.work_counter + 8, 1u);
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(p.watchdog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
         // ---- traversal mode: tight loop while the lanes that are traversing outnumber the waiting ones
