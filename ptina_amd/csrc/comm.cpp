@@ -49,12 +49,6 @@ static int rccl_load() {
         if (r_ != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(r_));  \
     } while (0)
 
-// Up to MPT_MAX_PIPE render streams, the main stream and the aux stream carry work at the same time.
-// The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told
-// otherwise) and streams that share one are serialised, so ask for more before the runtime starts --
-// unless the user has chosen a value.
-__attribute__((constructor)) static void mpt_want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-
 // ------------------------------------------------------------------ multi-GPU film gather (RCCL over xGMI)
 // One process per GPU; each renders the slab [x0,x1) of a replicated scene.  Film index is
 // x*ny + y (filmtable.py:38), so a slab is ONE contiguous float4 range: every rank sends its

@@ -7,6 +7,12 @@
 
 #include "miptina_ctx.h"
 
+// Up to MPT_MAX_PIPE render streams, the main stream and the aux stream carry work at the same time.
+// The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told
+// otherwise) and streams that share one are serialised, so ask for more before the runtime starts --
+// eight of our own plus room for what RCCL creates -- unless the user has chosen a value.
+__attribute__((constructor)) static void mpt_want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 
