@@ -38,7 +38,7 @@ for step in "$@"; do
                   cd $GRAFT_REPO_ROOT;
                   run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline) ;;
     slabtrace)   (run_dir=$GRAFT_REPO_ROOT/gpurun_out/slabtrace; rm -rf $run_dir; mkdir -p $run_dir;
-                  run slabtrace 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/slabtrace -- python3 tools/slab_trace.py 8 4 20) ;;
+                  STRIPE=16 run slabtrace 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/slabtrace -- python3 tools/slab_trace.py 8 3 40) ;;
     counters)    rocprofv3 -L > gpurun_out/counters_list.txt 2>&1; echo "counters listed" ;;
     pmc1)        run pmc1 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     pmc2)        run pmc2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
