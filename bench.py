@@ -3,33 +3,176 @@
 bench.py -- Msamples/s of the path-trace hot path on the 978-triangle cornell scene,
 512x512, 32 spp (BASELINE.json configs[1]), on N MI355X of one node.
 
-One "step" = the timed region of the reference's exams/benchmark.py:29-35: 32 x PathEngine.render()
-(each = Sobol update + one sample per pixel) followed by the film resolve of get_image().  The
-scene, BVH, Sobol tables and film are resident in HBM before the timed region starts; `value`
-stops at the resolved image in HBM, the D2H-inclusive rate is reported beside it.
+One "step" = the timed region of the reference's exams/benchmark.py:29-36: 32 x PathEngine.render()
+(each = Sobol update + one sample per pixel) followed by FilmTable.get_image() -- the resolve AND
+the read-back of the 4 MiB image into a host array.  The scene, BVH, Sobol tables and film are
+resident in HBM before the timed region starts.  `value` is that D2H-inclusive rate (the metric
+SURVEY.md 8d defines); `value_resolve_only` (stops at the resolved image in HBM, consecutive steps
+overlapped) is reported beside it.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the film columns are dealt out in
-stripes of 16, rank r renders stripes r, r+N, ... of the replicated scene and the stripes are
-gathered to rank 0 with grouped ncclSend/ncclRecv (RCCL over xGMI) before the resolve -- strong
-scaling of the same 512x512x32 job.  No PyTorch anywhere in the process: rendezvous of the RCCL unique id is a file,
-barriers and the max-over-ranks are RCCL all-reduces.
+N > 1, one rank per GPU: launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or -- when WORLD_SIZE is not set -- by this script itself, which then only spawns N
+fresh copies of itself (ptina_amd.dist.launch_ranks) before anything has touched the GPU and relays
+rank 0's line.  The film columns are dealt out in stripes of 16, rank r renders stripes r, r+N, ...
+of the replicated scene and the stripes are gathered to rank 0 with grouped ncclSend/ncclRecv (RCCL
+over xGMI) before the resolve: strong scaling of the same 512x512x32 job.  No PyTorch in the
+process; the RCCL unique id travels through a file, barriers and the max-over-ranks are RCCL
+all-reduces.
+
+Roofline (N = 1): the dominant kernel is bound by VALU issue at partial lane occupancy, not by HBM
+and not by MFMA -- its scene lives in LDS.  The `roofline` object therefore prices VALU lane-operations
+per second against the chip's f32 vector lane rate (256 CUs x 4 SIMD-32 x clock), with the counters
+collected IN THIS RUN: before the parent touches the GPU it runs itself twice under `rocprofv3 --pmc`
+(separate passes, a few seconds each) and reads SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU /
+SQ_THREAD_CYCLES_VALU and FETCH_SIZE / WRITE_SIZE of the render kernel from the CSVs.  `hbm` holds the
+measured HBM traffic and its GB/s.  Without rocprofv3 the committed summary of the same command
+(profiles/) is used and `counters_from` says so.
 '''
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-import numpy as np  # noqa: E402
-
 NX = NY = 512
 SPP = 32
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_SIMD = 256 * 4             # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
+SIMD_LANES = 32              # a wave64 VALU instruction issues over 2 cycles on a SIMD-32
+PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')
+
+PMC_PASSES = [
+    ['SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES',
+     'SQ_BUSY_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY'],
+    ['FETCH_SIZE', 'GRBM_GUI_ACTIVE'],
+    ['WRITE_SIZE', 'TCC_HIT_sum', 'TCC_MISS_sum'],
+]
+
+
+def render_kernel_name(mode, last_kernel):
+    if mode != 'fast':
+        return 'render_kernel_strict'
+    return 'render_kernel_lds' if last_kernel else 'render_kernel_fast'
+
+
+def collect_pmc(argv_tail, budget_s=150):
+    '''run this script (role pmc-child: the same steps, nothing printed) under `rocprofv3 --pmc`, one
+    pass per counter group, and return {counter: median per 32-spp render launch}.  Called BEFORE the
+    parent has made any HIP call; rocprofv3 gets the interpreter itself after `--`.'''
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    out = {}
+    work = tempfile.mkdtemp(prefix='miptina_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            d = os.path.join(work, f'pass{i}')
+            cmd = [exe, '--pmc', *counters, '--output-format', 'csv', '-d', d, '--',
+                   sys.executable, os.path.abspath(__file__), '--role', 'pmc-child', *argv_tail]
+            try:
+                p = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                     start_new_session=True)
+                try:
+                    _, err = p.communicate(timeout=budget_s)
+                except subprocess.TimeoutExpired:
+                    os.killpg(p.pid, 15)
+                    try:
+                        p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        os.killpg(p.pid, 9)
+                    return None, f'rocprofv3 pass {i} exceeded {budget_s}s'
+                if p.returncode != 0:
+                    return None, f'rocprofv3 pass {i} exited {p.returncode}: {err.decode("utf-8", "replace")[-300:]}'
+            except OSError as e:
+                return None, f'rocprofv3 could not start: {e}'
+            rows = []
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                rows += list(csv.DictReader(open(f)))
+            per = {}
+            for r in rows:
+                k = r['Kernel_Name']
+                if 'render_kernel' not in k or '<true>' in k or ', true>' in k:   # not the counting build
+                    continue
+                per.setdefault((k, r['Counter_Name']), {}).setdefault(r['Dispatch_Id'], 0.0)
+                per[(k, r['Counter_Name'])][r['Dispatch_Id']] += float(r['Counter_Value'])
+            for (k, cn), by_dispatch in per.items():
+                vals = sorted(by_dispatch.values())
+                # the 1-spp warm-up frame of the benchmark sequence is a render launch too: keep the big ones
+                big = [v for v in vals if v >= 0.5 * vals[-1]] if vals[-1] > 0 else vals
+                out[cn] = {'median': big[len(big) // 2], 'n': len(big), 'kernel': k}
+        return out, 'rocprofv3 --pmc in this run (%d passes, %s)' % (len(PMC_PASSES), os.path.basename(exe))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def committed_pmc(kernel):
+    try:
+        d = json.load(open(PROFILE_FALLBACK))
+        for k, v in d.items():
+            if kernel in k and '<true>' not in k and ', true>' not in k:
+                return {cn: dict(x, kernel=k) for cn, x in v.items()}, 'profiles/' + os.path.basename(PROFILE_FALLBACK)
+    except Exception:
+        pass
+    return None, 'no counters available'
+
+
+def roofline_blocks(pmc, source, kernel, avg_kernel_s, clock_hz, concurrent):
+    '''VALU roofline + HBM traffic of the dominant kernel from its PMC counters (per launch) and its
+    average launch duration measured with HIP events in this run.
+
+      wave-instructions      = SQ_INSTS_VALU
+      lane occupancy         = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
+      achieved lane-ops/s    = SQ_INSTS_VALU * 64 * lane occupancy / kernel time
+      peak lane-ops/s        = 1024 SIMD-32 x 32 lanes x clock (= 157.3 TFLOP/s / 2 at 2.4 GHz)
+      issue fraction         = SQ_INSTS_VALU * 2 cycles / (1024 SIMDs * clock * kernel time)
+    (2 cycles per wave64 VALU instruction on a SIMD-32: tools/valu_microbench.hip, profiles/)'''
+    peak = N_SIMD * SIMD_LANES * clock_hz
+    if not pmc or 'SQ_INSTS_VALU' not in pmc:
+        return ({'bound': 'valu', 'achieved': None, 'peak': round(peak / 1e12, 3), 'unit': 'Tlane-op/s', 'frac': None,
+                 'traffic': None, 'kernel': kernel, 'avg_kernel_ms': round(avg_kernel_s * 1e3, 4),
+                 'counters_from': source}, None)
+    g = lambda c: pmc[c]['median'] if c in pmc else None
+    insts = g('SQ_INSTS_VALU')
+    occ = g('SQ_THREAD_CYCLES_VALU') / (64.0 * g('SQ_ACTIVE_INST_VALU'))
+    lane_ops = insts * 64.0 * occ
+    achieved = lane_ops * concurrent / avg_kernel_s
+    fetch, write = g('FETCH_SIZE'), g('WRITE_SIZE')
+    traffic = int((fetch + write) * 1024) if fetch is not None and write is not None else None
+    roof = {
+        'bound': 'valu', 'achieved': round(achieved / 1e12, 4), 'peak': round(peak / 1e12, 3), 'unit': 'Tlane-op/s',
+        'frac': round(achieved / peak, 4), 'traffic': traffic,
+        'kernel': kernel, 'avg_kernel_ms': round(avg_kernel_s * 1e3, 4), 'concurrent_launches': concurrent,
+        'clock_ghz': round(clock_hz / 1e9, 3),
+        'valu_insts_per_launch': int(insts), 'lane_occupancy': round(occ, 4),
+        'valu_issue_frac': round(insts * 2.0 * concurrent / (N_SIMD * clock_hz * avg_kernel_s), 4),
+        'salu_per_valu': round(g('SQ_INSTS_SALU') / insts, 3) if g('SQ_INSTS_SALU') else None,
+        'wave_cycles_valu_frac': round(g('SQ_ACTIVE_INST_VALU') / g('SQ_WAVE_CYCLES'), 3) if g('SQ_WAVE_CYCLES') else None,
+        'wave_cycles_wait_inst_frac': round(g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'), 3) if g('SQ_WAVE_CYCLES') and g('SQ_WAIT_INST_ANY') else None,
+        'counters_from': source,
+        'note': 'f32 vector lane-operations per second against 256 CU x 4 SIMD-32 x clock; the 125 KB of nodes + '
+                'triangles are LDS-resident, so HBM is not the binding limit (see "hbm") and there is no contraction '
+                'for MFMA',
+    }
+    hbm = None
+    if traffic is not None:
+        gbs = traffic * concurrent / avg_kernel_s / 1e9
+        hbm = {'traffic_bytes': traffic, 'fetch_bytes': int(fetch * 1024), 'write_bytes': int(write * 1024),
+               'GB/s': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'frac': round(gbs / HBM_PEAK_GBS, 5),
+               'l2_hit_rate': round(g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')), 4) if g('TCC_HIT_sum') else None,
+               'note': 'FETCH_SIZE + WRITE_SIZE (KiB) per render launch; scattered 16-B accesses, so the guide\'s x2 '
+                       'correction for wide coalesced reads does not apply'}
+    return roof, hbm
 
 
 def algorithmic_bytes(c):
@@ -38,37 +181,6 @@ def algorithmic_bytes(c):
     of normals/uvs/mtlid + the 64-B packed material record'''
     return (32 * c['samples'] + 4 * c['n_draws'] + 32 * c['n_box'] + 40 * c['n_tri']
             + 128 * c['n_shade'])
-
-
-def measured_traffic():
-    '''HBM bytes per render launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/: FETCH_SIZE and WRITE_SIZE are in KiB; scattered 16-B accesses, so the guide's x2
-    read correction for wide coalesced streams is not applied), or None'''
-    try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
-        for k, v in d.items():
-            if 'render_kernel_lds<false' in k:
-                return int((v['FETCH_SIZE']['median'] + v['WRITE_SIZE']['median']) * 1024)
-    except Exception:
-        pass
-    return None
-
-
-def measured_valu(avg_kernel_s, n_simd=1024, clock_hz=2.4e9):
-    '''what actually bounds the LDS kernel, from the same committed PMC passes: the fraction of SIMD
-    cycles with a VALU instruction in flight (SQ_ACTIVE_INST_VALU counts 4-cycle issue slots) and the
-    fraction of lanes those instructions had switched on'''
-    try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
-        for k, v in d.items():
-            if 'render_kernel_lds<false' in k:
-                active = v['SQ_ACTIVE_INST_VALU']['median']
-                return {'valu_busy_frac': round(active * 4.0 / (n_simd * clock_hz * avg_kernel_s), 3),
-                        'lane_utilisation': round(v['SQ_THREAD_CYCLES_VALU']['median'] / (64.0 * active), 3),
-                        'valu_insts_per_launch': int(v['SQ_INSTS_VALU']['median'])}
-    except Exception:
-        pass
-    return None
 
 
 def host_threads():
@@ -123,7 +235,7 @@ def cpu_baseline(scene, camera, budget_s=15.0):
                       f'in {dt:.1f} s (C restatement of PTina\'s algorithm, OpenMP, {threads} threads)'}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -132,15 +244,16 @@ def main():
     ap.add_argument('--mode', default='fast')
     ap.add_argument('--chunk', type=int, default=-1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='do not run the rocprofv3 --pmc passes (counters from profiles/)')
     ap.add_argument('--force-comm', action='store_true', help='create the RCCL communicator even for one rank')
-    args = ap.parse_args()
+    ap.add_argument('--role', default='main', choices=['main', 'pmc-child'],
+                    help='pmc-child: the same render steps with nothing else around them (run under rocprofv3)')
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
-    from ptina_amd import scenes, _lib
+def run_rank(args, rank, world, pmc, pmc_source):
+    import numpy as np  # noqa: F401
+    from ptina_amd import scenes
     from ptina_amd.common import ctx
     from ptina_amd.things import FilmTable
     from ptina_amd.dist import RcclFilm
@@ -149,20 +262,32 @@ def main():
     scene = scenes.get_scene(args.scene)
     eng = setup_engine(scene, NX, NY, mode=args.mode)
     c = ctx()
+    if c.lib.mpt_device_count() < world:
+        raise SystemExit(f'--gpus {world} but only {c.lib.mpt_device_count()} GPU(s) visible')
     if args.chunk >= 0:
         c.set_option('chunk', args.chunk)
     c.set_option('batch', SPP)
     comm = RcclFilm(rank, world) if (world > 1 or args.force_comm) else None
     if comm:
         comm.set_stripes(NX)                  # every world-th stripe of 16 columns: even load
+    n_gpus = c.get_option('nranks') if comm else 1
+    if n_gpus != world:
+        raise SystemExit(f'communicator has {n_gpus} ranks, expected {world}')
+    film = FilmTable()
 
-    def step():
+    def step(d2h):
+        '''exams/benchmark.py:29-36: 32 x render() then get_image()'''
         eng.render(SPP)                       # 32 x (Sobol update + 1 spp), one fused launch
-        c.call('mpt_flush')
         if comm:
+            c.call('mpt_flush')
             comm.gather(0, 0)
         if rank == 0:
+            if d2h:
+                return film.get_image()       # resolve + D2H into a host array, blocking
             c.call('mpt_resolve', 0)
+        elif d2h:
+            c.call('mpt_synchronize')
+        return None
 
     def barrier():
         c.call('mpt_synchronize')
@@ -171,83 +296,125 @@ def main():
 
     # exams/benchmark.py:25-27: warm-up frame, read back, clear
     eng.render()
-    FilmTable().get_image()
-    FilmTable().clear()
+    film.get_image()
+    film.clear()
 
-    # warm-up steps double as the counting pass for the roofline's algorithmic bytes
+    if args.role == 'pmc-child':
+        for _ in range(max(args.steps, 1)):
+            step(True)
+        barrier()
+        return
+
+    # warm-up steps double as the counting pass (algorithmic counters of the traversal actually run)
     c.set_option('count', 1)
     c.call('mpt_reset_counters')
     W = max(args.warmup, 1)
     for _ in range(W):
-        step()
+        step(True)
     barrier()
     cnt = c.counters()
     c.set_option('count', 0)
     c.kernel_time()
-    bytes_per_launch = algorithmic_bytes(cnt) / W
-    for _ in range(1):                        # one untimed step of the production (non-counting) kernel
-        step()
+    step(True)                                # one untimed step of the production (non-counting) kernel
     barrier()
     c.kernel_time()
 
+    # ---- timed region: K steps, each ending with the image in host memory (max over ranks)
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        img = step(True)
     barrier()
     dt = time.perf_counter() - t0
     kms, nlaunch = c.kernel_time()
     if comm:
         dt = comm.allreduce_max(dt)
 
-    # D2H-inclusive variant of the same step (the reference's get_image returns a host array)
-    d2h = None
-    if rank == 0 and world == 1:
-        reps = max(args.steps // 4, 3)
-        eng.render(SPP)
-        FilmTable().get_image()               # untimed: first read-back allocates the staging buffer
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            eng.render(SPP)
-            FilmTable().get_image()
-        d2h = NX * NY * SPP * reps / (time.perf_counter() - t1) / 1e6
+    # ---- the same K steps stopping at the resolved image in HBM (consecutive launches overlap)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    barrier()
+    dt_resolve = time.perf_counter() - t1
+    c.kernel_time()
+    if comm:
+        dt_resolve = comm.allreduce_max(dt_resolve)
 
     if rank == 0:
+        assert img is not None and img.shape == (NX, NY, 4) and float(img[..., 3].min()) == 1.0
         total = NX * NY * SPP * args.steps
-        value = total / dt / 1e6
         avg_kernel_s = kms / 1e3 / max(nlaunch, 1)
-        # small launches (N > 1 slabs) take 1/G of the CUs each and G of them are resident at once
+        # small launches (N > 1 shares) take 1/G of the CUs each and G of them are resident at once
         concurrent = max(c.get_option('cur_div'), 1)
-        achieved = bytes_per_launch * concurrent / avg_kernel_s / 1e9
+        kernel = render_kernel_name(args.mode, c.get_option('last_kernel'))
+        clock_hz = c.get_option('clock_khz') * 1e3 or 2.4e9
+        if pmc is None and world == 1:
+            pmc, pmc_source = committed_pmc(kernel)
+        roof, hbm = roofline_blocks(pmc if world == 1 else None, pmc_source if world == 1 else 'N > 1: not collected',
+                                    kernel, avg_kernel_s, clock_hz, concurrent)
+        samples_per_launch = cnt['samples'] / W
         out = {
             'metric': 'Msamples/sec (pixels x spp / s), 512x512x32spp cornell-monkey (978 tri)',
-            'value': round(value, 3), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps,
+            'value': round(total / dt / 1e6, 3), 'unit': 'Msamples/s', 'n_gpus': n_gpus, 'steps': args.steps,
             'warmup': W, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.scene}: 978-tri synthetic cornell + bumpy sphere, {NX}x{NY}, {SPP} spp, '
-                                   'unidirectional MIS path tracer, depth<=5', 'film': [NX, NY], 'spp': SPP,
-                       'mode': args.mode, 'parallelism': f'film columns in 16-wide stripes over {world} GPUs, RCCL gather' if world > 1 else 'single GPU'},
-            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': measured_traffic(),
-                         'kernel': ('render_kernel_lds' if c.get_option('last_kernel') else 'render_kernel_fast')
-                         if args.mode == 'fast' else 'render_kernel_strict',
-                         'avg_kernel_ms': round(avg_kernel_s * 1e3, 4), 'launches': nlaunch, 'concurrent_launches': concurrent,
-                         'algorithmic_bytes_per_launch': int(bytes_per_launch),
-                         'bytes_per_sample': round(bytes_per_launch / (cnt['samples'] / W), 2),
-                         'note': 'algorithmic bytes (SURVEY 8d) over kernel time; the 125 KB of nodes+triangles are '
-                                 'served from LDS, so this exceeds what HBM could deliver and HBM is not the binding '
-                                 'limit: the kernel is VALU-issue bound (profiles/, DESIGN.md)'},
-            'valu': measured_valu(avg_kernel_s) if (world == 1 and args.mode == 'fast' and args.scene == 's978') else None,
+                                   'unidirectional MIS path tracer, depth<=5; step = 32 x render() + get_image() '
+                                   '(resolve + D2H), exams/benchmark.py:29-36', 'film': [NX, NY], 'spp': SPP,
+                       'mode': args.mode,
+                       'parallelism': f'film columns in 16-wide stripes over {n_gpus} GPUs, RCCL gather' if n_gpus > 1 else 'single GPU'},
+            'value_resolve_only': round(total / dt_resolve / 1e6, 3),
+            'ms_per_step_resolve_only': round(dt_resolve / args.steps * 1e3, 4),
+            'roofline': roof,
+            'hbm': hbm,
+            'algorithmic': {'bytes_per_sample': round(algorithmic_bytes(cnt) / max(cnt['samples'], 1), 2),
+                            'bytes_per_launch': int(algorithmic_bytes(cnt) / W),
+                            'GB/s': round(algorithmic_bytes(cnt) / W * concurrent / avg_kernel_s / 1e9, 1),
+                            'note': 'SURVEY 8(d) bytes of the traversal actually run (counting build), served from LDS: '
+                                    'NOT an HBM figure and not a roofline fraction'},
             'counters_per_sample': {k: round(v / max(cnt['samples'], 1), 3) for k, v in cnt.items() if k != 'samples'},
-            'mrays_per_s': round(cnt['rays'] / W / avg_kernel_s / 1e6, 1),
+            'mrays_per_s': round(cnt['rays'] / W * concurrent / avg_kernel_s / 1e6, 1),
+            'samples_per_launch': int(samples_per_launch),
         }
-        if d2h is not None:
-            out['value_incl_d2h'] = round(d2h, 3)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(scene, scenes.BENCH_CAMERA)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if comm:
         comm.barrier()
         comm.close()
+
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # nobody launched ranks for us: do it here, before this process makes any HIP call
+        from ptina_amd.dist import launch_ranks
+        rc, out = launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                               timeout=float(os.environ.get('MIPTINA_LAUNCH_TIMEOUT', '900')))
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        sys.exit(rc)
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    pmc, pmc_source = None, 'not collected'
+    if args.role == 'main' and world == 1 and args.mode == 'fast' and not args.no_pmc \
+            and os.environ.get('MIPTINA_BENCH_PMC', '1') != '0':
+        # before anything in this process touches the GPU
+        tail = ['--steps', '3', '--warmup', '1', '--scene', args.scene, '--mode', args.mode, '--no-cpu-baseline']
+        pmc, pmc_source = collect_pmc(tail)
+        if pmc is not None:
+            try:
+                os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+                with open(os.path.join(ROOT, 'gpurun_out', 'bench_pmc.json'), 'w') as f:
+                    json.dump(pmc, f, indent=1, sort_keys=True)
+            except OSError:
+                pass
+        else:
+            print('bench.py: ' + pmc_source, file=sys.stderr)
+    run_rank(args, rank, world, pmc, pmc_source)
 
 
 if __name__ == '__main__':

@@ -21,6 +21,8 @@
 #ifndef MIPTINA_H
 #define MIPTINA_H
 
+#include <stddef.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -148,12 +150,23 @@ int mpt_get_film_raw(mpt_ctx *ctx, int pass, float *out);
 /* device-side resolve only (no read-back): what get_image does before the copy */
 int mpt_resolve(mpt_ctx *ctx, int pass);
 
+/* Page-locked host buffers for the read-backs above: into such a buffer mpt_get_image /
+ * mpt_fast_export_image / mpt_get_film_raw are one DMA; any other buffer is served through a
+ * page-locked staging copy.  (The reference's get_image returns a fresh numpy array,
+ * ptina/filmtable.py:48; FilmTable.get_image here builds that array on a recycled buffer of these.) */
+void *mpt_host_alloc(size_t bytes);
+void  mpt_host_free(void *p);
+
 /* measurement */
 int mpt_get_counters(mpt_ctx *ctx, mpt_counters *out);
 /* Diagnostics (option "timeline" = 1): per wave of the last LDS-kernel launch, four 100 MHz timestamps
  * {start, scene copied to LDS, work queues found empty, exit}.  *nwaves = waves recorded. */
 int mpt_get_timeline(mpt_ctx *ctx, unsigned long long *out /* [cap_waves][4] */, int cap_waves, int *nwaves);
 int mpt_reset_counters(mpt_ctx *ctx);
+/* Diagnostics: launch a one-workgroup kernel (`threads` lanes, `lds_bytes` of LDS) on a stream of its own
+ * while the enqueued render launches keep running, and return the wall time until it has completed --
+ * what a collective's kernel would wait for a CU beside the persistent render workgroups. */
+int mpt_probe_kernel(mpt_ctx *ctx, int threads, int lds_bytes, double *usec);
 /* HIP-event time of the render kernels launched since the last call (ms) and their count */
 int mpt_kernel_time(mpt_ctx *ctx, double *ms, int *launches);
 

@@ -11,7 +11,8 @@ import threading
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libmiptina.so')
+# MIPTINA_LIB: another build of the same library (A/B runs of compiler flags, tools/gpu_round.sh)
+LIB_PATH = os.environ.get('MIPTINA_LIB') or os.path.join(HERE, 'libmiptina.so')
 
 MODE_FAST, MODE_STRICT = 0, 1
 LIGHT_TYPES = {'POINT': 1, 'AREA': 2}          # LightPool.TYPES, light/__init__.py:11
@@ -69,9 +70,12 @@ SIGNATURES = {
     'mpt_fast_export_image': (_i, [_vp, _i, _fp]),
     'mpt_get_film_raw': (_i, [_vp, _i, _fp]),
     'mpt_resolve': (_i, [_vp, _i]),
+    'mpt_host_alloc': (_vp, [C.c_size_t]),
+    'mpt_host_free': (None, [_vp]),
     'mpt_get_counters': (_i, [_vp, C.POINTER(Counters)]),
     'mpt_get_timeline': (_i, [_vp, C.POINTER(C.c_ulonglong), _i, C.POINTER(_i)]),
     'mpt_reset_counters': (_i, [_vp]),
+    'mpt_probe_kernel': (_i, [_vp, _i, _i, C.POINTER(C.c_double)]),
     'mpt_kernel_time': (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     'mpt_comm_unique_id': (_i, [C.c_char_p]),
     'mpt_comm_init': (_i, [_vp, C.c_char_p, _i, _i]),
@@ -112,6 +116,43 @@ def check(rc):
         raise RuntimeError(last_error())
 
 
+class HostBuffer:
+    '''a page-locked host buffer of libmiptina; goes back to the pool when the last numpy view dies'''
+    _pool = {}                                  # bytes -> [addresses]
+    _pool_cap = 4
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        free = HostBuffer._pool.get(self.nbytes)
+        if free:
+            self.addr = free.pop()
+        else:
+            self.addr = load_library().mpt_host_alloc(self.nbytes)
+            if not self.addr:
+                raise MemoryError(last_error())
+
+    def __del__(self):
+        try:
+            free = HostBuffer._pool.setdefault(self.nbytes, [])
+            if len(free) < HostBuffer._pool_cap:
+                free.append(self.addr)
+            else:
+                load_library().mpt_host_free(self.addr)
+        except Exception:
+            pass
+
+
+def host_array(shape, dtype=np.float32):
+    '''a fresh numpy array on page-locked memory (read-backs into it are a single DMA); the buffer is
+    recycled as soon as the array and every view of it are gone (plain reference counting: the array's
+    base is a ctypes buffer that owns the HostBuffer, and nothing points back)'''
+    count = int(np.prod(shape))
+    hb = HostBuffer(max(count * np.dtype(dtype).itemsize, 1))
+    buf = (C.c_char * hb.nbytes).from_address(hb.addr)
+    buf._owner = hb
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+
 def fptr(a):
     return a.ctypes.data_as(_fp)
 
@@ -131,10 +172,9 @@ class Context:
             setattr(c, k, int(v))
         self.caps = c
         if device is None:
+            # one rank per GPU: a rank whose LOCAL_RANK has no device fails in mpt_create ("device out of
+            # range") instead of piling onto somebody else's GPU
             device = int(os.environ.get('MIPTINA_DEVICE', os.environ.get('LOCAL_RANK', '0')))
-            ndev = lib.mpt_device_count()
-            if ndev > 0:
-                device %= ndev
         self.device = device
         self.lib = lib
         h = lib.mpt_create(C.byref(c), device)

@@ -95,6 +95,21 @@ __global__ __launch_bounds__(256) void export_kernel(const MptVec4 *__restrict__
     out[o * 3 + 0] = v.x; out[o * 3 + 1] = v.y; out[o * 3 + 2] = v.z;
 }
 
+// diagnostics: a one-workgroup kernel with a chosen LDS footprint -- a stand-in for a collective's
+// kernel when measuring how long such a kernel waits for a CU while persistent render workgroups
+// hold all of them (mpt_probe_kernel)
+__global__ void probe_kernel(double *out) {
+    extern __shared__ int probe_lds[];
+    probe_lds[threadIdx.x] = (int)threadIdx.x;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (double)probe_lds[blockDim.x - 1];
+}
+
+MPT_KERNEL_API hipError_t mpt_launch_probe(double *out, int threads, size_t lds_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(threads), lds_bytes, stream, out);
+    return hipGetLastError();
+}
+
 MPT_KERNEL_API hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0,
                                               int count, int keep, hipStream_t stream) {
     int grid = (dim + 255) / 256;

@@ -84,9 +84,18 @@ extern "C" int mpt_comm_gather_film(mpt_ctx *c, int pass, int root) {
     // mpt_set_stripes(width, rank, R) -- stripes r, r+R, ... of `width` columns; each piece is one
     // contiguous float4 range (film index x*ny + y) and travels as its own send/recv of one group
     const int R = c->nranks;
+    if (root < 0 || root >= R) return fail("gather root %d outside [0, %d)", root, R);
     if (c->stripe_w && (c->stripe_mod != R || c->stripe_idx != c->rank))
         return fail("stripes (index %d of %d) do not match the communicator (rank %d of %d)", c->stripe_idx,
                     c->stripe_mod, c->rank, R);
+    if (!c->stripe_w && R > 1) {
+        // slab mode: what this rank rendered must be exactly the columns the others expect from it
+        const int lo = (int)((long long)c->rank * c->nx / R), hi = (int)((long long)(c->rank + 1) * c->nx / R);
+        if (c->x0 != lo || c->x1 != hi)
+            return fail("slab [%d,%d) of rank %d does not match the communicator's split [%d,%d) of %d ranks: "
+                        "set it with mpt_set_slab(rank*nx/R, (rank+1)*nx/R) or use mpt_set_stripes",
+                        c->x0, c->x1, c->rank, lo, hi, R);
+    }
     auto pieces = [&](int r, std::vector<std::pair<size_t, size_t>> &out) {
         out.clear();
         if (c->stripe_w == 0) {

@@ -44,6 +44,11 @@ int use_ro(mpt_ctx *c) {   // entry of calls that only read results
 
 int use(mpt_ctx *c) {      // entry of calls that may change what the next render launch reads
     if (use_ro(c)) return 1;
+    // frames enqueued so far render with the state they were enqueued under
+    if (mpt_flush(c)) return 1;
+    // Marked AFTER that flush: the flush records ev_main and clears the mark, and what this call is
+    // about to enqueue on the main stream (a Sobol reset, an upload, a film clear) must be behind the
+    // ev_main the NEXT batch's aux / render streams wait for.
     c->main_dirty = true;
     return 0;
 }
@@ -113,8 +118,10 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess) return bail("event");
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            c->num_cus = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            if (prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+            c->clock_khz = prop.clockRate;
+        }
     }
     if (make_render_streams(c)) return bail("render streams");
     {
@@ -146,6 +153,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     hipStreamSynchronize(c->stream);
     mpt_comm_release(c);
     if (c->aux) hipStreamDestroy(c->aux);
+    if (c->probe_stream) hipStreamDestroy(c->probe_stream);
     for (int k = 0; k < MPT_MAX_PIPE; k++) {
         if (c->rstream[k]) hipStreamDestroy(c->rstream[k]);
         if (c->ev_render[k]) hipEventDestroy(c->ev_render[k]);
@@ -163,6 +171,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
     if (c->h_watchdog) hipHostFree(c->h_watchdog);
+    if (c->h_stage) hipHostFree(c->h_stage);
     hipFree(c->d_verts); hipFree(c->d_mtlids); hipFree(c->d_cen); hipFree(c->d_bounds); hipFree(c->d_depth);
     hipFree(c->d_keys_in); hipFree(c->d_keys_out); hipFree(c->d_sort_tmp);
     hipFree(c->d_child); hipFree(c->d_parent); hipFree(c->d_leaf); hipFree(c->d_mc);
@@ -171,10 +180,64 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     delete c;
 }
 
+// ------------------------------------------------------------------ page-locked host buffers
+// Read-backs into page-locked memory are one DMA (4 MiB film: ~80 us); into pageable memory the runtime
+// stages them through its own bounce buffers at a fraction of that rate.  mpt_host_alloc hands out
+// page-locked buffers (FilmTable.get_image builds its arrays on them); buffers of any other origin go
+// through one page-locked staging buffer of the context and a memcpy.
+static std::mutex g_host_mu;
+static std::map<uintptr_t, size_t> g_host_bufs;   // base -> bytes
+
+extern "C" void *mpt_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) {
+        fail("hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    g_host_bufs[(uintptr_t)p] = bytes;
+    return p;
+}
+
+extern "C" void mpt_host_free(void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        g_host_bufs.erase((uintptr_t)p);
+    }
+    hipHostFree(p);
+}
+
+static bool is_locked_range(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    auto it = g_host_bufs.upper_bound((uintptr_t)p);
+    if (it == g_host_bufs.begin()) return false;
+    --it;
+    return (uintptr_t)p + bytes <= it->first + it->second;
+}
+
+// device -> caller buffer on the main stream, blocking
+static int read_back(mpt_ctx *c, void *out, const void *dev, size_t bytes) {
+    if (is_locked_range(out, bytes)) {
+        HIP_TRY(hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    if (bytes > c->h_stage_bytes) {
+        if (c->h_stage) hipHostFree(c->h_stage);
+        c->h_stage = nullptr; c->h_stage_bytes = 0;
+        HIP_TRY(hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault));
+        c->h_stage_bytes = bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_stage, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_stage, bytes);
+    return 0;
+}
+
 // ------------------------------------------------------------------ options
 extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     std::string k = key ? key : "";
     if (k == "mode") {
         if (value != MPT_MODE_FAST && value != MPT_MODE_STRICT) return fail("mode must be 0 (fast) or 1 (strict)");
@@ -243,6 +306,10 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "cur_div") *value = c->cur_div;
     else if (k == "last_kernel") *value = c->last_kernel;
     else if (k == "num_cus") *value = c->num_cus;
+    else if (k == "nranks") *value = c->nranks;
+    else if (k == "rank") *value = c->rank;
+    else if (k == "device") *value = c->device;
+    else if (k == "clock_khz") *value = c->clock_khz;
     else return fail("unknown option '%s'", k.c_str());
     return 0;
 }
@@ -250,7 +317,6 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
 // ------------------------------------------------------------------ film
 extern "C" int mpt_set_size(mpt_ctx *c, int nx, int ny) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if (nx <= 0 || ny <= 0) return fail("film size must be positive, got %dx%d", nx, ny);
     size_t npix = (size_t)nx * ny;
     if (npix > (size_t)c->caps.max_filmsize)
@@ -283,7 +349,6 @@ extern "C" int mpt_get_size(mpt_ctx *c, int *nx, int *ny) {
 
 extern "C" int mpt_set_slab(mpt_ctx *c, int x0, int x1) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if (x0 < 0 || x1 > c->nx || x0 > x1) return fail("slab [%d,%d) outside film width %d", x0, x1, c->nx);
     c->x0 = x0; c->x1 = x1;
     c->stripe_w = 0; c->stripe_idx = 0; c->stripe_mod = 1;
@@ -295,7 +360,6 @@ extern "C" int mpt_set_slab(mpt_ctx *c, int x0, int x1) {
 // cost 25 % more than the outer ones); interleaved stripes even that out.
 extern "C" int mpt_set_stripes(mpt_ctx *c, int width, int index, int modulo) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if (c->nx <= 0) return fail("film size not set: call set_size() first");
     if (width <= 0 || width % MPT_TILE != 0) return fail("stripe width must be a positive multiple of %d", MPT_TILE);
     if (modulo < 1 || index < 0 || index >= modulo) return fail("stripe index %d outside [0, %d)", index, modulo);
@@ -323,7 +387,6 @@ static void share_extent(const mpt_ctx *c, int tile, long long *cols, int *tile_
 // ------------------------------------------------------------------ scene upload
 extern "C" int mpt_load_model(mpt_ctx *c, const float *verts, const int32_t *mtlids, int n) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if (n < 0 || (n > 0 && !verts)) return fail("bad model arguments");
     if (n >= c->caps.max_faces) return fail("too many faces");                // model.py:84
     c->nfaces = n;
@@ -339,7 +402,6 @@ extern "C" int mpt_load_model(mpt_ctx *c, const float *verts, const int32_t *mtl
 
 extern "C" int mpt_load_materials(mpt_ctx *c, const float *fac, const int32_t *tex, int m) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if (m < 0 || m > c->caps.max_materials) return fail("%d materials exceed max_materials=%d", m, c->caps.max_materials);
     std::vector<MptMaterial> h(std::max(m, 1));
     for (int i = 0; i < m; i++) {
@@ -363,7 +425,6 @@ extern "C" int mpt_load_materials(mpt_ctx *c, const float *fac, const int32_t *t
 
 extern "C" int mpt_reset_images(mpt_ctx *c) {                                  // image.py:90-92
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     c->h_images.clear();
     c->texels_used = 0;
     return 0;
@@ -371,7 +432,6 @@ extern "C" int mpt_reset_images(mpt_ctx *c) {                                  /
 
 extern "C" int mpt_load_image(mpt_ctx *c, const float *rgba, int nx, int ny, int *id) {   // image.py:51-88
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if ((int)c->h_images.size() >= c->caps.max_textures) return fail("Out of ID!");       // allocator.py:53
     size_t need = (size_t)nx * ny;
     if (c->texels_used + need > (size_t)c->caps.max_texels) return fail("Out of memory!"); // allocator.py:24
@@ -389,7 +449,6 @@ extern "C" int mpt_load_image(mpt_ctx *c, const float *rgba, int nx, int ny, int
 
 extern "C" int mpt_set_camera(mpt_ctx *c, const float v2w[16], const float w2v[16]) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     memcpy(c->v2w, v2w, sizeof c->v2w);
     if (w2v) memcpy(c->w2v, w2v, sizeof c->w2v);
     return 0;
@@ -397,7 +456,6 @@ extern "C" int mpt_set_camera(mpt_ctx *c, const float v2w[16], const float w2v[1
 
 extern "C" int mpt_clear_lights(mpt_ctx *c) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     c->h_lights.clear();
     return 0;
 }
@@ -405,7 +463,6 @@ extern "C" int mpt_clear_lights(mpt_ctx *c) {
 extern "C" int mpt_add_light(mpt_ctx *c, int type, const float color[3], const float pos[3], const float axes[9],
                              float size, int *index) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if (type != MPT_LIGHT_POINT && type != MPT_LIGHT_AREA) return fail("unknown light type %d", type);
     if ((int)c->h_lights.size() >= c->caps.max_lights) return fail("too many lights (max_lights=%d)", c->caps.max_lights);
     MptLight L{};
@@ -422,7 +479,6 @@ extern "C" int mpt_add_light(mpt_ctx *c, int type, const float color[3], const f
 
 extern "C" int mpt_set_world_light(mpt_ctx *c, const float fac[4], int tex) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     memcpy(c->world_fac, fac, sizeof c->world_fac);
     c->world_tex = tex;
     return 0;
@@ -431,7 +487,6 @@ extern "C" int mpt_set_world_light(mpt_ctx *c, const float fac[4], int tex) {
 // ------------------------------------------------------------------ sobol
 extern "C" int mpt_sobol_init(mpt_ctx *c, const int32_t *V, int rows, int dim) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if (rows < 2 || dim < 1 || !V) return fail("bad sobol grid %dx%d", rows, dim);
     HIP_TRY(hipStreamSynchronize(c->stream));
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
@@ -465,7 +520,6 @@ static int sobol_advance(mpt_ctx *c, int count, int keep, hipStream_t stream = n
 
 extern "C" int mpt_sobol_reset(mpt_ctx *c, int skip) {                         // sobol.py:92-97
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if (!c->sV) return fail("sobol sampler not initialised");
     c->stime = 0;
     HIP_TRY(hipMemsetAsync(c->sX, 0, (size_t)c->sdim * sizeof(int), c->stream));
@@ -474,14 +528,12 @@ extern "C" int mpt_sobol_reset(mpt_ctx *c, int skip) {                         /
 
 extern "C" int mpt_sobol_update(mpt_ctx *c, int count) {                       // sobol.py:99-105
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if (!c->sV) return fail("sobol sampler not initialised");
     return sobol_advance(c, count, 0);
 }
 
 extern "C" int mpt_sobol_get(mpt_ctx *c, int32_t *X, float *P, int32_t *time) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     if (!c->sV) return fail("sobol sampler not initialised");
     std::vector<int32_t> x(c->sdim);
     HIP_TRY(hipMemcpyAsync(x.data(), c->sX, (size_t)c->sdim * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -690,7 +742,6 @@ extern "C" int mpt_render(mpt_ctx *c, int nframes) {                           /
 
 extern "C" int mpt_render_preview(mpt_ctx *c, int nframes) {                   // preview.py:18-41
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     while (nframes > 0) {
         int B = std::min(nframes, MPT_MAX_BATCH);
         MptRenderParams p;
@@ -709,8 +760,10 @@ extern "C" int mpt_render_preview(mpt_ctx *c, int nframes) {                   /
 
 // a persistent render kernel that had to be stopped by its watchdog leaves a flag behind (in host-pinned
 // memory: no copy to read it); call after the streams have been synchronised
-static int check_watchdog(mpt_ctx *c) {
-    if (__atomic_load_n(c->h_watchdog, __ATOMIC_ACQUIRE))
+int check_watchdog(mpt_ctx *c) {
+    // read and re-arm: the failure is reported once, by the first read-back after it (the film holds
+    // incomplete sums until the caller clears it)
+    if (__atomic_exchange_n(c->h_watchdog, 0u, __ATOMIC_ACQ_REL))
         return fail("render kernel stopped by its watchdog (scheduler made no progress): film is incomplete");
     return 0;
 }
@@ -727,7 +780,6 @@ extern "C" int mpt_synchronize(mpt_ctx *c) {                                   /
 extern "C" int mpt_clear(mpt_ctx *c, int pass) {                               // filmtable.py:44-45: every pass, `id` ignored
     (void)pass;
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     size_t npix = (size_t)c->nx * c->ny;
     for (int p = 0; p < 3; p++)
         if (c->film[p]) HIP_TRY(hipMemsetAsync(c->film[p], 0, npix * sizeof(MptVec4), c->stream));
@@ -750,8 +802,7 @@ extern "C" int mpt_resolve(mpt_ctx *c, int pass) {
 
 extern "C" int mpt_get_image(mpt_ctx *c, int pass, float *out) {               // filmtable.py:47-63
     if (mpt_resolve(c, pass)) return 1;
-    HIP_TRY(hipMemcpyAsync(out, c->resolved, (size_t)c->nx * c->ny * sizeof(MptVec4), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (read_back(c, out, c->resolved, (size_t)c->nx * c->ny * sizeof(MptVec4))) return 1;
     return check_watchdog(c);
 }
 
@@ -760,18 +811,16 @@ extern "C" int mpt_fast_export_image(mpt_ctx *c, int pass, float *out) {       /
     if (mpt_flush(c)) return 1;
     if (check_pass(c, pass)) return 1;
     HIP_TRY(mpt_launch_export(c->film[pass], c->exported, c->nx, c->ny, c->stream));
-    HIP_TRY(hipMemcpyAsync(out, c->exported, (size_t)c->nx * c->ny * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    if (read_back(c, out, c->exported, (size_t)c->nx * c->ny * 3 * sizeof(float))) return 1;
+    return check_watchdog(c);
 }
 
 extern "C" int mpt_get_film_raw(mpt_ctx *c, int pass, float *out) {
     if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
     if (check_pass(c, pass)) return 1;
-    HIP_TRY(hipMemcpyAsync(out, c->film[pass], (size_t)c->nx * c->ny * sizeof(MptVec4), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    if (read_back(c, out, c->film[pass], (size_t)c->nx * c->ny * sizeof(MptVec4))) return 1;
+    return check_watchdog(c);
 }
 
 // ------------------------------------------------------------------ measurement
@@ -799,9 +848,24 @@ extern "C" int mpt_get_timeline(mpt_ctx *c, unsigned long long *out, int cap_wav
     return 0;
 }
 
+// diagnostics: wall time from the launch of a one-workgroup kernel (threads lanes, lds_bytes of LDS) on a
+// stream of its own to its completion, with whatever render launches are in flight left running -- how long
+// a small foreign kernel (RCCL's) waits for a CU next to the persistent workgroups
+extern "C" int mpt_probe_kernel(mpt_ctx *c, int threads, int lds_bytes, double *usec) {
+    if (use_ro(c)) return 1;
+    if (threads < 64 || threads > 1024 || lds_bytes < 4 * threads || lds_bytes > 64 * 1024)
+        return fail("probe: threads in 64..1024, lds_bytes in 4*threads..65536");
+    if (!c->probe_stream) HIP_TRY(hipStreamCreateWithFlags(&c->probe_stream, hipStreamNonBlocking));
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(mpt_launch_probe(c->d_scratch + 1, threads, (size_t)lds_bytes, c->probe_stream));
+    HIP_TRY(hipStreamSynchronize(c->probe_stream));
+    auto t1 = std::chrono::steady_clock::now();
+    if (usec) *usec = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    return 0;
+}
+
 extern "C" int mpt_reset_counters(mpt_ctx *c) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), c->stream));
     return 0;
 }

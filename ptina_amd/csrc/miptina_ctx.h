@@ -11,7 +11,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,6 +30,7 @@ MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *parti
                                          int stripe_w, int stripe_pitch,
                                          int nchunks, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_probe(double *out, int threads, size_t lds_bytes, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
 
 // on-GPU LBVH build (lbvh_build.hip)
@@ -65,6 +69,7 @@ struct mpt_ctx {
     // options
     int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1, lds_block = 0;
     int num_cus = 256;
+    int clock_khz = 0;                   // hipDeviceProp_t.clockRate: peak shader clock (roofline peaks in bench.py)
     int tile_w_shift = 3, tile_h_shift = 3;   // work-item tile 2^w x 2^h pixels
     int sched_num = 2, sched_den = 1;    // scheduler: stay in traversal mode while traversing*num >= waiting*den (tuned on MI355X)
     int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
@@ -128,6 +133,7 @@ struct mpt_ctx {
     hipStream_t rstream[MPT_MAX_PIPE] = {};
     hipEvent_t ev_render[MPT_MAX_PIPE] = {};          // render of the batch on rstream[k] finished
     hipEvent_t ev_free[MPT_MAX_PIPE] = {};            // combine has consumed partial[k]
+    hipStream_t probe_stream = nullptr;               // mpt_probe_kernel
     hipStream_t aux = nullptr;                        // Sobol advances + queue resets of the pipelined batches
     hipEvent_t ev_sobol2[MPT_MAX_PIPE] = {};          // Sobol points + zeroed queue heads of the batch on rstream[k] ready
     int pipe_depth = 0;                               // batches in flight (slots of P / partial / queue heads); 0 = auto
@@ -148,6 +154,7 @@ struct mpt_ctx {
     unsigned long long *d_counters = nullptr;
     unsigned int *d_work = nullptr;
     unsigned int *h_watchdog = nullptr, *d_watchdog = nullptr;   // host-pinned, device-mapped: raised by a render kernel's watchdog
+    void *h_stage = nullptr; size_t h_stage_bytes = 0;           // page-locked staging for read-backs into pageable buffers
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
 
@@ -161,6 +168,7 @@ struct mpt_ctx {
 MPT_INTERNAL int use_ro(mpt_ctx *c);   // calls that only read results
 MPT_INTERNAL int use(mpt_ctx *c);      // calls that may change what the next render launch reads
 MPT_INTERNAL int check_pass(mpt_ctx *c, int pass);
+MPT_INTERNAL int check_watchdog(mpt_ctx *c);   // after a synchronise: did a persistent kernel give up?
 
 template <class T>
 static int dev_alloc(T **p, size_t count) {

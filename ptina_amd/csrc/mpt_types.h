@@ -23,6 +23,7 @@
 #define MPT_TILE 16
 #define MPT_MAX_BATCH 64       // frames per launch
 #define MPT_MAX_LIGHTS 64
+#define MPT_MAX_DEVICES 64     // device ids a process may hold contexts on (per-device launch caches)
 
 struct MptVec4 { float x, y, z, w; };
 

@@ -24,6 +24,7 @@
 //   one 16x16 tile per workgroup, blockIdx remapped so an XCD's blocks cover a contiguous run of tiles.
 
 #include "pt_device.h"
+#include <atomic>
 
 #if MPT_STRICT
 #define MPT_SUFFIX(x) x##_strict
@@ -621,15 +622,20 @@ static int blocks_per_cu(K kernel) {
 MPT_KERNEL_API hipError_t MPT_SUFFIX(mpt_launch_render)(const MptRenderParams *p, int grid, int stack, int count,
                                                      hipStream_t stream) {
 #if !MPT_STRICT
-    static int occ[4] = { 0, 0, 0, 0 };
+    // occupancy answers are per device (the C ABI allows one context per GPU in a process)
+    static std::atomic<int> occ_cache[MPT_MAX_DEVICES][4];
     int v = (stack <= 32 ? 0 : 2) + (count ? 1 : 0);
-    if (!occ[v]) {
-        occ[v] = v == 0 ? blocks_per_cu(MPT_SUFFIX(render_kernel)<32, false>)
-               : v == 1 ? blocks_per_cu(MPT_SUFFIX(render_kernel)<32, true>)
-               : v == 2 ? blocks_per_cu(MPT_SUFFIX(render_kernel)<64, false>)
-                        : blocks_per_cu(MPT_SUFFIX(render_kernel)<64, true>);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MPT_MAX_DEVICES) return hipErrorInvalidDevice;
+    int occ = occ_cache[dev][v].load(std::memory_order_relaxed);
+    if (!occ) {
+        occ = v == 0 ? blocks_per_cu(MPT_SUFFIX(render_kernel)<32, false>)
+            : v == 1 ? blocks_per_cu(MPT_SUFFIX(render_kernel)<32, true>)
+            : v == 2 ? blocks_per_cu(MPT_SUFFIX(render_kernel)<64, false>)
+                     : blocks_per_cu(MPT_SUFFIX(render_kernel)<64, true>);
+        occ_cache[dev][v].store(occ, std::memory_order_relaxed);
     }
-    grid *= occ[v];
+    grid *= occ;
 #endif
     if (stack <= 32) {
         if (count) hipLaunchKernelGGL((MPT_SUFFIX(render_kernel)<32, true>), dim3(grid), dim3(MPT_BLOCK), 0, stream, *p);
@@ -645,12 +651,15 @@ MPT_KERNEL_API hipError_t MPT_SUFFIX(mpt_launch_render)(const MptRenderParams *p
 // lds_bytes = scene records + 2 KiB per stack level; grid = one persistent workgroup per CU
 template <bool COUNT>
 static hipError_t launch_lds(const MptRenderParams *p, int grid, int block, size_t lds_bytes, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
+    // function attributes are per device: remember which devices have been told about the 160 KiB
+    static std::atomic<bool> configured[MPT_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MPT_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!configured[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *)render_kernel_lds<COUNT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((render_kernel_lds<COUNT>), dim3(grid), dim3(block), lds_bytes, stream, *p);
     return hipGetLastError();

@@ -470,7 +470,6 @@ static int build_tree_gpu(mpt_ctx *c) {
 
 extern "C" int mpt_build_tree(mpt_ctx *c) {
     if (use(c)) return 1;
-    if (mpt_flush(c)) return 1;
     return c->gpu_build ? build_tree_gpu(c) : build_tree_host(c);
 }
 

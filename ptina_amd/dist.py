@@ -41,14 +41,30 @@ def env_rank():
         int(os.environ.get('LOCAL_RANK', '0'))
 
 
+def rendezvous_path():
+    '''where rank 0 leaves the RCCL unique id for the other ranks of this node.
+
+    * MIPTINA_RDZV_DIR set (launch_ranks() below makes a private directory per job and hands it to
+      every rank through the environment): <dir>/rccl_uid -- nothing to collide with, nothing stale;
+    * under torch.distributed.run the workers are children of ONE agent process, so its pid plus
+      MASTER_PORT names the job: /tmp/miptina_uid_<port>_<agent pid>;
+    * ranks started any other way have no common key to derive: they must be given MIPTINA_RDZV_DIR.'''
+    d = os.environ.get('MIPTINA_RDZV_DIR')
+    if d:
+        return os.path.join(d, 'rccl_uid')
+    if 'TORCHELASTIC_RUN_ID' in os.environ or 'TORCHELASTIC_RESTART_COUNT' in os.environ:
+        return '/tmp/miptina_uid_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+    raise RuntimeError('multi-rank run without a rendezvous: start the ranks with bench.py --gpus N, '
+                       'ptina_amd.dist.launch_ranks() or torch.distributed.run, or give every rank the same '
+                       'MIPTINA_RDZV_DIR')
+
+
 def exchange_unique_id(make_uid, rank, world, timeout=120.0):
     '''hand rank 0's 128-byte ncclUniqueId to the other ranks of this node through a file
-    (the only non-RCCL step; torchrun's workers share a parent pid and MASTER_PORT)'''
+    (the only non-RCCL step of a multi-GPU run)'''
     if world == 1:
         return make_uid()
-    tag = '%s_%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.getppid(),
-                        os.environ.get('TORCHELASTIC_RUN_ID', 'none'))
-    path = os.path.join(os.environ.get('MIPTINA_RDZV_DIR', '/tmp'), f'miptina_uid_{tag}')
+    path = rendezvous_path()
     if rank == 0:
         uid = make_uid()
         tmp = path + '.tmp'
@@ -68,6 +84,86 @@ def exchange_unique_id(make_uid, rank, world, timeout=120.0):
         if time.time() - t0 > timeout:
             raise RuntimeError(f'rank {rank}: no RCCL unique id at {path} after {timeout}s')
         time.sleep(0.01)
+
+
+def launch_ranks(world, argv, timeout=None, env=None):
+    '''start `world` fresh processes of `argv` (one rank per GPU of this node), wait for them and
+    return (exit code, rank 0's stdout).  The caller must not have touched the GPU: the children are
+    new programs, and a process that has initialised HIP must never exec another (nor fork one that does).
+
+    Each child gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT like a torchrun worker,
+    plus MIPTINA_RDZV_DIR = a directory made for this job (the RCCL unique id travels through it).
+    The first rank that fails takes the others down with it: the exit code is that rank's, never 0
+    unless every rank returned 0.'''
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+    if world < 1:
+        raise ValueError('world must be >= 1')
+    rdzv = tempfile.mkdtemp(prefix='miptina_rdzv_')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                MIPTINA_RDZV_DIR=rdzv)
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs on this driver
+    procs = []
+    try:
+        for r in range(world):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            # rank 0's stdout goes to a file (a pipe nobody drains while we poll could fill up)
+            so = open(os.path.join(rdzv, 'rank0.out'), 'wb') if r == 0 else subprocess.DEVNULL
+            procs.append(subprocess.Popen(list(argv), env=e, stdout=so, start_new_session=True))
+            if r == 0:
+                so.close()
+        t0 = time.time()
+        rc = None
+        live = set(range(world))
+        while live and rc is None:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0:
+                    rc = code if code > 0 else 128 - code
+                    sys_err(f'launch_ranks: rank {r} exited with {code}; stopping the other ranks')
+                    break
+            if rc is None and timeout is not None and time.time() - t0 > timeout:
+                rc = 124
+                sys_err(f'launch_ranks: no result after {timeout}s; stopping every rank')
+            if live and rc is None:
+                time.sleep(0.02)
+        out0 = b''
+        if rc is None:
+            rc = 0
+            with open(os.path.join(rdzv, 'rank0.out'), 'rb') as f:
+                out0 = f.read()
+        return rc, out0.decode('utf-8', 'replace')
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, 15)                     # the rank's own process group, nobody else's
+                except OSError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                try:
+                    os.killpg(p.pid, 9)
+                except OSError:
+                    pass
+        shutil.rmtree(rdzv, ignore_errors=True)
+
+
+def sys_err(msg):
+    import sys
+    print(msg, file=sys.stderr, flush=True)
 
 
 class RcclFilm:
@@ -90,10 +186,8 @@ class RcclFilm:
         self.ctx.call('mpt_comm_init', uid, self.world, self.rank)
         self.barrier()
         if self.rank == 0 and self.world > 1:
-            tag = '%s_%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.getppid(),
-                                os.environ.get('TORCHELASTIC_RUN_ID', 'none'))
             try:
-                os.remove(os.path.join(os.environ.get('MIPTINA_RDZV_DIR', '/tmp'), f'miptina_uid_{tag}'))
+                os.remove(rendezvous_path())
             except OSError:
                 pass
 

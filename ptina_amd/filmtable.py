@@ -5,7 +5,7 @@ element x*ny + y, rgb sums + sample count in w.
 
 from .common import *                 # noqa: F401,F403
 from .common import Singleton, register, ctx, np
-from ._lib import fptr
+from ._lib import fptr, host_array
 import ctypes as C
 
 
@@ -38,7 +38,7 @@ class FilmTable(metaclass=Singleton):
     def get_image(self, id=0):
         '''reference filmtable.py:47-63: [nx, ny, 4] f32, rgb / w, w -> 1; empty -> (.9,.4,.9,0)'''
         nx, ny = self._res()
-        arr = np.empty((nx, ny, 4), np.float32)
+        arr = host_array((nx, ny, 4))          # a fresh array, as in the reference; page-locked -> one DMA
         ctx().call('mpt_get_image', int(id), fptr(arr))
         return arr
 

@@ -89,10 +89,100 @@ def test_two_rank_slab_gather_is_bit_identical(tmp_path, oracle_mod):
 def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
     from ptina_amd import dist as D
     monkeypatch.setenv('MIPTINA_RDZV_DIR', str(tmp_path))
-    monkeypatch.setenv('MASTER_PORT', '12345')
     uid = bytes(range(128))
+    assert D.rendezvous_path() == str(tmp_path / 'rccl_uid')
     assert D.exchange_unique_id(lambda: uid, 0, 2) == uid
     assert D.exchange_unique_id(lambda: b'', 1, 2, timeout=2.0) == uid
-    with pytest.raises(RuntimeError):
-        monkeypatch.setenv('MASTER_PORT', '54321')
+    other = tmp_path / 'other_job'
+    other.mkdir()
+    monkeypatch.setenv('MIPTINA_RDZV_DIR', str(other))
+    with pytest.raises(RuntimeError, match='no RCCL unique id'):
         D.exchange_unique_id(lambda: b'', 1, 2, timeout=0.2)
+
+
+def test_rendezvous_needs_a_common_key(monkeypatch):
+    '''ranks that are neither children of launch_ranks() nor torchrun workers have nothing to derive a
+    common path from: that must be an error, not a guess'''
+    from ptina_amd import dist as D
+    for k in ('MIPTINA_RDZV_DIR', 'TORCHELASTIC_RUN_ID', 'TORCHELASTIC_RESTART_COUNT'):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(RuntimeError, match='MIPTINA_RDZV_DIR'):
+        D.exchange_unique_id(lambda: bytes(128), 1, 2, timeout=0.1)
+    monkeypatch.setenv('TORCHELASTIC_RUN_ID', 'none')        # torchrun: siblings under one agent
+    monkeypatch.setenv('MASTER_PORT', '29511')
+    assert D.rendezvous_path() == '/tmp/miptina_uid_29511_%d' % os.getppid()
+
+
+STUB_RANK = r'''
+import json, os, sys, time
+sys.path.insert(0, os.environ['MIPTINA_TEST_ROOT'])
+from ptina_amd.dist import exchange_unique_id
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+assert int(os.environ['LOCAL_RANK']) == rank and os.environ['MASTER_ADDR'] == '127.0.0.1'
+mode = os.environ.get('STUB_MODE', 'ok')
+if mode == 'fail' and rank == world - 1:
+    sys.exit(3)                                   # e.g. no device for this LOCAL_RANK
+uid = exchange_unique_id(lambda: bytes([7]) * 128, rank, world, timeout=20.0)   # the stub "renderer": rendezvous only
+assert uid == bytes([7]) * 128
+if mode == 'fail':
+    time.sleep(60)                                # a rank stuck in a collective its peer never joins
+if rank == 0:
+    print(json.dumps({'metric': 'stub', 'n_gpus': world, 'rdzv': os.environ['MIPTINA_RDZV_DIR']}))
+'''
+
+
+def test_launcher_starts_ranks_and_relays_rank0(tmp_path):
+    '''ptina_amd.dist.launch_ranks -- what `bench.py --gpus N` runs when nobody launched ranks for it:
+    N fresh processes with RANK / LOCAL_RANK / WORLD_SIZE and a private rendezvous directory, rank 0's
+    line relayed, the directory removed afterwards'''
+    import json
+    from ptina_amd.dist import launch_ranks
+    script = tmp_path / 'stub_rank.py'
+    script.write_text(STUB_RANK)
+    env = dict(os.environ, MIPTINA_TEST_ROOT=ROOT)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MIPTINA_RDZV_DIR'):
+        env.pop(k, None)
+    rc, out = launch_ranks(4, [sys.executable, str(script)], timeout=60, env=env)
+    assert rc == 0
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line['n_gpus'] == 4
+    assert not os.path.exists(line['rdzv'])
+
+
+def test_launcher_fails_loudly_when_a_rank_fails(tmp_path):
+    import time
+    from ptina_amd.dist import launch_ranks
+    script = tmp_path / 'stub_rank.py'
+    script.write_text(STUB_RANK)
+    env = dict(os.environ, MIPTINA_TEST_ROOT=ROOT, STUB_MODE='fail')
+    t0 = time.time()
+    rc, out = launch_ranks(2, [sys.executable, str(script)], timeout=60, env=env)
+    assert rc == 3 and out == ''
+    assert time.time() - t0 < 30                  # the stuck rank was stopped, not waited for
+
+
+def test_bench_self_launch_is_decided_before_any_gpu_call(monkeypatch, tmp_path):
+    '''`python bench.py --gpus 2` without WORLD_SIZE goes through launch_ranks with its own argv (checked
+    here with the launcher stubbed out: no GPU, no children)'''
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    from ptina_amd import dist as D
+    seen = {}
+
+    def fake(world, argv, timeout=None, env=None):
+        seen.update(world=world, argv=argv)
+        return 0, '{"n_gpus": %d}\n' % world
+    monkeypatch.setattr(D, 'launch_ranks', fake)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '5'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    assert seen['world'] == 2 and seen['argv'][1].endswith('bench.py') and seen['argv'][2:] == ['--gpus', '2', '--steps', '5']
+    # under a launcher that set WORLD_SIZE the flag must agree with it
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert 'WORLD_SIZE=4' in str(e.value.code)

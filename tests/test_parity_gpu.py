@@ -2,12 +2,14 @@
 GPU parity tests (-m gpu): the HIP path, driven through the C ABI by the PTina-named Python
 classes, against the CPU oracle on the same seeded inputs.
 
-Tolerances (resolved image, per-pixel L2 over rgb), calibrated on MI355X and against the
-oracle's own f32-vs-f64 spread (test_oracle_cpu.py::test_f32_oracle_agrees_with_f64_build):
-  strict build : >= 99 % of pixels within 1e-4 * (1 + |ref|), relative RMSE <= 1e-2
-  fast build   : >= 99.5 % of pixels within 1e-3 * (1 + |ref|) needs many spp to hold, because one
-                 flipped discrete decision (lobe choice, edge hit) moves a pixel by O(sample/spp);
-                 stated per test below.
+Tolerances (resolved image, per-pixel L2 over rgb; helpers.STRICT / helpers.FAST), calibrated on
+MI355X and against the oracle's own f32-vs-f64 spread
+(test_oracle_cpu.py::test_f32_oracle_agrees_with_f64_build):
+  strict build : >= 99.9 % of pixels within 1e-4 * (1 + |ref|), relative RMSE <= 1e-4
+  fast build   : >= 99.5 % of pixels within 1e-3 * (1 + |ref|), relative RMSE <= 2e-3 (SURVEY 8d);
+                 one flipped discrete decision (lobe choice, edge hit) moves a pixel by O(sample/spp),
+                 so cases with few samples per pixel or ill-conditioned materials state their own
+                 calibrated bound, with the measurement it comes from.
 Integer / index work (Sobol state, tree arrays, sample counts) is bit-exact.
 '''
 
@@ -20,6 +22,7 @@ from ptina_amd import scenes
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+from helpers import STRICT, FAST, bounds   # noqa: E402  (the calibrated parity bounds)
 
 
 def _engine(fresh, *a, **kw):
@@ -84,7 +87,7 @@ def test_strict_build_matches_oracle(fresh, oracle_mod, name, nx, ny, spp):
     eng = _engine(fresh, scene, nx, ny, mode='strict')
     img = _bench_sequence(eng, FilmTable(), spp)
     assert np.all(img[..., 3] == 1.0)
-    assert_parity(img, want, 1e-4, 0.01, 1e-2, what=f'strict {name} {nx}x{ny}x{spp}')
+    assert_parity(img, want, *STRICT, what=f'strict {name} {nx}x{ny}x{spp}')
 
 
 @pytest.mark.parametrize('name,nx,ny,spp', [('s34', 96, 96, 32), ('s978', 128, 128, 32)])
@@ -100,7 +103,7 @@ def test_fast_build_matches_oracle(fresh, oracle_mod, name, nx, ny, spp):
     eng = _engine(fresh, scene, nx, ny, mode='fast')
     img = _bench_sequence(eng, FilmTable(), spp)
     assert np.all(img[..., 3] == 1.0)
-    assert_parity(img, want, 1e-3, 0.02, 1e-2, what=f'fast {name} {nx}x{ny}x{spp}')
+    assert_parity(img, want, *FAST, what=f'fast {name} {nx}x{ny}x{spp}')
 
 
 def test_golden_fixture_film(fresh):
@@ -112,7 +115,7 @@ def test_golden_fixture_film(fresh):
     img = _bench_sequence(eng, FilmTable(), 4)
     raw = FilmTable().get_raw()
     assert np.all(raw[:, 3] == 4.0)
-    assert_parity(img, g['image'], 1e-4, 0.02, 2e-2, what='golden s34 24x24x4')
+    assert_parity(img, g['image'], *STRICT, what='golden s34 24x24x4')
 
 
 def test_film_api_semantics(fresh):
@@ -612,7 +615,7 @@ def test_full_size_properties_and_oracle_parity(fresh, oracle_mod, name):
         imgs[key] = img
     reset_all()
     assert np.array_equal(imgs['fast'], imgs['fast2']), 'render is not run-to-run deterministic'
-    assert_parity(imgs['fast'], imgs['strict'], 1e-3, 0.01, 5e-3, what='full-size fast vs strict')
+    assert_parity(imgs['fast'], imgs['strict'], *FAST, what='full-size fast vs strict')
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -624,8 +627,9 @@ def test_full_size_properties_and_oracle_parity(fresh, oracle_mod, name):
     ref.clear()
     ref.render(spp)
     want = ref.get_image()[x0:x1]
-    assert_parity(imgs['strict'][x0:x1], want, 1e-4, 0.01, 1e-2, what=f'full-size strict, columns [{x0},{x1})')
-    assert_parity(imgs['fast'][x0:x1], want, 1e-3, 0.02, 1e-2, what=f'full-size fast, columns [{x0},{x1})')
+    # rel-RMSE of the whole 262 144-pixel film: a handful of flipped 32-spp pixels put it at 9e-5 (measured)
+    assert_parity(imgs['strict'][x0:x1], want, STRICT[0], STRICT[1], 3e-4, what=f'full-size strict, columns [{x0},{x1})')
+    assert_parity(imgs['fast'][x0:x1], want, *FAST, what=f'full-size fast, columns [{x0},{x1})')
 
 
 def test_rccl_film_gather_single_rank(fresh):
@@ -840,7 +844,7 @@ def test_disney_lobes_parity(fresh, oracle_mod, name):
     (the oracle's two builds) already disagree on 5-11 % of the pixels at 16 spp (a refracted path
     flips between lobes on the last bit of a re-used sample), with equal means.  For those two
     materials the bound is therefore calibrated against that spread instead of a fixed tolerance.'''
-    from helpers import setup_oracle, assert_parity, image_stats
+    from helpers import setup_oracle, assert_parity, image_stats, tile_means, _report
     from ptina_amd.things import FilmTable
     from ptina_amd.common import reset_all
     v, m, mats, _ = scenes.scene_s34()
@@ -866,7 +870,7 @@ def test_disney_lobes_parity(fresh, oracle_mod, name):
         got = FilmTable().get_image()
         assert np.isfinite(got).all()
         if not chaotic:
-            assert_parity(got, want, tol, 0.02, 2e-2, what=f'{name} {mode}')
+            assert_parity(got, want, *bounds(mode), what=f'{name} {mode}')
             continue
         d, refn, rel = image_stats(got, want)
         out = float((d > tol * (1 + refn)).mean())
@@ -874,6 +878,16 @@ def test_disney_lobes_parity(fresh, oracle_mod, name):
         print(f'{name} {mode}: outliers {out:.3%} rel-RMSE {rel:.2e} mean error {mean_err:.2%} '
               f'(f64-vs-f32 oracle: {spread_out:.3%}, {spread_rmse:.2e})')
         assert mean_err < 0.01, f'{name} {mode}: mean radiance off by {mean_err:.2%}'
+        # a biased lobe cannot hide in the chaos: the 8x8-pixel tile means must agree as well as the
+        # reference algorithm agrees with itself at another precision (plus 1 % of the mean radiance)
+        tm_got, tm_want = tile_means(got), tile_means(want)
+        scale = float(want[..., :3].mean())
+        tile_err = float(np.sqrt(((tm_got - tm_want) ** 2).sum(axis=-1)).mean()) / scale
+        tile_spread = float(np.sqrt(((tile_means(ref64.get_image()) - tm_want) ** 2).sum(axis=-1)).mean()) / scale
+        print(f'{name} {mode}: mean 8x8-tile error {tile_err:.3%} of the mean radiance (f64-vs-f32 oracle: {tile_spread:.3%})')
+        _report(f'{name} {mode}: tile error {tile_err:.3%} spread {tile_spread:.3%} outliers {out:.3%} relrmse {rel:.2e} mean_err {mean_err:.3%}')
+        assert tile_err < (0.01 if mode == 'strict' else 0.01 + 2 * tile_spread), \
+            f'{name} {mode}: 8x8 tile means off by {tile_err:.2%} (spread {tile_spread:.2%})'
         if mode == 'strict':       # same arithmetic as the f32 oracle up to libm: only a few flips
             assert out < 0.03 and rel < 1e-2, f'{name} strict: {out:.3%} outliers, rel-RMSE {rel:.2e}'
         else:                      # within twice the spread the reference algorithm shows itself
@@ -909,3 +923,199 @@ def test_many_lights(fresh, oracle_mod):
         eng.render(16)
         assert_parity(FilmTable().get_image(), ref.get_image(), tol, 0.03, 3e-2, what=f'64 lights {mode}')
     reset_all()
+
+
+# ---------------------------------------------------------------- round 2: ordering, BASELINE configs 3-5 as stated
+def test_state_change_between_partial_batches_is_ordered(fresh):
+    '''frames enqueued below the batch size, then a call that enqueues work on the main stream
+    (Sobol reset, preview pass, counter reset), then more frames: the pipelined launch on the aux /
+    render streams must see that work.  One-frame launches (batch = 1) are the reference order.'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.sampling.sobol import SobolSampler
+    from ptina_amd.engine.preview import PreviewEngine
+    from ptina_amd.common import ctx, reset_all
+    films = {}
+    for batch in (1, 32):
+        reset_all()
+        eng = _engine(None, scenes.scene_s978(), 128, 96, mode='fast')
+        ctx().set_option('batch', batch)
+        for rep in range(3):                       # several rounds so that stale events would be picked up
+            eng.render(5)
+            SobolSampler().reset()
+            eng.render(32)
+            eng.render(3)
+            PreviewEngine().render()
+            eng.render(7)
+            ctx().call('mpt_reset_counters')
+            eng.render(2)
+            ctx().call('mpt_sobol_update', 3)
+            eng.render(30)
+        films[batch] = (FilmTable().get_raw(0), FilmTable().get_raw(1), FilmTable().get_raw(2))
+    reset_all()
+    for a, b in zip(films[1], films[32]):
+        assert np.array_equal(a, b)
+    assert np.all(films[1][0][:, 3] == 3 * (5 + 32 + 3 + 7 + 2 + 30))
+
+
+C5_SEED_REF_CAN_BUILD = 12346
+
+
+def test_config5_reference_build_fails_on_the_stated_scene(fresh, oracle_mod):
+    '''BASELINE configs[4] as generated (seed 12345): three of the 1 M centroids share a 30-bit Morton
+    code, and the reference's own hierarchy (tree/lbvh.py:93-146, no index tie-break) is corrupted by
+    it -- its genAABBs raises 'AABB step never stop' (lbvh.py:251-261).  The oracle restates that and
+    fails the same way; the product (64-bit code<<32|index keys) must build and render it anyway.'''
+    from ptina_amd.things import init_things, ModelPool, BVHTree, FilmTable
+    from ptina_amd.common import ctx, reset_all
+    n = 1_000_000
+    scene = scenes.scene_random_tris(n)            # seed 12345, BASELINE's scene
+    o = oracle_mod.Oracle(threads=1)
+    o.load_model(scene[0], scene[1])
+    with pytest.raises(RuntimeError, match='AABB step never stop'):
+        o.build_tree()
+    del o
+    init_things()
+    ModelPool().load(scene[0], scene[1])
+    trees = {}
+    for gpu in (1, 0):
+        ctx().set_option('gpu_build', gpu)
+        BVHTree().build()
+        trees[gpu] = BVHTree().to_numpy()
+    for k in ('mc', 'leaf', 'child', 'bmin', 'bmax', 'depth'):
+        assert np.array_equal(trees[0][k], trees[1][k]), k
+    assert np.array_equal(np.sort(trees[1]['leaf']), np.arange(n))
+    reset_all()
+    nx = ny = 1024
+    spp = 16
+    eng = _engine(None, scene, nx, ny, mode='fast')
+    eng.render(spp)
+    raw = FilmTable().get_raw().reshape(nx, ny, 4)
+    assert np.all(raw[..., 3] == spp) and np.isfinite(raw).all() and raw[..., :3].min() >= 0
+    fast = FilmTable().get_image()
+    x0, x1 = 508, 516
+    reset_all()
+    eng = _engine(None, scene, nx, ny, mode='strict', slab=(x0, x1))
+    eng.render(spp)
+    strict = FilmTable().get_image()
+    reset_all()
+    from helpers import assert_parity
+    assert_parity(fast[x0:x1], strict[x0:x1], *FAST, what='C5 (seed 12345) fast vs strict, 8 columns')
+
+
+def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
+    '''BASELINE configs[4] at full size on the first seed whose Morton codes the reference's build can
+    handle: device-built LBVH == host build == the oracle's tree node for node; 1024x1024x16 fast render
+    with every pixel counted; an 8-column window of both builds against the oracle'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import init_things, ModelPool, BVHTree, FilmTable
+    from ptina_amd.common import ctx, reset_all
+    n = 1_000_000
+    scene = scenes.scene_random_tris(n, seed=C5_SEED_REF_CAN_BUILD)
+    nx = ny = 1024
+    spp = 16
+    x0, x1 = 508, 516
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    ref = setup_oracle(oracle_mod, scene, nx, ny, threads=min(cores, 16))
+    want_tree = ref.get_tree(n)
+    init_things()
+    ModelPool().load(scene[0], scene[1])
+    for gpu in (1, 0):
+        ctx().set_option('gpu_build', gpu)
+        BVHTree().build()
+        t = BVHTree().to_numpy()
+        for k in ('mc', 'leaf', 'child', 'bmin', 'bmax'):
+            assert np.array_equal(t[k], want_tree[k]), (gpu, k)
+    reset_all()
+    ref.set_window(x0, x1)
+    ref.render(spp)
+    want = ref.get_image()[x0:x1]
+    eng = _engine(None, scene, nx, ny, mode='fast')
+    assert ctx().get_option('gpu_build') == 1
+    eng.render(spp)
+    raw = FilmTable().get_raw().reshape(nx, ny, 4)
+    assert np.all(raw[..., 3] == spp) and np.isfinite(raw).all() and raw[..., :3].min() >= 0
+    assert_parity(FilmTable().get_image()[x0:x1], want, *FAST, what='C5 1M triangles fast, 8 columns x 16 spp')
+    reset_all()
+    eng = _engine(None, scene, nx, ny, mode='strict', slab=(x0, x1))
+    eng.render(spp)
+    assert_parity(FilmTable().get_image()[x0:x1], want, *STRICT, what='C5 1M triangles strict, 8 columns x 16 spp')
+    reset_all()
+
+
+def test_config4_full_scene_with_environment_vs_oracle(fresh, oracle_mod):
+    '''BASELINE configs[3] as stated: 99 382 triangles in the cornell walls, equirect environment image
+    as world light (light/world.py:22-29), 1024x1024; 8 spp over the whole film (every pixel counted),
+    a 32-column window of both builds against the oracle'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    scene = scenes.scene_c4()
+    assert scene[1].shape[0] == 99382
+    world = ([1.0, 1.0, 1.0, 1.0], 0)
+    nx = ny = 1024
+    spp = 8
+    x0, x1 = 496, 528
+    ref = setup_oracle(oracle_mod, scene, nx, ny, world=world)
+    ref.set_window(x0, x1)
+    ref.render(spp)
+    want = ref.get_image()[x0:x1]
+    eng = _engine(None, scene, nx, ny, mode='fast', world=world)
+    eng.render(spp)
+    assert ctx().get_option('last_kernel') == 0           # gather kernel: the scene does not fit LDS
+    raw = FilmTable().get_raw().reshape(nx, ny, 4)
+    assert np.all(raw[..., 3] == spp) and np.isfinite(raw).all() and raw[..., :3].min() >= 0
+    assert_parity(FilmTable().get_image()[x0:x1], want, *FAST, what='C4 99k triangles + env fast, 32 columns x 8 spp')
+    reset_all()
+    eng = _engine(None, scene, nx, ny, mode='strict', world=world, slab=(x0, x1))
+    eng.render(spp)
+    assert_parity(FilmTable().get_image()[x0:x1], want, *STRICT, what='C4 99k triangles + env strict, 32 columns x 8 spp')
+    reset_all()
+
+
+def test_config3_eight_stripe_shares_reassemble_bit_identically(fresh):
+    '''BASELINE configs[2]'s film split as bench.py --gpus 8 splits it: 2048x2048, 32 spp, stripes of 16
+    columns dealt to 8 ranks (mpt_set_stripes(16, r, 8)); all eight shares rendered one after the other on
+    this GPU must reassemble into exactly the single-GPU film'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd.dist import stripe_columns
+    n, spp, R = 2048, 32, 8
+    scene = scenes.scene_s978()
+    eng = _engine(None, scene, n, n, mode='fast', max_filmsize=n * n)
+    eng.render(spp)
+    full = FilmTable().get_raw().reshape(n, n, 4).copy()
+    assert np.all(full[..., 3] == spp) and np.isfinite(full).all()
+    tiled = np.zeros_like(full)
+    for r in range(R):
+        reset_all()
+        eng = _engine(None, scene, n, n, mode='fast', max_filmsize=n * n)
+        ctx().call('mpt_set_stripes', 16, r, R)
+        eng.render(spp)
+        part = FilmTable().get_raw().reshape(n, n, 4)
+        cols = stripe_columns(n, R, r)
+        assert np.all(part[np.setdiff1d(np.arange(n), cols)] == 0)
+        tiled[cols] = part[cols]
+    reset_all()
+    assert np.array_equal(tiled, full)
+
+
+def test_bench_refuses_more_gpus_than_the_box_has(fresh):
+    '''bench.py --gpus 2 on a one-GPU box: the launcher starts two ranks, rank 1 finds no device for its
+    LOCAL_RANK and the whole run exits non-zero (no silent pile-up on GPU 0, no n_gpus: 1 line)'''
+    import subprocess
+    import sys
+    from ptina_amd import _lib
+    if _lib.load_library().mpt_device_count() >= 2:
+        pytest.skip('needs a box with exactly one GPU')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    env['MIPTINA_LAUNCH_TIMEOUT'] = '240'
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert '"n_gpus"' not in p.stdout

@@ -383,8 +383,51 @@ def c5sah(n=1024, spp=16):
     return res
 
 
+def probe(name='s978', spp=32, n=512, world=8, rounds=40):
+    '''how long does a small foreign kernel (stand-in for RCCL's send/recv kernel) wait for a CU while this
+    rank's share of the film is rendered by G overlapped persistent launches?  One 256-lane workgroup with
+    16 KiB of LDS on a stream of its own, launched right after a burst of render launches was enqueued;
+    wall time until it completes, against the same probe on an idle GPU.'''
+    import ctypes as C
+    res = {}
+    for share, label in (((16, 0, world), f'1/{world} share (G launches overlapped)'), (None, 'whole film')):
+        common.reset_all()
+        eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
+        c = ctx()
+        c.set_option('batch', spp)
+        if share:
+            c.call('mpt_set_stripes', *share)
+        us = C.c_double(0)
+        idle = []
+        c.call('mpt_synchronize')
+        for _ in range(10):
+            c.call('mpt_probe_kernel', 256, 16384, C.byref(us))
+            idle.append(us.value)
+        busy = []
+        for _ in range(rounds):
+            for _ in range(6):
+                eng.render(spp)             # six launches enqueued: the ring is full, G resident
+            c.call('mpt_probe_kernel', 256, 16384, C.byref(us))
+            busy.append(us.value)
+        c.call('mpt_synchronize')
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.render(spp)
+        c.call('mpt_synchronize')
+        step_us = (time.perf_counter() - t0) / 20 * 1e6
+        res[label] = {'idle_us_median': float(np.median(idle)), 'busy_us_median': float(np.median(busy)),
+                      'busy_us_p90': float(np.percentile(busy, 90)), 'busy_us_max': float(np.max(busy)),
+                      'step_us': step_us, 'grid_div': c.get_option('cur_div'), 'pipe_depth': c.get_option('cur_depth')}
+        print('probe', label, res[label], flush=True)
+    out['probe'] = res
+    save()
+    common.reset_all()
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'probe' in what:
+        probe()
     if 'c5sah' in what:
         out['c5sah'] = c5sah()
         save()

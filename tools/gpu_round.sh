@@ -31,6 +31,11 @@ for step in "$@"; do
     c3)          run c3 300 python tools/gpu_diag.py c3 ;;
     configs)     run configs 600 python tools/run_configs.py ;;
     c5sah)       run c5sah 600 python tools/gpu_diag.py c5sah ;;
+    probe)       run probe 300 python tools/gpu_diag.py probe ;;
+    ubench)      run ubench 200 tools/microbench/valu_microbench --json ;;
+    ubench_pmc)  run ubench_pmc 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/ubench_pmc -- tools/microbench/valu_microbench ;;
+    bench_noslp) MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_noslp.so run bench_noslp 300 python bench.py --no-pmc --no-cpu-baseline ;;
+    bench_quick) run bench_quick 300 python bench.py --no-pmc --no-cpu-baseline ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
     tests_all)   run tests_all 900 python -m pytest tests -m gpu -q ;;
     bench)       run bench 600 python bench.py ;;
