@@ -74,6 +74,9 @@ def load(f64=False):
     sig('orc_disney_brdf', None, rp, rp, real, rp, rp, rp)
     sig('orc_disney_bounce', None, rp, rp, real, rp, rp, rp)
     sig('orc_power_heuristic', real, real, real)
+    sig('orc_unit_microfacet', None, C.c_int, rp, rp)
+    sig('orc_unit_common', None, C.c_int, rp, rp)
+    sig('orc_unit_face_shading', None, rp, rp, real, real, rp, rp)
     sig('orc_sobol_vgrid', None, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32),
         C.POINTER(C.c_uint32), C.c_int, C.c_int, ip)
     sig('orc_create', vp)

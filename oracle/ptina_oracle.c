@@ -1211,16 +1211,20 @@ static lightsample lights_sample(const orc_ctx *c, v3 hitpos, v3 samp) {     /* 
     return ret;
 }
 
+static inline void dir2tex(v3 dir, real *s, real *t) {                       /* common.py:234-239 */
+    v3 dn = vnormalized(dir);
+    *s = R_ATAN2(dn.z, dn.x) / PI * (real)0.5 + (real)0.5;
+    *t = R_ATAN2(dn.y, R_SQRT(dn.x * dn.x + dn.z * dn.z)) / PI + (real)0.5;
+}
+
 static v3 world_at(const orc_ctx *c, v3 dir) {                               /* light/world.py:22-29 */
     v4 fac = c->wfac;
     int texid = c->wtex;
     if (texid != -1) {
         real ny = dir.z, nz = -dir.y;                   /* dir.y, dir.z = dir.z, -dir.y */
         dir.y = ny; dir.z = nz;
-        /* dir2tex, common.py:234-239 */
-        v3 dn = vnormalized(dir);
-        real s = R_ATAN2(dn.z, dn.x) / PI * (real)0.5 + (real)0.5;
-        real t = R_ATAN2(dn.y, R_SQRT(dn.x * dn.x + dn.z * dn.z)) / PI + (real)0.5;
+        real s, t;
+        dir2tex(dir, &s, &t);
         fac = v4mul(fac, image_sample(c, texid, s, t));
     }
     return V3(fac.x, fac.y, fac.z);
@@ -1251,18 +1255,26 @@ void orc_camera_generate(orc_ctx *c, real x, real y, real o[3], real d[3]) {
 /* ------------------------------------------------------------------ */
 /* shading geometry, model.py:88-101 + geometries.py:96-108             */
 
+/* Face.normal / Face.texcoord, geometries.py:96-108 */
+static inline void face_shading(v3 vn0, v3 vn1, v3 vn2, const real *t0, const real *t1, const real *t2, real u, real v,
+                                v3 *nrm, real *tu, real *tv) {
+    real wx = (real)1 - u - v, wy = u, wz = v;          /* w = V(1 - u - v, u, v) */
+    *nrm = vnormalized(vadd(vadd(vscale(vn0, wx), vscale(vn1, wy)), vscale(vn2, wz)));
+    *tu = wx * t0[0] + wy * t1[0] + wz * t2[0];
+    *tv = wx * t0[1] + wy * t1[1] + wz * t2[1];
+}
+
 static void get_geometries(const orc_ctx *c, const bvhhit *hit, v3 ro, v3 rd, v3 *hitpos, v3 *normal,
                            disney *material) {
     int f = hit->index;
     real u = hit->u, v = hit->v;
-    real wx = (real)1 - u - v, wy = u, wz = v;          /* w = V(1 - u - v, u, v) */
     v3 vn0 = vert_nrm(c, f * 3), vn1 = vert_nrm(c, f * 3 + 1), vn2 = vert_nrm(c, f * 3 + 2);
-    v3 nrm = vnormalized(vadd(vadd(vscale(vn0, wx), vscale(vn1, wy)), vscale(vn2, wz)));
     const real *t0 = c->vertices + (size_t)(f * 3) * 8 + 6;
     const real *t1 = c->vertices + (size_t)(f * 3 + 1) * 8 + 6;
     const real *t2 = c->vertices + (size_t)(f * 3 + 2) * 8 + 6;
-    real tu = wx * t0[0] + wy * t1[0] + wz * t2[0];
-    real tv = wx * t0[1] + wy * t1[1] + wz * t2[1];
+    v3 nrm;
+    real tu, tv;
+    face_shading(vn0, vn1, vn2, t0, t1, t2, u, v, &nrm, &tu, &tv);
     *hitpos = vadd(ro, vscale(rd, hit->depth));
 
     real sign = -vdot(rd, nrm);
@@ -1455,3 +1467,41 @@ void orc_get_film_raw(orc_ctx *c, int pass, float *out) {
 
 void orc_get_counters(orc_ctx *c, orc_counters *out) { *out = c->cnt; }
 void orc_reset_counters(orc_ctx *c) { memset(&c->cnt, 0, sizeof c->cnt); }
+
+/* ------------------------------------------------------------------ */
+/* unit exports: the small functions one by one, for tests/test_reference_l1_cpu.py          */
+
+void orc_unit_microfacet(int which, const real in[3], real out[3]) {          /* microfacet.py:9-78 */
+    out[0] = out[1] = out[2] = 0;
+    v3 r;
+    switch (which) {
+    case 0: out[0] = schlickFresnel(in[0]); break;
+    case 1: out[0] = dielectricFresnel(in[0], in[1], in[2]); break;
+    case 2: out[0] = GTR1(in[0], in[1]); break;
+    case 3: out[0] = GTR2(in[0], in[1]); break;
+    case 4: out[0] = smithGGX(in[0], in[1]); break;
+    case 5: r = sample_GTR1(in[0], in[1], in[2]); out[0] = r.x; out[1] = r.y; out[2] = r.z; break;
+    case 6: r = sample_GTR2(in[0], in[1], in[2]); out[0] = r.x; out[1] = r.y; out[2] = r.z; break;
+    default: break;
+    }
+}
+
+void orc_unit_common(int which, const real in[7], real out[4]) {              /* common.py:213-260 */
+    out[0] = out[1] = out[2] = out[3] = 0;
+    v3 a = V3(in[0], in[1], in[2]), b = V3(in[3], in[4], in[5]), r;
+    switch (which) {
+    case 0: r = tanspace_mul(a, b); out[0] = r.x; out[1] = r.y; out[2] = r.z; break;   /* tanspace(a) @ b */
+    case 1: r = spherical(in[0], in[1]); out[0] = r.x; out[1] = r.y; out[2] = r.z; break;
+    case 2: dir2tex(a, &out[0], &out[1]); break;
+    case 3: r = reflectv(a, b); out[0] = r.x; out[1] = r.y; out[2] = r.z; break;
+    case 4: out[0] = (real)refractv(a, b, in[6], &r); out[1] = r.x; out[2] = r.y; out[3] = r.z; break;
+    default: break;
+    }
+}
+
+void orc_unit_face_shading(const real vn[9], const real vt[6], real u, real v, real nrm[3], real tex[2]) {
+    v3 n;
+    face_shading(V3(vn[0], vn[1], vn[2]), V3(vn[3], vn[4], vn[5]), V3(vn[6], vn[7], vn[8]), vt, vt + 2, vt + 4, u, v,
+                 &n, &tex[0], &tex[1]);
+    nrm[0] = n.x; nrm[1] = n.y; nrm[2] = n.z;
+}

@@ -73,6 +73,16 @@ void orc_disney_bounce(const orc_real params[14], const orc_real normal[3], orc_
                        const orc_real indir[3], const orc_real samp[3], orc_real out[7]);
 /* engine/path.py:11-15 */
 orc_real orc_power_heuristic(orc_real a, orc_real b);
+/* the small functions one by one (tests/test_reference_l1_cpu.py).
+ * microfacet.py:9-78, which = 0 schlickFresnel(cost) | 1 dielectricFresnel(etai, etao, cosi) | 2 GTR1(cosh, alpha) |
+ *   3 GTR2(cosh, alpha) | 4 smithGGX(cosi, alpha) | 5 sample_GTR1(u, v, alpha) -> xyz | 6 sample_GTR2(u, v, alpha) -> xyz */
+void orc_unit_microfacet(int which, const orc_real in[3], orc_real out[3]);
+/* common.py:213-260, which = 0 tanspace(in[0:3]) @ in[3:6] | 1 spherical(h, p) | 2 dir2tex(dir) -> (s, t) |
+ *   3 reflect(I, N) | 4 refract(I, N, eta = in[6]) -> (has_r, T) */
+void orc_unit_common(int which, const orc_real in[7], orc_real out[4]);
+/* Face.normal / Face.texcoord, geometries.py:96-108 */
+void orc_unit_face_shading(const orc_real vn[9], const orc_real vt[6], orc_real u, orc_real v, orc_real nrm[3],
+                           orc_real tex[2]);
 
 /* sampling/sobol.py:32-70 : V has (L+1) rows of D, L = ceil(log2(nsamples)).
  * s[j], a[j], m[j][18] for j>=1 are the Joe-Kuo triplets; dimension 0 is van der Corput. */

@@ -264,6 +264,9 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         if (value != 0 && value != 256 && value != 512 && value != 768 && value != 1024)
             return fail("lds_block must be 0 (auto), 256, 512, 768 or 1024");
         c->lds_block = value;
+    } else if (k == "reserve_cus") {
+        if (value < -1 || value >= c->num_cus) return fail("reserve_cus must be -1 (auto) or 0..%d", c->num_cus - 1);
+        c->reserve_cus = value;
     } else if (k == "tree") {
         if (value != 0 && value != 1) return fail("tree must be 0 (LBVH) or 1 (SAH)");
         if (value != c->tree_kind) { c->tree_kind = value; c->tree_valid = false; }
@@ -306,6 +309,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "cur_div") *value = c->cur_div;
     else if (k == "last_kernel") *value = c->last_kernel;
     else if (k == "num_cus") *value = c->num_cus;
+    else if (k == "reserve_cus") *value = c->reserve_cus;
     else if (k == "nranks") *value = c->nranks;
     else if (k == "rank") *value = c->rank;
     else if (k == "device") *value = c->device;
@@ -686,10 +690,18 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         HIP_TRY(hipStreamWaitEvent(rs, c->ev_sobol2[k], 0));
         HIP_TRY(hipStreamWaitEvent(rs, c->ev_free[k], 0));   // combine of the batch that last used partial[k]
     }
+    // Persistent workgroups hold their CUs for a whole launch, and G launches keep every CU taken all the
+    // time: a foreign kernel -- RCCL's send/recv kernel of the film gather -- then waits for a launch to end
+    // (measured with mpt_probe_kernel on MI355X: median 0.47 ms, up to 2.2 ms beside a 1/8 share's launches,
+    // 4.2 ms beside whole-film launches, against 11 us on an idle GPU).  With a communicator of more than one
+    // rank a few CUs are therefore left unclaimed (option "reserve_cus"; -1 = 2 with a communicator, else 0).
+    const int reserve = c->reserve_cus >= 0 ? c->reserve_cus : ((c->comm && c->nranks > 1) ? 2 : 0);
+    const int usable_cus = std::max(c->num_cus - reserve, 1);
+    const int launch_cus = std::max(usable_cus / std::max(c->cur_div, 1), 1);   // G launches never claim more than usable_cus
     p.timeline = nullptr;
     if (c->timeline && lds_kernel) {
         const int block = c->lds_block ? c->lds_block : 1024;
-        const int waves = ((c->num_cus + c->cur_div - 1) / c->cur_div) * (block / 64);
+        const int waves = launch_cus * (block / 64);
         if (waves != c->timeline_waves) {
             HIP_TRY(hipDeviceSynchronize());
             hipFree(c->d_timeline); c->d_timeline = nullptr;
@@ -701,8 +713,8 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(hipEventRecord(e0, rs));
     if (!fast) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, rs));
-    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, (c->num_cus + c->cur_div - 1) / c->cur_div, c->lds_block ? c->lds_block : 1024, lds_bytes, c->count, rs));
-    else HIP_TRY(mpt_launch_render_fast(&p, (c->num_cus + c->cur_div - 1) / c->cur_div, stack, c->count, rs));
+    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, launch_cus, c->lds_block ? c->lds_block : 1024, lds_bytes, c->count, rs));
+    else HIP_TRY(mpt_launch_render_fast(&p, launch_cus, stack, c->count, rs));
     c->last_kernel = lds_kernel ? 1 : 0;
     HIP_TRY(hipEventRecord(e1, rs));
     c->events.push_back({ e0, e1 });

@@ -390,11 +390,14 @@ def probe(name='s978', spp=32, n=512, world=8, rounds=40):
     wall time until it completes, against the same probe on an idle GPU.'''
     import ctypes as C
     res = {}
-    for share, label in (((16, 0, world), f'1/{world} share (G launches overlapped)'), (None, 'whole film')):
+    for share, label, reserve in (((16, 0, world), f'1/{world} share (G launches overlapped)', 0),
+                                  ((16, 0, world), f'1/{world} share, 2 CUs reserved', 2),
+                                  (None, 'whole film', 0), (None, 'whole film, 2 CUs reserved', 2)):
         common.reset_all()
         eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
         c = ctx()
         c.set_option('batch', spp)
+        c.set_option('reserve_cus', reserve)
         if share:
             c.call('mpt_set_stripes', *share)
         us = C.c_double(0)
