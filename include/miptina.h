@@ -83,8 +83,8 @@ void mpt_destroy(mpt_ctx *ctx);
  * walks the LBVH itself), "grid_div" (each launch takes 1/G of the CUs so that G launches are resident
  * in different phases; 0 = choose by samples per lane, default), "pipe_depth" (batches in flight,
  * 2..6; 0 = auto), "lds_block" (lanes per persistent workgroup of the LDS kernel, diagnostics),
- * "timeline" (1 = record mpt_get_timeline data), "reserve_cus" (CUs the persistent render workgroups leave
- * free for foreign kernels such as RCCL's; -1 = 2 when a communicator of more than one rank exists, else 0).
+ * "timeline" (1 = record mpt_get_timeline data), "reserve_cus" (CUs every persistent render launch leaves
+ * unclaimed, default 0; measured to be of no use to foreign kernels while launches overlap, kept for experiments).
  * read-only: "tree_depth", "fast_depth", "pending", "last_kernel" (1 = LDS-resident), "num_cus",
  * "cur_div", "cur_depth" (what the last launch used) */
 int mpt_set_option(mpt_ctx *ctx, const char *key, int value);

@@ -265,7 +265,7 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
             return fail("lds_block must be 0 (auto), 256, 512, 768 or 1024");
         c->lds_block = value;
     } else if (k == "reserve_cus") {
-        if (value < -1 || value >= c->num_cus) return fail("reserve_cus must be -1 (auto) or 0..%d", c->num_cus - 1);
+        if (value < 0 || value >= c->num_cus) return fail("reserve_cus must be in 0..%d", c->num_cus - 1);
         c->reserve_cus = value;
     } else if (k == "tree") {
         if (value != 0 && value != 1) return fail("tree must be 0 (LBVH) or 1 (SAH)");
@@ -690,12 +690,15 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         HIP_TRY(hipStreamWaitEvent(rs, c->ev_sobol2[k], 0));
         HIP_TRY(hipStreamWaitEvent(rs, c->ev_free[k], 0));   // combine of the batch that last used partial[k]
     }
-    // Persistent workgroups hold their CUs for a whole launch, and G launches keep every CU taken all the
-    // time: a foreign kernel -- RCCL's send/recv kernel of the film gather -- then waits for a launch to end
-    // (measured with mpt_probe_kernel on MI355X: median 0.47 ms, up to 2.2 ms beside a 1/8 share's launches,
-    // 4.2 ms beside whole-film launches, against 11 us on an idle GPU).  With a communicator of more than one
-    // rank a few CUs are therefore left unclaimed (option "reserve_cus"; -1 = 2 with a communicator, else 0).
-    const int reserve = c->reserve_cus >= 0 ? c->reserve_cus : ((c->comm && c->nranks > 1) ? 2 : 0);
+    // Persistent workgroups hold their CUs for a whole launch, and the launches of the ring keep every CU taken
+    // all the time: a foreign kernel -- RCCL's send/recv kernel of the film gather -- waits for a launch to end
+    // (measured with mpt_probe_kernel on MI355X: median 0.13-0.47 ms, up to 2.2 ms beside a 1/8 share's launches,
+    // 4.2 ms beside whole-film launches, against 12 us on an idle GPU).  Leaving CUs out of every launch does NOT
+    // change that while launches overlap -- the workgroups of the next launch in the ring take any free CU at
+    // once (same waits measured with 2 CUs left out) -- so "reserve_cus" defaults to 0 and the gather of batch i
+    // simply completes one launch late; nothing waits for it but the read-back, and a step that ends with a
+    // read-back (bench.py's `value`) has no other launch in flight when its gather starts.
+    const int reserve = std::max(c->reserve_cus, 0);
     const int usable_cus = std::max(c->num_cus - reserve, 1);
     const int launch_cus = std::max(usable_cus / std::max(c->cur_div, 1), 1);   // G launches never claim more than usable_cus
     p.timeline = nullptr;

@@ -137,7 +137,7 @@ struct mpt_ctx {
     hipStream_t aux = nullptr;                        // Sobol advances + queue resets of the pipelined batches
     hipEvent_t ev_sobol2[MPT_MAX_PIPE] = {};          // Sobol points + zeroed queue heads of the batch on rstream[k] ready
     int pipe_depth = 0;                               // batches in flight (slots of P / partial / queue heads); 0 = auto
-    int reserve_cus = -1;                             // CUs no persistent workgroup claims; -1 = auto (2 with a communicator)
+    int reserve_cus = 0;                              // CUs no persistent workgroup claims (experiments: see mpt_flush)
     int grid_div = 0;                                 // each launch takes 1/grid_div of the CUs; 0 = auto
     int cur_depth = 2, cur_div = 1;                   // what the last launch used
     hipEvent_t ev_main = nullptr;                     // main-stream work a render must see (uploads, resets, ...)

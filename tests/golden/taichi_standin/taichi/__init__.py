@@ -257,6 +257,13 @@ class Matrix:
     def __rtruediv__(self, o): return self._bin(o, lambda a, b: a / b, True)
     def __pow__(self, o): return self._bin(o, lambda a, b: a ** b)
     def __mod__(self, o): return self._bin(o, lambda a, b: a % b)
+    def __floordiv__(self, o): return self._bin(o, lambda a, b: a // b)
+    def __and__(self, o): return self._bin(o, lambda a, b: a & b)
+    def __rand__(self, o): return self._bin(o, lambda a, b: a & b, True)
+    def __or__(self, o): return self._bin(o, lambda a, b: a | b)
+    def __xor__(self, o): return self._bin(o, lambda a, b: a ^ b)
+    def __lshift__(self, o): return self._bin(o, lambda a, b: a << b)
+    def __rshift__(self, o): return self._bin(o, lambda a, b: a >> b)
     def __neg__(self): return Matrix([-a for a in self.entries], self.n, self.m)
     def __pos__(self): return self
     def __abs__(self): return Matrix([abs(a) for a in self.entries], self.n, self.m)
@@ -336,16 +343,242 @@ def Vector(xs, *a, **k):
 
 
 Vector.unit = lambda n, i: Matrix.unit(n, i)
-Vector.field = Matrix.field = lambda *a, **k: field()
 
 
-class _Field:
-    def __getattr__(self, name):
-        raise RuntimeError('Taichi fields have no stand-in (L1 functions only)')
+# ---------------------------------------------------------------- integers with Taichi's i32 behaviour
+class I32(int):
+    """a Python int that wraps like Taichi's default integer (i32) under arithmetic.  Being an int
+    subclass it stays "weak" for numpy: np.float32 * I32 is float32, as f32 * i32 is in Taichi."""
+    __slots__ = ()
+
+    @staticmethod
+    def wrap(v):
+        v = int(v) & 0xFFFFFFFF
+        return v - (1 << 32) if v & 0x80000000 else v
+
+    def __new__(cls, v=0):
+        return int.__new__(cls, I32.wrap(v))
 
 
-def field(*a, **k):
-    return _Field()
+def _i32_bin(name, f, int_result=True):
+    def op(a, b):
+        if isinstance(b, Matrix):
+            return NotImplemented
+        if isinstance(b, (int, np.integer)):
+            r = f(int(a), int(b))
+            return I32(r) if int_result else r
+        return f(int(a), b)                     # a float operand: the plain int is "weak" for numpy
+
+    def rop(a, b):
+        if isinstance(b, (int, np.integer)):
+            r = f(int(b), int(a))
+            return I32(r) if int_result else r
+        return f(b, int(a))
+    setattr(I32, '__%s__' % name, op)
+    setattr(I32, '__r%s__' % name, rop)
+
+
+I32.__array_ufunc__ = None                      # numpy scalars defer to the reflected operators below
+for _n, _f in (('add', lambda a, b: a + b), ('sub', lambda a, b: a - b), ('mul', lambda a, b: a * b),
+               ('and', lambda a, b: a & b), ('or', lambda a, b: a | b), ('xor', lambda a, b: a ^ b),
+               ('lshift', lambda a, b: a << b), ('rshift', lambda a, b: a >> b),
+               ('floordiv', lambda a, b: a // b), ('mod', lambda a, b: a % b)):
+    _i32_bin(_n, _f)
+_i32_bin('truediv', lambda a, b: a / b, int_result=False)
+_i32_bin('pow', lambda a, b: a ** b, int_result=False)
+for _n, _f in (('lt', lambda a, b: a < b), ('le', lambda a, b: a <= b), ('gt', lambda a, b: a > b),
+               ('ge', lambda a, b: a >= b), ('eq', lambda a, b: a == b), ('ne', lambda a, b: a != b)):
+    setattr(I32, '__%s__' % _n, (lambda f: lambda a, b: NotImplemented if isinstance(b, Matrix) else bool(f(int(a), b)))(_f))
+I32.__hash__ = lambda a: hash(int(a))
+I32.__neg__ = lambda a: I32(-int(a))
+I32.__pos__ = lambda a: a
+I32.__invert__ = lambda a: I32(~int(a))
+I32.__abs__ = lambda a: I32(abs(int(a)))
+
+
+def ti_int(x):
+    """kernel-scope int(): element-wise cast to i32 (u32 values keep their bit pattern)"""
+    if isinstance(x, Matrix):
+        return Matrix([ti_int(e) for e in x.entries], x.n, x.m)
+    if isinstance(x, (np.floating, float)):
+        return I32(int(x))                     # truncation toward zero
+    return I32(int(x))
+
+
+def ti_float(x):
+    """kernel-scope float(): element-wise cast to the default float type"""
+    if isinstance(x, Matrix):
+        return Matrix([ti_float(e) for e in x.entries], x.n, x.m)
+    return _fp[0](x)
+
+
+def atomic_max(a, b):
+    old = Matrix(a) if isinstance(a, Matrix) else a
+    if isinstance(a, Matrix):
+        B = b.entries if isinstance(b, Matrix) else [b] * len(a.entries)
+        for k, e in enumerate(B):
+            a.entries[k] = a.entries[k] if a.entries[k] > e else e
+        return old
+    raise RuntimeError('atomic on a Python scalar local has no stand-in')
+
+
+def atomic_min(a, b):
+    old = Matrix(a) if isinstance(a, Matrix) else a
+    if isinstance(a, Matrix):
+        B = b.entries if isinstance(b, Matrix) else [b] * len(a.entries)
+        for k, e in enumerate(B):
+            a.entries[k] = a.entries[k] if a.entries[k] < e else e
+        return old
+    raise RuntimeError('atomic on a Python scalar local has no stand-in')
+
+
+def ndrange(*dims):
+    import itertools
+    return itertools.product(*[range(int(d)) if not isinstance(d, tuple) else range(int(d[0]), int(d[1])) for d in dims])
+
+
+def grouped(x):
+    raise RuntimeError('ti.grouped has no stand-in')
+
+
+# ---------------------------------------------------------------- fields (numpy storage)
+def _np_dtype(dt):
+    if dt in (int, i32):
+        return np.int32
+    if dt is float:
+        return _fp[0]
+    return dt
+
+
+def _wrap_scalar(v, dtype):
+    if np.issubdtype(dtype, np.integer):
+        return I32(int(v))
+    return dtype(v)
+
+
+class ScalarField:
+    def __init__(self, dtype, shape=None):
+        self.dtype = _np_dtype(dtype)
+        self.data = None
+        if shape is not None:
+            self._alloc(shape)
+
+    def _alloc(self, shape):
+        if isinstance(shape, (int, np.integer)):
+            shape = (int(shape),)
+        self.shape = tuple(int(d) for d in shape)
+        self.data = np.zeros(self.shape, self.dtype)
+
+    @staticmethod
+    def _ix(i):
+        if i is None:
+            return ()
+        if isinstance(i, Matrix):
+            return tuple(int(e) for e in i.entries)
+        if isinstance(i, tuple):
+            return tuple(int(e) for e in i)
+        return (int(i),)
+
+    def __getitem__(self, i):
+        return _wrap_scalar(self.data[self._ix(i)], self.dtype)
+
+    def __setitem__(self, i, v):
+        if np.issubdtype(self.dtype, np.integer):
+            v = I32.wrap(int(v))
+        self.data[self._ix(i)] = v
+
+    def fill(self, v):
+        self.data[...] = v
+
+    def from_numpy(self, a):
+        a = np.asarray(a)
+        if np.issubdtype(self.dtype, np.integer):
+            a = (a.astype(np.int64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(a.shape)
+        self.data[tuple(slice(0, d) for d in a.shape)] = a
+
+    def to_numpy(self):
+        return self.data.copy()
+
+
+class FieldMatrix(Matrix):
+    """the value of a vector / matrix field element: reads are plain entries, item and attribute
+    assignment writes through to the field (in Taichi a field subscript is an lvalue)"""
+
+    def __init__(self, field, ix):
+        vals = [_wrap_scalar(v, field.dtype) for v in field.data[ix].reshape(-1)]
+        Matrix.__init__(self, vals, field.n, field.m)
+        object.__setattr__(self, '_field', field)
+        object.__setattr__(self, '_ix', ix)
+
+    def __setitem__(self, i, v):
+        Matrix.__setitem__(self, i, v)
+        self._field.data[self._ix] = np.array(self.entries, self._field.dtype).reshape(self._field.data[self._ix].shape)
+
+
+def _fm_set(k):
+    def setter(self, v):
+        self[k] = v
+    return setter
+
+
+for _k, _nm in enumerate('xyzw'):
+    setattr(FieldMatrix, _nm, property(lambda s, _k=_k: s.entries[_k], _fm_set(_k)))
+
+
+class MatrixField:
+    def __init__(self, n, m, dtype, shape):
+        self.n, self.m = n, m
+        self.dtype = _np_dtype(dtype)
+        if isinstance(shape, (int, np.integer)):
+            shape = (int(shape),)
+        self.shape = tuple(int(d) for d in shape)
+        self.data = np.zeros(self.shape + ((n,) if m == 1 else (n, m)), self.dtype)
+
+    def __getitem__(self, i):
+        return FieldMatrix(self, ScalarField._ix(i))
+
+    def __setitem__(self, i, v):
+        if isinstance(v, Matrix):
+            v = [e for e in v.entries]
+        a = np.array(v, dtype=np.float64 if not np.issubdtype(self.dtype, np.integer) else np.int64)
+        self.data[ScalarField._ix(i)] = a.reshape(self.data[ScalarField._ix(i)].shape).astype(self.dtype)
+
+    def fill(self, v):
+        self.data[...] = v
+
+    def from_numpy(self, a):
+        a = np.asarray(a)
+        self.data[tuple(slice(0, d) for d in a.shape)] = a
+
+    def to_numpy(self):
+        return self.data.copy()
+
+
+def field(dtype, shape=None, **k):
+    return ScalarField(dtype, shape)
+
+
+Vector.field = lambda n, dtype, shape=None, **k: MatrixField(n, 1, dtype, shape)
+Matrix.field = staticmethod(lambda n, m, dtype, shape=None, **k: MatrixField(n, m, dtype, shape))
+
+
+class _SNode:
+    def __init__(self, dims=()):
+        self.dims = dims
+
+    def dense(self, axes, n):
+        n = n if isinstance(n, (tuple, list)) else (n,)
+        return _SNode(self.dims + tuple(int(x) for x in n))
+
+    def place(self, *fields):
+        for f in fields:
+            f._alloc(self.dims)
+
+
+root = _SNode()
+i, j, k, l = 'i', 'j', 'k', 'l'
+ij, ijk = 'ij', 'ijk'
+cfg = types.SimpleNamespace(arch=cuda, cpu_max_num_threads=8)
 
 
 # taichi.lang.common_ops.TaichiOperations: the reference adds __pos__ to it at import
