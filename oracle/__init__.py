@@ -105,6 +105,7 @@ def load(f64=False):
     sig('orc_get_image', None, vp, C.c_int, fp)
     sig('orc_fast_export_image', None, vp, C.c_int, fp)
     sig('orc_get_film_raw', None, vp, C.c_int, fp)
+    sig('orc_get_film_real', None, vp, C.c_int, rp)
     sig('orc_get_counters', None, vp, C.POINTER(Counters))
     sig('orc_reset_counters', None, vp)
     sig('orc_trace_pixel', None, vp, C.c_int, C.c_int, rp)
@@ -304,6 +305,12 @@ class Oracle:
     def get_film_raw(self, id=0):
         out = np.empty((self.nx * self.ny, 4), np.float32)
         self.lib.orc_get_film_raw(self.ctx, id, _ptr(out, C.c_float))
+        return out
+
+    def get_film_real(self, id=0):
+        '''raw sums in the build's own precision'''
+        out = np.zeros((self.nx * self.ny, 4), self.npreal)
+        self.lib.orc_get_film_real(self.ctx, id, _ptr(out, self.real))
         return out
 
     def counters(self):

@@ -1465,6 +1465,14 @@ void orc_get_film_raw(orc_ctx *c, int pass, float *out) {
     }
 }
 
+/* the sums in the build's own precision (the f64 build's film is not rounded to f32 on the way out) */
+void orc_get_film_real(orc_ctx *c, int pass, real *out) {
+    for (size_t t = 0; t < (size_t)c->nx * c->ny; t++) {
+        out[t * 4 + 0] = c->film[pass][t].x; out[t * 4 + 1] = c->film[pass][t].y;
+        out[t * 4 + 2] = c->film[pass][t].z; out[t * 4 + 3] = c->film[pass][t].w;
+    }
+}
+
 void orc_get_counters(orc_ctx *c, orc_counters *out) { *out = c->cnt; }
 void orc_reset_counters(orc_ctx *c) { memset(&c->cnt, 0, sizeof c->cnt); }
 

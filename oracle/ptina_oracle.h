@@ -121,6 +121,7 @@ void orc_clear(orc_ctx *c);                            /* filmtable.py:44-45 (al
 void orc_get_image(orc_ctx *c, int pass, float *out /*[nx][ny][4]*/);  /* filmtable.py:47-63 */
 void orc_fast_export_image(orc_ctx *c, int pass, float *out /*[ny*nx*3]*/); /* filmtable.py:66-79 */
 void orc_get_film_raw(orc_ctx *c, int pass, float *out /*[nx*ny][4]*/);
+void orc_get_film_real(orc_ctx *c, int pass, orc_real *out /*[nx*ny][4]*/);   /* in the build's own precision */
 void orc_get_counters(orc_ctx *c, orc_counters *out);
 void orc_reset_counters(orc_ctx *c);
 

@@ -378,7 +378,12 @@ def _i32_bin(name, f, int_result=True):
     setattr(I32, '__r%s__' % name, rop)
 
 
-I32.__array_ufunc__ = None                      # numpy scalars defer to the reflected operators below
+def _i32_ufunc(self, ufunc, method, *inputs, **kw):
+    # numpy sees a plain Python int ("weak": f32 * i32 stays f32, as in Taichi)
+    return getattr(ufunc, method)(*[int(x) if isinstance(x, I32) else x for x in inputs], **kw)
+
+
+I32.__array_ufunc__ = _i32_ufunc
 for _n, _f in (('add', lambda a, b: a + b), ('sub', lambda a, b: a - b), ('mul', lambda a, b: a * b),
                ('and', lambda a, b: a & b), ('or', lambda a, b: a | b), ('xor', lambda a, b: a ^ b),
                ('lshift', lambda a, b: a << b), ('rshift', lambda a, b: a >> b),
@@ -443,9 +448,9 @@ def grouped(x):
 
 # ---------------------------------------------------------------- fields (numpy storage)
 def _np_dtype(dt):
-    if dt in (int, i32):
+    if dt in (int, i32, ti_int):      # `int` inside the reference's modules may be the kernel-scope cast
         return np.int32
-    if dt is float:
+    if dt in (float, ti_float):
         return _fp[0]
     return dt
 
