@@ -77,8 +77,7 @@ void mpt_destroy(mpt_ctx *ctx);
  * 0 = auto), "count" (1 = accumulate mpt_counters, slower), "lds" (1 = use the LDS-resident
  * persistent kernel when the scene fits a CU's 160 KiB LDS, default; 0 = always gather from HBM/L2).
  * "tree" (fast build: 1 = SAH re-partition of the LBVH's leaves, default; 0 = walk the LBVH itself;
- * takes effect at the next mpt_build_tree), "sched_num"/"sched_den" (leave traversal mode when
- * traversing*num < waiting*den), "tile_w_shift"/"tile_h_shift" (work-item tile 2^w x 2^h pixels),
+ * takes effect at the next mpt_build_tree), "tile_w_shift"/"tile_h_shift" (work-item tile 2^w x 2^h pixels),
  * "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
  * walks the LBVH itself), "grid_div" (each launch takes 1/G of the CUs so that G launches are resident
  * in different phases; 0 = choose by samples per lane, default), "pipe_depth" (batches in flight,

@@ -277,12 +277,6 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         if ((value ? 1 : 0) != c->gpu_build) { c->gpu_build = value ? 1 : 0; c->tree_valid = false; }
     } else if (k == "sah_max") {
         c->sah_max = value; c->tree_valid = false;
-    } else if (k == "sched_num") {
-        if (value < 1) return fail("sched_num must be >= 1");
-        c->sched_num = value;
-    } else if (k == "sched_den") {
-        if (value < 0) return fail("sched_den must be >= 0");
-        c->sched_den = value;
     } else {
         return fail("unknown option '%s'", k.c_str());
     }
@@ -656,19 +650,17 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     if (fast) {
         chunk = c->chunk;
         if (chunk <= 0) {
-            // work items are (8x8 tile, chunk of frames); persistent waves refill from the queue as
-            // soon as their pool drains, so small items cost nothing and balance best: aim for
-            // ~16 items per resident wave
-            int want_items = 16 * 16 * c->num_cus;
-            int want = (want_items + tiles8 - 1) / std::max(tiles8, 1);
-            want = std::max(1, std::min(want, B));
-            chunk = std::max((B + want - 1) / want, 1);
+            // Work items are (8x8 tile, chunk of frames).  Persistent waves refill from the queue the moment their
+            // pool drains, so small items cost one returning atomic each and nothing else, and the launch ends
+            // with what the last items hold: one frame of a tile (64 samples = one generation of paths per wave)
+            // measured best on MI355X -- 512x512x32: 4.56 ms per launch against 4.67 (2 frames) and 5.07 (4);
+            // 32-sample items (8x4 tiles) lose again (4.70) because a wave then starts half empty.
+            chunk = 1;
         }
         chunk = std::min(chunk, B);
         nchunks = (B + chunk - 1) / chunk;
     }
     p.chunk = chunk; p.nchunks = nchunks;
-    p.sched_num = c->sched_num; p.sched_den = c->sched_den;
     p.nitems = tiles8 * nchunks;
     p.tile_w_shift = c->tile_w_shift; p.tile_h_shift = c->tile_h_shift;
     if (fast) {

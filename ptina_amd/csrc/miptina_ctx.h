@@ -71,7 +71,6 @@ struct mpt_ctx {
     int num_cus = 256;
     int clock_khz = 0;                   // hipDeviceProp_t.clockRate: peak shader clock (roofline peaks in bench.py)
     int tile_w_shift = 3, tile_h_shift = 3;   // work-item tile 2^w x 2^h pixels
-    int sched_num = 2, sched_den = 1;    // scheduler: stay in traversal mode while traversing*num >= waiting*den (tuned on MI355X)
     int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
 
     // film

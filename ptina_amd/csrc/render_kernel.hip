@@ -198,9 +198,11 @@ struct LaneState {
     // ray being traversed (closest: the path ray; shadow: hitpos -> light)
     V3 to, td, inv, oinv;
     float tbest;               // closest: best depth so far; shadow: li.dis
-    int curr, sp, hidx;
+    int curr, sp, hidx;        // hidx: leaf slot of the hit so far, -1 = none (closest) / any occluder found (shadow)
     float hu, hv;
-    bool shadow, hit;
+    int shadow;                // 1: the ray in flight is a shadow ray.  An int in a VGPR on purpose: as a bool the
+                               // compiler keeps it in a scalar lane mask and re-merges that mask (s_andn2 / s_and /
+                               // s_or) around every divergent region of the traversal loop
 };
 
 DEV Rng lane_rng(const MptRenderParams &p, const LaneState &L) {
@@ -244,7 +246,7 @@ DEV void lane_start_ray(LaneState &L, STACK &stk, V3 o, V3 d, float tmax, bool s
     L.to = o; L.td = d;
     L.inv = v3(m_rcp(d.x), m_rcp(d.y), m_rcp(d.z));
     L.oinv = o * L.inv;
-    L.tbest = tmax; L.shadow = shadow; L.hit = false; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f;
+    L.tbest = tmax; L.shadow = shadow ? 1 : 0; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f;
     stk.sp = 0;
     stk.push(STACK::SENTINEL);
     L.curr = 0; L.sp = 1;
@@ -310,9 +312,9 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     float dd, su, sv;
     if (tri_test(g0, g1, g2, g3, L.to, L.td, &dd, &su, &sv)) {
         if (L.shadow) {
-            if (dd <= L.tbest) { L.hit = true; stop = true; }               // path.py:51: any occluder within li.dis
+            if (dd <= L.tbest) { L.hidx = slot; stop = true; }              // path.py:51: any occluder within li.dis
         } else if (dd < L.tbest) {                                          // lbvh.py:331
-            L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv; L.hit = true;
+            L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv;
         }
     }
     stk.sp = L.sp;
@@ -326,22 +328,23 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
 // then the next bounce starts from hitpos (= the shadow ray's origin), path.py:60
 template <bool COUNT, class STACK>
 DEV void stage_shadow_done(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cnt) {
-    if (!L.hit) L.result = L.result + L.direct;
+    if (L.hidx < 0) L.result = L.result + L.direct;
     lane_next_bounce<COUNT>(p, L, stk, L.to, cnt);
 }
 
 // path.py:31-62 for one bounce.  On entry L.to / L.prd are the path ray r.o / r.d and
-// (L.hit, L.tbest, L.hidx, L.hu, L.hv) the closest hit.
+// (L.hidx >= 0, L.tbest, L.hidx, L.hu, L.hv) the closest hit.
 template <bool COUNT, class STACK>
 DEV void stage_shade(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cnt) {
     V3 ro = L.to, rd = L.prd;
-    float hdepth = L.hit ? L.tbest : MPT_INF;
+    const bool was_hit = L.hidx >= 0;
+    float hdepth = was_hit ? L.tbest : MPT_INF;
     LightHit lit = lights_hit(p, ro, rd);
-    if (lit.hit && (!L.hit || lit.dis < hdepth)) {
+    if (lit.hit && (!was_hit || lit.dis < hdepth)) {
         float mis = power_heuristic(L.last_brdf_pdf, lit.pdf);
         L.result = L.result + L.throughput * (lit.color * mis);
     }
-    if (!L.hit) {
+    if (!was_hit) {
         L.result = L.result + L.throughput * world_at(p, rd);
         L.depth = 5;                                                         // break, path.py:39
         lane_next_bounce<COUNT>(p, L, stk, ro, cnt);
@@ -433,7 +436,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     bool more = true;
     LaneState L;
     L.st = ST_NEW;
-    L.sp = 0; L.curr = 0; L.hit = false; L.shadow = false;
+    L.sp = 0; L.curr = 0; L.shadow = 0;
     L.result = v3s(0.0f); L.throughput = v3s(0.0f); L.prd = v3s(0.0f); L.direct = v3s(0.0f);
     L.to = v3s(0.0f); L.td = v3s(0.0f); L.inv = v3s(0.0f); L.oinv = v3s(0.0f);
     L.tbest = 0.0f; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f; L.last_brdf_pdf = 0.0f;
@@ -451,7 +454,9 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             int cn = wave_count(L.st == ST_NODE);
             int cl = wave_count(L.st == ST_LEAF);
             int cw = wave_count(L.st == ST_DONE || L.st == ST_NEW);
-            if (cn + cl == 0 || (cn + cl) * p.sched_num < cw * p.sched_den) break;
+            // leave when the waiting lanes outnumber the traversing ones 2 : 1 (best of the ratios tried on MI355X;
+            // a compile-time constant: as a launch parameter it cost two s_mul and two SGPRs in this loop)
+            if (cn + cl == 0 || (cn + cl) * 2 < cw) break;
             if (cn >= cl) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
                 if (L.st == ST_NODE) stage_node<COUNT>(sc, stk, L, cnt);

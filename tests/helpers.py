@@ -17,7 +17,7 @@ def setup_engine(scene, nx, ny, mode='fast', camera=scenes.BENCH_CAMERA, lights=
     eng = PathEngine()
     ctx().set_option('mode', _lib.MODE_STRICT if mode == 'strict' else _lib.MODE_FAST)
     import os
-    for key in ('sched_num', 'sched_den', 'lds'):                # experiment switches (tools/gpu_round.sh)
+    for key in ('lds',):                # experiment switches (tools/gpu_round.sh)
         if os.environ.get('MIPTINA_' + key.upper()):
             ctx().set_option(key, int(os.environ['MIPTINA_' + key.upper()]))
     FilmTable().set_size(nx, ny)

@@ -59,8 +59,6 @@ def timing(name, mode, chunk, steps=5, spp=32, n=512, lds=1, sched=(1, 1)):
     c.set_option('batch', spp)
     c.set_option('chunk', chunk)
     c.set_option('lds', lds)
-    c.set_option('sched_num', sched[0])
-    c.set_option('sched_den', sched[1])
     eng.render(spp)
     c.call('mpt_synchronize')
     c.kernel_time()
@@ -87,8 +85,6 @@ def ab(variants=((0, 2, 1), (0, 3, 2), (0, 1, 1)),
     res = {v: [] for v in variants}
     for r in range(rounds + 1):
         for v in variants:
-            c.set_option('sched_num', v[1])
-            c.set_option('sched_den', v[2])
             eng.render(spp)
             c.call('mpt_synchronize')
             ms, nl = c.kernel_time()
@@ -184,8 +180,6 @@ def util(name='s978', spp=32, n=512):
         eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
         c = ctx()
         c.set_option('batch', spp)
-        c.set_option('sched_num', sched[0])
-        c.set_option('sched_den', sched[1])
         c.set_option('count', 1)
         eng.render(spp)
         k = c.counters()
@@ -427,8 +421,43 @@ def probe(name='s978', spp=32, n=512, world=8, rounds=40):
     common.reset_all()
 
 
+def sync_sweep(name='s978', spp=32, n=512, steps=15):
+    '''the benchmark's step (32 x render + get_image, synchronous) under work-item granularities:
+    frames per item (chunk) and tile shape; ms per step and render-kernel ms'''
+    res = {}
+    variants = [('default', {})] + [(f'chunk={ch}', {'chunk': ch}) for ch in (1, 2, 4)] + \
+               [(f'chunk=1 tile={1 << w}x{1 << h}', {'chunk': 1, 'tile_w_shift': w, 'tile_h_shift': h}) for w, h in ((3, 2), (2, 2))] + \
+               [(f'tile={1 << w}x{1 << h}', {'tile_w_shift': w, 'tile_h_shift': h}) for w, h in ((3, 2), (2, 2))]
+    extra = [kv.split('=') for kv in filter(None, os.environ.get('MIPTINA_OPTS', '').split(','))]
+    for label, opts in variants:
+        common.reset_all()
+        eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
+        c = ctx()
+        c.set_option('batch', spp)
+        for k, v in list(opts.items()) + [(k, int(v)) for k, v in extra]:
+            c.set_option(k, v)
+        for _ in range(3):
+            eng.render(spp)
+            FilmTable().get_image()
+        c.kernel_time()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.render(spp)
+            FilmTable().get_image()
+        dt = (time.perf_counter() - t0) / steps
+        kms, nl = c.kernel_time()
+        res[label] = {'ms_per_step': round(dt * 1e3, 4), 'kernel_ms': round(kms / max(nl, 1), 4),
+                      'msamples_s': round(n * n * spp / dt / 1e6, 1)}
+        print('sync_sweep', label, res[label], flush=True)
+    out['sync_sweep'] = res
+    save()
+    common.reset_all()
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'sync_sweep' in what:
+        sync_sweep()
     if 'probe' in what:
         probe()
     if 'c5sah' in what:

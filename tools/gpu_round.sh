@@ -32,10 +32,15 @@ for step in "$@"; do
     configs)     run configs 600 python tools/run_configs.py ;;
     c5sah)       run c5sah 600 python tools/gpu_diag.py c5sah ;;
     probe)       run probe 300 python tools/gpu_diag.py probe ;;
+    sync_sweep)  run sync_sweep 300 python tools/gpu_diag.py sync_sweep ;;
     ubench)      run ubench 200 tools/microbench/valu_microbench --json ;;
     ubench_pmc)  run ubench_pmc 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/ubench_pmc -- tools/microbench/valu_microbench ;;
     bench_noslp) MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_noslp.so run bench_noslp 300 python bench.py --no-pmc --no-cpu-baseline ;;
     bench_quick) run bench_quick 300 python bench.py --no-pmc --no-cpu-baseline ;;
+    bench_ab)    MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_ab.so run bench_ab 300 python bench.py --no-pmc --no-cpu-baseline ;;
+    bench_ab2)   MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_ab2.so run bench_ab2 300 python bench.py --no-pmc --no-cpu-baseline ;;
+    bench_ab3)   MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_ab3.so run bench_ab3 300 python bench.py --no-pmc --no-cpu-baseline ;;
+    tests_fast)  run tests_fast 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'fast_build or strict_build or full_size or batching or pipelining or lds_and_gather or lobes or ordered' ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
     tests_all)   run tests_all 900 python -m pytest tests -m gpu -q ;;
     bench)       run bench 600 python bench.py ;;
