@@ -31,7 +31,7 @@ __device__ __forceinline__ float construct_float(int i) {
 
 __global__ __launch_bounds__(256) void sobol_update_kernel(int *__restrict__ X, const int *__restrict__ V,
                                                            float *__restrict__ P, int dim, int rows, int time0,
-                                                           int count, int pstride_frames) {
+                                                           int count, int pstride_frames, int write_x) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= dim) return;
     int x = X[j];
@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void sobol_update_kernel(int *__restrict__ X, 
         // (reset's skipped updates never read P)
         if (f >= count - pstride_frames) P[(size_t)(f - (count - pstride_frames)) * dim + j] = construct_float(x);
     }
-    X[j] = x;
+    // write_x = 0: the points of the NEXT batch computed ahead of time; the state moves when that batch is launched
+    if (write_x) X[j] = x;
 }
 
 // film[pix] += sample[0][pix], then sample[1][pix], ... : the reference's frame-by-frame
@@ -111,9 +112,9 @@ MPT_KERNEL_API hipError_t mpt_launch_probe(double *out, int threads, size_t lds_
 }
 
 MPT_KERNEL_API hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0,
-                                              int count, int keep, hipStream_t stream) {
+                                              int count, int keep, int write_x, hipStream_t stream) {
     int grid = (dim + 255) / 256;
-    hipLaunchKernelGGL(sobol_update_kernel, dim3(grid), dim3(256), 0, stream, X, V, P, dim, rows, time0, count, keep);
+    hipLaunchKernelGGL(sobol_update_kernel, dim3(grid), dim3(256), 0, stream, X, V, P, dim, rows, time0, count, keep, write_x);
     return hipGetLastError();
 }
 

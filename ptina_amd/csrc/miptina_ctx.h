@@ -25,7 +25,7 @@ MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *, int gri
 MPT_KERNEL_API hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
-                                              int keep, hipStream_t);
+                                              int keep, int write_x, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
                                          int stripe_w, int stripe_pitch,
                                          int nchunks, hipStream_t);
@@ -142,6 +142,11 @@ struct mpt_ctx {
     hipEvent_t ev_main = nullptr;                     // main-stream work a render must see (uploads, resets, ...)
     bool main_dirty = true;
     int flip = 0;
+    // Sobol points of the NEXT batch, computed ahead of time into the ring slot it will use (the sequence is
+    // deterministic): valid while nothing has touched the sampler or the ring since
+    bool spec_valid = false;
+    int spec_slot = -1, spec_B = 0;
+    int32_t spec_time = 0;
     MptVec4 *partial2[MPT_MAX_PIPE] = {};
     size_t partial2_cap[MPT_MAX_PIPE] = {};           // float4 elements per buffer
     float *sP2[MPT_MAX_PIPE] = {};

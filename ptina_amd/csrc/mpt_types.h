@@ -51,7 +51,8 @@ struct MptRenderParams {
     int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders
     int32_t nframes, chunk, nchunks, n;     // batch frames; frames per work item; items per tile; #triangles
     int32_t sobol_dim, nlights, world_tex, tiles_x;   // tiles_* : 16x16 tiles of the slab (strict build)
-    int32_t tiles_y, ntiles, pad0, pad1;
+    int32_t tiles_y, ntiles, pad0;
+    float sobol_inv_dim;                    // 1 / sobol_dim (quotient estimate of the draw index reduction)
     int32_t nitems, tile_w_shift, tile_h_shift, pad2;   // fast build: (2^w x 2^h tile, chunk) work items of this launch
     // columns rendered: x = x0 + s*stripe_pitch + w, w < stripe_w, x < x1 (one contiguous slab: stripe_w = 2^30)
     int32_t stripe_w, stripe_pitch, pad3, pad4;

@@ -191,7 +191,9 @@ struct LaneState {
     // path, path.py:19-23
     V3 result, throughput;
     float last_brdf_pdf;
-    int avoid, depth, rng_i;
+    int navoid, depth, rng_i;  // navoid: the id a node record holds for the triangle the ray left from (~slot; 0 = none:
+                               // id 0 is the root, which is nobody's child)
+    int rng_k;                 // rng_i reduced into [0, dim): the Sobol dimension of the lane's next draw
     int pix, frame;
     V3 prd;                    // closest ray: the path direction r.d; shadow ray: the NEXT bounce direction
     V3 direct;                 // shadow ray in flight: candidate direct light, added if unoccluded
@@ -209,28 +211,41 @@ DEV Rng lane_rng(const MptRenderParams &p, const LaneState &L) {
     Rng r; r.dim = p.sobol_dim; r.P = p.P + (size_t)L.frame * p.sobol_dim; r.i = L.rng_i; return r;
 }
 
+// Python's floor-mod of the proxy counter by the table size (sobol.py:123), without an integer division:
+// an estimate of the quotient from the float reciprocal, then the remainder is put right exactly
+DEV int reduce_mod_dim(int h, int dim, float inv_dim) {
+    int q = (int)floorf((float)h * inv_dim);                       // within +-1 of floor(h / dim)
+    int r = (int)((unsigned)h - (unsigned)q * (unsigned)dim);      // exact modulo 2^32, and the true remainder is small
+    if (r < 0) r += dim;
+    if (r < 0) r += dim;
+    if (r >= dim) r -= dim;
+    if (r >= dim) r -= dim;
+    return r;
+}
+
 // N consecutive draws of the lane's Sobol proxy (sobol.py:121-125).  The proxy's counter is an i32
 // that the reference reduces mod dim (floor-mod) at every draw; unless the counter is about to wrap
-// (probability ~N/2^32 per pixel) the N indices are k, k+1, ... with one wrap at dim, so one integer
-// division serves all of them.  The wrapping case takes the literal per-draw path.
+// (probability ~N/2^32 per pixel) the N indices are k, k+1, ... with one wrap at dim: the lane carries k
+// along with the counter, so a draw costs a load and a compare.  The wrapping case takes the literal path.
 template <int N>
 DEV void lane_draws(const MptRenderParams &p, LaneState &L, float *out) {
     const float *P = p.P + (size_t)L.frame * p.sobol_dim;
     const int dim = p.sobol_dim;
     if (L.rng_i <= 0x7fffffff - N) {
-        int k = L.rng_i % dim;
-        if (k < 0) k += dim;
+        int k = L.rng_k;
 #pragma unroll
         for (int t = 0; t < N; t++) {
             out[t] = P[k];
             k = (k + 1 == dim) ? 0 : k + 1;
         }
+        L.rng_k = k;
         L.rng_i += N;
     } else {
         Rng rng = lane_rng(p, L);
 #pragma unroll
         for (int t = 0; t < N; t++) out[t] = rng_random(rng);
         L.rng_i = rng.i;
+        L.rng_k = pymod(L.rng_i, dim);
     }
 }
 
@@ -289,8 +304,8 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     bool h0 = box_fast(a.x, b.x, c.x, a.z, b.z, c.z, L.inv, L.oinv, L.tbest, &tn0);
     bool h1 = box_fast(a.y, b.y, c.y, a.w, b.w, c.w, L.inv, L.oinv, L.tbest, &tn1);
     // a leaf that is the triangle the ray left from is never tested (lbvh.py:329)
-    h0 = h0 && (~id0 != L.avoid);
-    h1 = h1 && (~id1 != L.avoid);
+    h0 = h0 && (id0 != L.navoid);
+    h1 = h1 && (id1 != L.navoid);
     bool swap = tn1 < tn0;
     int nearid = swap ? id1 : id0, farid = swap ? id0 : id1;
     int next = h0 ? (h1 ? nearid : id0) : id1;
@@ -350,7 +365,7 @@ DEV void stage_shade(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cn
         lane_next_bounce<COUNT>(p, L, stk, ro, cnt);
         return;
     }
-    L.avoid = L.hidx;
+    L.navoid = ~L.hidx;
     Hit hit; hit.hit = 1; hit.depth = hdepth; hit.index = L.hidx; hit.u = L.hu; hit.v = L.hv;
     V3 hitpos, normal; Disney mat;
     get_geometries(p, hit, ro, rd, &hitpos, &normal, mat);
@@ -387,6 +402,7 @@ DEV void stage_shade(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cn
 template <bool COUNT, class STACK>
 DEV void lane_begin(const MptRenderParams &p, LaneState &L, STACK &stk, int i, int j, Cnt &cnt) {
     L.rng_i = wanghash2(i, j);                                               // path.py:72-73
+    L.rng_k = reduce_mod_dim(L.rng_i, p.sobol_dim, p.sobol_inv_dim);
     float jit[2];
     lane_draws<2>(p, L, jit);                                                // random2: dx then dy, path.py:87
     float dx = jit[0], dy = jit[1];
@@ -394,7 +410,7 @@ DEV void lane_begin(const MptRenderParams &p, LaneState &L, STACK &stk, int i, i
     float y = m_div((float)j + dy, (float)p.ny) * 2.0f - 1.0f;
     V3 ro;
     camera_generate(p, x, y, &ro, &L.prd);
-    L.avoid = -1; L.depth = 0;
+    L.navoid = 0; L.depth = 0;
     L.result = v3s(0.0f); L.throughput = v3s(1.0f); L.last_brdf_pdf = 0.0f;
     if (COUNT) { cnt.samples++; cnt.n_draws += 2; }
     lane_next_bounce<COUNT>(p, L, stk, ro, cnt);
@@ -440,7 +456,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     L.result = v3s(0.0f); L.throughput = v3s(0.0f); L.prd = v3s(0.0f); L.direct = v3s(0.0f);
     L.to = v3s(0.0f); L.td = v3s(0.0f); L.inv = v3s(0.0f); L.oinv = v3s(0.0f);
     L.tbest = 0.0f; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f; L.last_brdf_pdf = 0.0f;
-    L.avoid = -1; L.depth = 0; L.rng_i = 0; L.pix = 0; L.frame = 0;
+    L.navoid = 0; L.depth = 0; L.rng_i = 0; L.rng_k = 0; L.pix = 0; L.frame = 0;
     // Every pass of this loop retires at least one stage for at least one lane, so it ends when the
     // queues are empty.  The pass counter is a watchdog only: a scheduling bug must not be able to keep
     // a persistent wave (and with it the GPU) spinning -- the host turns the flag into an error.

@@ -40,6 +40,7 @@ for step in "$@"; do
     bench_ab)    MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_ab.so run bench_ab 300 python bench.py --no-pmc --no-cpu-baseline ;;
     bench_ab2)   MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_ab2.so run bench_ab2 300 python bench.py --no-pmc --no-cpu-baseline ;;
     bench_ab3)   MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_ab3.so run bench_ab3 300 python bench.py --no-pmc --no-cpu-baseline ;;
+    ablibs)      for L in $ABLIBS; do MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_$L.so run ab_$L 300 python bench.py --no-pmc --no-cpu-baseline; done ;;
     tests_fast)  run tests_fast 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'fast_build or strict_build or full_size or batching or pipelining or lds_and_gather or lobes or ordered' ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
     tests_all)   run tests_all 900 python -m pytest tests -m gpu -q ;;
