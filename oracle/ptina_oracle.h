@@ -6,10 +6,14 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * The product (ptina_amd) never links, imports or calls it.
  *
- * PARITY UNPINNED: the reference is Python + Taichi; Taichi is not installed in the
- * build container (ordinary ModuleNotFoundError) and the reference's own tests hold
- * no golden vectors for this path.  What IS pinned independently:
- * the Sobol sampler, against scipy's unscrambled Sobol points (tests/golden).
+ * PARITY: formally UNPINNED against real PTina output -- the reference is Python + Taichi, Taichi is
+ * not installed in the build container (ordinary ModuleNotFoundError) and the reference's own tests hold
+ * no golden vectors for this path.  What IS pinned:
+ *   - the restatement's LOGIC, to the reference's own source executed as plain Python on numpy scalars
+ *     (tests/golden/taichi_standin + make_reference_l1_golden.py / make_reference_path_golden.py; the
+ *     f64 build of this file reproduces the reference's functions and its end-to-end films to 1e-12);
+ *   - the Sobol sampler, against scipy's unscrambled Sobol points (tests/golden/sobol_points.npz).
+ * Not reproduced by anything here: Taichi's own code generation (fast-math, backend intrinsics).
  *
  * All citations are file:line into /root/reference.
  */

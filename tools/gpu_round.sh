@@ -47,14 +47,14 @@ for step in "$@"; do
     bench)       run bench 600 python bench.py ;;
     prof)        (cd /tmp; run_dir=$GRAFT_REPO_ROOT/gpurun_out/prof; rm -rf $run_dir; mkdir -p $run_dir;
                   cd $GRAFT_REPO_ROOT;
-                  run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline) ;;
+                  run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pmc) ;;
     slabtrace)   (run_dir=$GRAFT_REPO_ROOT/gpurun_out/slabtrace; rm -rf $run_dir; mkdir -p $run_dir;
                   STRIPE=16 run slabtrace 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/slabtrace -- python3 tools/slab_trace.py 8 3 40) ;;
     counters)    rocprofv3 -L > gpurun_out/counters_list.txt 2>&1; echo "counters listed" ;;
-    pmc1)        run pmc1 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
-    pmc2)        run pmc2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
-    pmc3)        run pmc3 400 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
-    pmc4)        run pmc4 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc4 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
+    pmc1)        run pmc1 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc1 -- python3 bench.py --role pmc-child --steps 3 --warmup 1 ;;
+    pmc2)        run pmc2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc2 -- python3 bench.py --role pmc-child --steps 3 --warmup 1 ;;
+    pmc3)        run pmc3 400 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc3 -- python3 bench.py --role pmc-child --steps 3 --warmup 1 ;;
+    pmc4)        run pmc4 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc4 -- python3 bench.py --role pmc-child --steps 3 --warmup 1 ;;
     pmcbig1)     run pmcbig1 500 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcbig1 -- python3 tools/run_configs.py C4 C5 ;;
     pmcbig2)     run pmcbig2 500 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmcbig2 -- python3 tools/run_configs.py C4 C5 ;;
     pmcbig3)     run pmcbig3 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcbig3 -- python3 tools/run_configs.py C4 C5 ;;
