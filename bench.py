@@ -62,7 +62,7 @@ PMC_PASSES = [
 def render_kernel_name(mode, last_kernel):
     if mode != 'fast':
         return 'render_kernel_strict'
-    return 'render_kernel_lds' if last_kernel else 'render_kernel_fast'
+    return ('render_kernel_fast', 'render_kernel_lds', 'render_kernel_wide')[last_kernel]
 
 
 def collect_pmc(argv_tail, budget_s=150):

@@ -78,13 +78,15 @@ void mpt_destroy(mpt_ctx *ctx);
  * persistent kernel when the scene fits a CU's 160 KiB LDS, default; 0 = always gather from HBM/L2).
  * "tree" (fast build: 1 = SAH re-partition of the LBVH's leaves, default; 0 = walk the LBVH itself;
  * takes effect at the next mpt_build_tree), "tile_w_shift"/"tile_h_shift" (work-item tile 2^w x 2^h pixels),
- * "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
+ * "wide" (scenes that do not fit LDS: 1 = walk the fast tree collapsed into 4-wide nodes, 0 = the binary tree,
+ * -1 = decide by the expected number of fetches per ray, default), "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
  * walks the LBVH itself), "grid_div" (each launch takes 1/G of the CUs so that G launches are resident
  * in different phases; 0 = choose by samples per lane, default), "pipe_depth" (batches in flight,
  * 2..6; 0 = auto), "lds_block" (lanes per persistent workgroup of the LDS kernel, diagnostics),
  * "timeline" (1 = record mpt_get_timeline data), "reserve_cus" (CUs every persistent render launch leaves
  * unclaimed, default 0; measured to be of no use to foreign kernels while launches overlap, kept for experiments).
- * read-only: "tree_depth", "fast_depth", "pending", "last_kernel" (1 = LDS-resident), "num_cus",
+ * read-only: "tree_depth", "fast_depth", "wide_nodes", "wide_depth", "wide_ratio_permille", "pending", "last_kernel" (0 = gather over
+ * the binary tree, 1 = LDS-resident, 2 = gather over 4-wide nodes), "num_cus",
  * "cur_div", "cur_depth" (what the last launch used) */
 int mpt_set_option(mpt_ctx *ctx, const char *key, int value);
 int mpt_get_option(mpt_ctx *ctx, const char *key, int *value);

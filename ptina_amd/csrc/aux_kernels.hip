@@ -106,6 +106,20 @@ __global__ void probe_kernel(double *out) {
     if (threadIdx.x == 0) out[0] = (double)probe_lds[blockDim.x - 1];
 }
 
+// layout A/B (option "node_soa"): the 64-B node records transposed into four arrays of float4
+__global__ __launch_bounds__(256) void transpose_nodes_kernel(const MptVec4 *__restrict__ in, MptVec4 *__restrict__ out, int ni) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)ni * 4) return;
+    size_t i = t >> 2, k = t & 3;
+    out[k * (size_t)ni + i] = in[t];
+}
+
+MPT_KERNEL_API hipError_t mpt_launch_transpose_nodes(const MptVec4 *in, MptVec4 *out, int ni, hipStream_t stream) {
+    if (ni <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transpose_nodes_kernel, dim3((unsigned)(((size_t)ni * 4 + 255) / 256)), dim3(256), 0, stream, in, out, ni);
+    return hipGetLastError();
+}
+
 MPT_KERNEL_API hipError_t mpt_launch_probe(double *out, int threads, size_t lds_bytes, hipStream_t stream) {
     hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(threads), lds_bytes, stream, out);
     return hipGetLastError();

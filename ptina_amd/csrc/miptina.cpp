@@ -167,7 +167,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     for (auto &ev : c->event_pool) hipEventDestroy(ev);
     for (int p = 0; p < 3; p++) hipFree(c->film[p]);
     hipFree(c->resolved); hipFree(c->exported);
-    hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade);
+    hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade); hipFree(c->wnode); hipFree(c->stack_spill); hipFree(c->fnode_soa);
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
@@ -268,6 +268,11 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
     } else if (k == "reserve_cus") {
         if (value < 0 || value >= c->num_cus) return fail("reserve_cus must be in 0..%d", c->num_cus - 1);
         c->reserve_cus = value;
+    } else if (k == "node_soa") {
+        c->node_soa = value ? 1 : 0;
+    } else if (k == "wide") {
+        if (value < -1 || value > 1) return fail("wide must be -1 (auto), 0 or 1");
+        c->use_wide = value;
     } else if (k == "tree") {
         if (value != 0 && value != 1) return fail("tree must be 0 (LBVH) or 1 (SAH)");
         if (value != c->tree_kind) { c->tree_kind = value; c->tree_valid = false; }
@@ -305,6 +310,10 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "last_kernel") *value = c->last_kernel;
     else if (k == "num_cus") *value = c->num_cus;
     else if (k == "reserve_cus") *value = c->reserve_cus;
+    else if (k == "wide") *value = c->use_wide;
+    else if (k == "wide_nodes") *value = c->wide_nodes;
+    else if (k == "wide_ratio_permille") *value = (int)(c->wide_ratio * 1000.f + 0.5f);
+    else if (k == "wide_depth") *value = c->wide_depth;
     else if (k == "nranks") *value = c->nranks;
     else if (k == "rank") *value = c->rank;
     else if (k == "device") *value = c->device;
@@ -566,6 +575,7 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     p.ntiles = p.tiles_x * p.tiles_y;
     memcpy(p.world_fac, c->world_fac, sizeof p.world_fac);
     memcpy(p.v2w, c->v2w, sizeof p.v2w);
+    p.wnode = c->wnode; p.stack_spill = c->stack_spill;
     p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade;
     p.mats = c->mats; p.lights = c->lights; p.images = c->images; p.texels = c->texels;
     p.P = c->sP;
@@ -701,6 +711,40 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     const int reserve = std::max(c->reserve_cus, 0);
     const int usable_cus = std::max(c->num_cus - reserve, 1);
     const int launch_cus = std::max(usable_cus / std::max(c->cur_div, 1), 1);   // G launches never claim more than usable_cus
+    // scenes that do not fit LDS walk the 4-wide nodes (option "wide"; built by mpt_build_tree unless too deep)
+    // A wide step costs 2.3x the VALU instructions of a binary one (four box tests and a sorting network: ~135
+    // against 58) and the kernel is issue-bound, so the collapse pays only where it removes more than half of
+    // the expected fetches (MI355X: 99 k-triangle mesh, ratio 0.46: +10 %; 1 M-triangle soup, 0.51: -7 %).
+    const bool wide_pays = c->use_wide == 1 || (c->use_wide < 0 && c->wide_ratio <= 0.48f);
+    const bool wide_kernel = fast && !lds_kernel && wide_pays && c->wide_nodes > 0;
+    int wide_blocks = 0;
+    if (wide_kernel) {
+        HIP_TRY(mpt_wide_blocks(launch_cus, c->count, &wide_blocks));
+        const size_t need_spill = (size_t)wide_blocks * MPT_BLOCK * 88;   // SpillStack::SPILL entries per lane
+        if (need_spill > c->stack_spill_cap) {
+            HIP_TRY(hipDeviceSynchronize());
+            hipFree(c->stack_spill); c->stack_spill = nullptr; c->stack_spill_cap = 0;
+            if (dev_alloc(&c->stack_spill, need_spill)) return 1;
+            c->stack_spill_cap = need_spill;
+        }
+        p.stack_spill = c->stack_spill;
+    }
+    if (fast && !lds_kernel && !wide_kernel && c->node_soa && c->nfaces >= 2) {
+        // layout A/B: the same records as four arrays (one 16-B gather per array instead of one 64-B record)
+        const size_t ni = (size_t)c->nfaces - 1;
+        if (!c->fnode_soa_valid) {
+            if (ni > c->fnode_soa_cap) {
+                HIP_TRY(hipDeviceSynchronize());
+                hipFree(c->fnode_soa); c->fnode_soa = nullptr; c->fnode_soa_cap = 0;
+                if (dev_alloc(&c->fnode_soa, ni * 4)) return 1;
+                c->fnode_soa_cap = ni;
+            }
+            HIP_TRY(mpt_launch_transpose_nodes(c->fnode, c->fnode_soa, (int)ni, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->fnode_soa_valid = true;
+        }
+        p.fnode = c->fnode_soa; p.fnode_soa_n = (int)ni;
+    }
     p.timeline = nullptr;
     if (c->timeline && lds_kernel) {
         const int block = c->lds_block ? c->lds_block : 1024;
@@ -717,8 +761,9 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     HIP_TRY(hipEventRecord(e0, rs));
     if (!fast) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, rs));
     else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, launch_cus, c->lds_block ? c->lds_block : 1024, lds_bytes, c->count, rs));
+    else if (wide_kernel) HIP_TRY(mpt_launch_render_wide(&p, wide_blocks, c->count, rs));
     else HIP_TRY(mpt_launch_render_fast(&p, launch_cus, stack, c->count, rs));
-    c->last_kernel = lds_kernel ? 1 : 0;
+    c->last_kernel = lds_kernel ? 1 : wide_kernel ? 2 : 0;
     HIP_TRY(hipEventRecord(e1, rs));
     c->events.push_back({ e0, e1 });
     if (c->events.size() > 4096) {

@@ -21,6 +21,8 @@
 // kernel launchers (render_kernel.hip x2, aux_kernels.hip)
 MPT_KERNEL_API hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int *blocks);
+MPT_KERNEL_API hipError_t mpt_launch_render_wide(const MptRenderParams *, int blocks, int count, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
@@ -30,6 +32,7 @@ MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *parti
                                          int stripe_w, int stripe_pitch,
                                          int nchunks, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_transpose_nodes(const MptVec4 *in, MptVec4 *out, int ni, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_probe(double *out, int threads, size_t lds_bytes, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
 
@@ -104,6 +107,14 @@ struct mpt_ctx {
     std::vector<int32_t> h_child, h_leaf, h_mc;
     std::vector<float> h_bmin, h_bmax;
     MptVec4 *snode = nullptr, *fnode = nullptr, *tgeo = nullptr, *tshade = nullptr;
+    MptVec4 *wnode = nullptr; size_t wnode_cap = 0;   // 4-wide nodes of the fast tree (gather kernel), 8 float4 each
+    int wide_nodes = 0, wide_depth = 0;               // 0 nodes: not built (scene fits LDS, or too deep)
+    float wide_ratio = 1.f;                           // expected fetches per ray, wide / binary (surface-area sums)
+    int use_wide = -1;                                // option "wide": 1 walk the 4-wide nodes when the scene does not fit LDS,
+                                                      // 0 the binary tree, -1 decide by wide_ratio (mpt_flush)
+    int *stack_spill = nullptr; size_t stack_spill_cap = 0;
+    int node_soa = 0;                                 // option "node_soa" (layout A/B): binary gather kernel reads an SoA transpose
+    MptVec4 *fnode_soa = nullptr; size_t fnode_soa_cap = 0; bool fnode_soa_valid = false;
     size_t node_cap = 0, tri_cap = 0;
 
     // materials / images / lights / world / camera

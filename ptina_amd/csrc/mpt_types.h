@@ -8,6 +8,11 @@
 //                           register pairs v_pk_fma_f32 wants:
 //                           {c0.lo.x, c1.lo.x, c0.hi.x, c1.hi.x} {..y..} {..z..} {id0, id1, -, -}
 //                           id >= 0: internal node index; id < 0: leaf, slot = ~id
+//   wnode  float4[nw*8]     4-wide traversal node (gather kernel): the binary tree collapsed so that one 128-B
+//                           record holds four child boxes, component by component with the four children side
+//                           by side: {lo.x[4]} {hi.x[4]} {lo.y[4]} {hi.y[4]} {lo.z[4]} {hi.z[4]} {id[4]} {-};
+//                           id >= 0: wide node index, id < 0: leaf, slot = ~id; an unused child is a point box at
+//                           1e30 that no ray reaches
 //   tgeo   float4[n*4]      per-leaf-slot triangle, ray-independent terms of geometries.py:118-148
 //                           hoisted: {v0.xyz, D} {u.xyz, uu} {v.xyz, uv} {n.xyz, vv}
 //   tshade float4[n*4]      per-leaf-slot shading data: {n0.xyz, n1.x} {n1.yz, n2.xy} {n2.z, uv0.xy, uv1.x}
@@ -51,7 +56,8 @@ struct MptRenderParams {
     int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders
     int32_t nframes, chunk, nchunks, n;     // batch frames; frames per work item; items per tile; #triangles
     int32_t sobol_dim, nlights, world_tex, tiles_x;   // tiles_* : 16x16 tiles of the slab (strict build)
-    int32_t tiles_y, ntiles, pad0;
+    int32_t tiles_y, ntiles;
+    int32_t fnode_soa_n;                    // 0, or the node count when fnode holds the SoA transpose (layout A/B)
     float sobol_inv_dim;                    // 1 / sobol_dim (quotient estimate of the draw index reduction)
     int32_t nitems, tile_w_shift, tile_h_shift, pad2;   // fast build: (2^w x 2^h tile, chunk) work items of this launch
     // columns rendered: x = x0 + s*stripe_pitch + w, w < stripe_w, x < x1 (one contiguous slab: stripe_w = 2^30)
@@ -60,6 +66,7 @@ struct MptRenderParams {
     float v2w[16];
     const MptVec4 *snode;
     const MptVec4 *fnode;
+    const MptVec4 *wnode;                    // 4-wide traversal nodes (scenes that do not fit LDS), or null
     const MptVec4 *tgeo;
     const MptVec4 *tshade;
     const MptMaterial *mats;
@@ -73,6 +80,7 @@ struct MptRenderParams {
     MptVec4 *partial;                        // fast build: per-sample radiance [nframes][nx*ny]
     unsigned long long *counters;            // mpt_counters when counting, else unused
     unsigned int *work_counter;              // persistent kernels: 8 per-range item counters
+    int *stack_spill;                        // wide kernel: 88 overflow stack entries per lane of the grid
     unsigned int *watchdog;                  // host-pinned flag a persistent wave raises when it gives up
     unsigned long long *timeline;            // diagnostics: per wave {start, scene ready, queue empty, exit} in
                                              // 100 MHz ticks, or null

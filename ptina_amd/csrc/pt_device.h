@@ -189,14 +189,58 @@ struct Stack {
 
 // scene records served from HBM/L2 through the vector L1 (any scene size)
 struct GlobalScene {
+    static constexpr bool WIDE = false;
     const MptVec4 *fnode, *tgeo;
+    int soa_n;                 // node count, for the layout A/B build below
     DEV void node(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &d) const {
+#if MPT_X_NODE_SOA
+        // layout A/B build only (option "node_soa" = 1 hands it the transposed arrays): four arrays of float4
+        const MptVec4 *nd = fnode + i;
+        a = nd[0]; b = nd[soa_n]; c = nd[2 * (size_t)soa_n]; d = nd[3 * (size_t)soa_n];
+#else
         const MptVec4 *nd = fnode + (size_t)i * 4;
         a = nd[0]; b = nd[1]; c = nd[2]; d = nd[3];
+#endif
     }
     DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2, MptVec4 &g3) const {
         const MptVec4 *g = tgeo + (size_t)slot * 4;
         g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3];
+    }
+};
+
+// 4-wide nodes gathered from HBM / L2 / Infinity Cache (scenes that do not fit LDS): a traversal step is one
+// 128-B record and four box tests, and a ray makes half as many DEPENDENT fetches as through the binary tree --
+// those fetches, not their bytes, are what bounds the big scenes (measured: binary16 boxes at half the bytes
+// bought 3-7 %)
+struct WideScene {
+    static constexpr bool WIDE = true;
+    const MptVec4 *wnode, *tgeo;
+    DEV void node4(int i, MptVec4 &lx, MptVec4 &hx, MptVec4 &ly, MptVec4 &hy, MptVec4 &lz, MptVec4 &hz, MptVec4 &id) const {
+        const MptVec4 *nd = wnode + (size_t)i * 8;
+        lx = nd[0]; hx = nd[1]; ly = nd[2]; hy = nd[3]; lz = nd[4]; hz = nd[5]; id = nd[6];
+    }
+    DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2, MptVec4 &g3) const {
+        const MptVec4 *g = tgeo + (size_t)slot * 4;
+        g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3];
+    }
+};
+
+// LIFO of the wide traversal: a step may push three entries, so the worst case is 3 x depth; the first CAP
+// levels live in LDS like Stack's, the (rare) rest in a per-lane strip of global memory
+struct SpillStack {
+    static constexpr int SENTINEL = (int)0x80000000;
+    static constexpr int CAP = 40, SPILL = 88;    // 40 levels x 256 lanes x 4 B = 40 KiB of LDS: four workgroups per CU
+    int *base;                 // &lds[threadIdx.x]
+    int *spill;                // this lane's SPILL entries
+    int sp;
+    DEV void push(int v) {
+        if (sp < CAP) base[sp * MPT_BLOCK] = v;
+        else spill[sp - CAP] = v;
+        sp++;
+    }
+    DEV int pop() {
+        sp--;
+        return sp < CAP ? base[sp * MPT_BLOCK] : spill[sp - CAP];
     }
 };
 
@@ -209,6 +253,7 @@ typedef __attribute__((address_space(3))) short *LdsShortPtr;
 DEV MptVec4 lds_ld(LdsVec4Ptr q) { mpt_f4 v = *q; MptVec4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
 
 struct LdsScene {
+    static constexpr bool WIDE = false;
     LdsVec4Ptr fnode, tgeo;
     DEV void node(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &d) const {
         LdsVec4Ptr nd = fnode + i * 4;

@@ -58,7 +58,7 @@ DEV BlockTracer make_block_tracer(const MptRenderParams &p, int *lds) {
 typedef Tracer<GlobalScene, Stack> BlockTracer;
 DEV BlockTracer make_block_tracer(const MptRenderParams &p, int *lds) {
     BlockTracer t;
-    t.sc.fnode = p.fnode; t.sc.tgeo = p.tgeo;
+    t.sc.fnode = p.fnode; t.sc.tgeo = p.tgeo; t.sc.soa_n = p.fnode_soa_n;
     t.st.base = lds; t.st.sp = 0;
     t.n = p.n;
     return t;
@@ -236,6 +236,11 @@ DEV void lane_draws(const MptRenderParams &p, LaneState &L, float *out) {
 #pragma unroll
         for (int t = 0; t < N; t++) {
             out[t] = P[k];
+#if MPT_X_DUP_P_LOADS
+            // A/B build: every Sobol load issued twice (same film): the slowdown bounds what the loads cost
+            float dup = __builtin_nontemporal_load(P + k);
+            out[t] = dup == out[t] ? out[t] : dup;
+#endif
             k = (k + 1 == dim) ? 0 : k + 1;
         }
         L.rng_k = k;
@@ -312,6 +317,43 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     stk.sp = L.sp;
     if (h0 && h1) stk.push(farid);
     if (!(h0 || h1)) next = stk.pop();
+    L.sp = stk.sp;
+    L.curr = next;
+    L.st = classify<STACK>(next);
+}
+
+// The same step through a 4-wide node: four box tests on one 128-B record, the children that are hit sorted
+// by entry distance (a five-comparator network on (distance bits, id) pairs; a miss sorts last), the nearest
+// taken next and the others pushed farthest first.
+template <bool COUNT, class SCENE, class STACK>
+DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
+    MptVec4 lx, hx, ly, hy, lz, hz, idv;
+    sc.node4(L.curr, lx, hx, ly, hy, lz, hz, idv);
+    int id0 = __float_as_int(idv.x), id1 = __float_as_int(idv.y), id2 = __float_as_int(idv.z), id3 = __float_as_int(idv.w);
+    if (COUNT) { cnt.n_node++; cnt.n_box += 4; }
+    float t0, t1, t2, t3;
+    bool h0 = box_fast(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, L.inv, L.oinv, L.tbest, &t0);
+    bool h1 = box_fast(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, L.inv, L.oinv, L.tbest, &t1);
+    bool h2 = box_fast(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, L.inv, L.oinv, L.tbest, &t2);
+    bool h3 = box_fast(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, L.inv, L.oinv, L.tbest, &t3);
+    // entry distances are >= 0, so their bit patterns order like the values; a miss (or the triangle the ray
+    // left from, lbvh.py:329) gets the largest key
+    const unsigned MISS = 0xffffffffu;
+    unsigned k0 = (h0 && id0 != L.navoid) ? (unsigned)__float_as_int(t0) : MISS;
+    unsigned k1 = (h1 && id1 != L.navoid) ? (unsigned)__float_as_int(t1) : MISS;
+    unsigned k2 = (h2 && id2 != L.navoid) ? (unsigned)__float_as_int(t2) : MISS;
+    unsigned k3 = (h3 && id3 != L.navoid) ? (unsigned)__float_as_int(t3) : MISS;
+#define MPT_CSWAP(ka, ia, kb, ib) { bool sw = kb < ka; unsigned tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
+                                    int ti_ = sw ? ib : ia; ib = sw ? ia : ib; ia = ti_; }
+    MPT_CSWAP(k0, id0, k1, id1) MPT_CSWAP(k2, id2, k3, id3) MPT_CSWAP(k0, id0, k2, id2) MPT_CSWAP(k1, id1, k3, id3)
+    MPT_CSWAP(k1, id1, k2, id2)
+#undef MPT_CSWAP
+    stk.sp = L.sp;
+    if (k3 != MISS) stk.push(id3);
+    if (k2 != MISS) stk.push(id2);
+    if (k1 != MISS) stk.push(id1);
+    int next = id0;
+    if (k0 == MISS) next = stk.pop();
     L.sp = stk.sp;
     L.curr = next;
     L.st = classify<STACK>(next);
@@ -475,7 +517,10 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             if (cn + cl == 0 || (cn + cl) * 2 < cw) break;
             if (cn >= cl) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
-                if (L.st == ST_NODE) stage_node<COUNT>(sc, stk, L, cnt);
+                if (L.st == ST_NODE) {
+                    if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
+                    else stage_node<COUNT>(sc, stk, L, cnt);
+                }
             } else {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
                 if (L.st == ST_LEAF) stage_leaf<COUNT>(sc, stk, L, cnt);
@@ -568,6 +613,21 @@ __global__ MPT_RENDER_BOUNDS void MPT_SUFFIX(render_kernel)(const MptRenderParam
 }
 
 #if !MPT_STRICT
+// ---------------------------------------------------------------- gather kernel over 4-wide nodes
+template <bool COUNT>
+__global__ __launch_bounds__(MPT_BLOCK, 4) void render_kernel_wide(const MptRenderParams p) {
+    __shared__ int s_stack[SpillStack::CAP * MPT_BLOCK];
+    WideScene sc; sc.wnode = p.wnode; sc.tgeo = p.tgeo;
+    SpillStack stk;
+    stk.base = s_stack + threadIdx.x;
+    stk.spill = p.stack_spill + ((size_t)blockIdx.x * MPT_BLOCK + threadIdx.x) * SpillStack::SPILL;
+    stk.sp = 0;
+    Cnt cnt = {};
+    WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
+    trace_stream<COUNT>(p, sc, stk, wq, cnt);
+    flush_counters<COUNT>(p, cnt);
+}
+
 // ---------------------------------------------------------------- LDS-resident persistent kernel
 // dynamic LDS: [ (n-1)*4 node float4 | n*4 triangle float4 | lds_stack x 1024 int16 ]
 template <bool COUNT>
@@ -690,6 +750,29 @@ static hipError_t launch_lds(const MptRenderParams *p, int grid, int block, size
 MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *p, int grid, int block, size_t lds_bytes, int count,
                                             hipStream_t stream) {
     return count ? launch_lds<true>(p, grid, block, lds_bytes, stream) : launch_lds<false>(p, grid, block, lds_bytes, stream);
+}
+#endif
+
+#if !MPT_STRICT
+// persistent workgroups over 4-wide nodes; `grid` = number of CUs (scaled here by the blocks each CU can hold);
+// *blocks = workgroups launched (the spill strip must hold blocks x 256 lanes x SpillStack::SPILL entries)
+MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int *blocks) {
+    static std::atomic<int> occ_cache[MPT_MAX_DEVICES][2];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MPT_MAX_DEVICES) return hipErrorInvalidDevice;
+    int occ = occ_cache[dev][count ? 1 : 0].load(std::memory_order_relaxed);
+    if (!occ) {
+        occ = count ? blocks_per_cu(render_kernel_wide<true>) : blocks_per_cu(render_kernel_wide<false>);
+        occ_cache[dev][count ? 1 : 0].store(occ, std::memory_order_relaxed);
+    }
+    *blocks = grid * occ;
+    return hipSuccess;
+}
+
+MPT_KERNEL_API hipError_t mpt_launch_render_wide(const MptRenderParams *p, int blocks, int count, hipStream_t stream) {
+    if (count) hipLaunchKernelGGL((render_kernel_wide<true>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
+    else hipLaunchKernelGGL((render_kernel_wide<false>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
+    return hipGetLastError();
 }
 #endif
 

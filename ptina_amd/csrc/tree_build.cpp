@@ -468,9 +468,114 @@ static int build_tree_gpu(mpt_ctx *c) {
     return 0;
 }
 
+// The binary tree the fast build walks (c->fnode: a node record holds its two children's boxes), collapsed into
+// 4-wide nodes for the gather kernel: starting from a node's two children, the internal child with the largest
+// surface area is replaced by its own two children until four are held (or only leaves are left).  A ray then
+// makes about half as many dependent record fetches, which is what the scenes that do not fit LDS wait for.
+// Host pass over the downloaded records (1 M triangles: 64 MB down, ~0.1 s, 64 MB up), off the render path.
+static int make_wide(mpt_ctx *c) {
+    c->wide_nodes = 0; c->wide_depth = 0;
+    const int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
+    if (ni < 1) return 0;
+    std::vector<MptVec4> fnode((size_t)ni * 4);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(fnode.data(), c->fnode, fnode.size() * sizeof(MptVec4), hipMemcpyDeviceToHost));
+    auto asi = [](float f) { int32_t v; memcpy(&v, &f, 4); return v; };
+    auto asf = [](int32_t v) { float f; memcpy(&f, &v, 4); return f; };
+    struct Child { int32_t id; float lo[3], hi[3]; };
+    auto children_of = [&](int b, Child out[2]) {
+        const MptVec4 *r = &fnode[(size_t)b * 4];
+        const float lox[2] = { r[0].x, r[0].y }, hix[2] = { r[0].z, r[0].w };
+        const float loy[2] = { r[1].x, r[1].y }, hiy[2] = { r[1].z, r[1].w };
+        const float loz[2] = { r[2].x, r[2].y }, hiz[2] = { r[2].z, r[2].w };
+        const int32_t id[2] = { asi(r[3].x), asi(r[3].y) };
+        for (int k = 0; k < 2; k++) {
+            out[k].id = id[k];
+            out[k].lo[0] = lox[k]; out[k].lo[1] = loy[k]; out[k].lo[2] = loz[k];
+            out[k].hi[0] = hix[k]; out[k].hi[1] = hiy[k]; out[k].hi[2] = hiz[k];
+        }
+    };
+    auto area = [](const Child &ch) {
+        float dx = std::max(ch.hi[0] - ch.lo[0], 0.f), dy = std::max(ch.hi[1] - ch.lo[1], 0.f), dz = std::max(ch.hi[2] - ch.lo[2], 0.f);
+        return dx * dy + dy * dz + dz * dx;
+    };
+    // expected dependent fetches per ray ~ sum of the surface areas of the nodes that are fetched (SAH argument):
+    // over all internal nodes for the binary tree, over the nodes wide records are grown from for the collapse
+    std::vector<float> node_area((size_t)ni, 0.f);
+    {
+        Child two[2];
+        children_of(0, two);
+        Child root = two[0];
+        for (int a = 0; a < 3; a++) { root.lo[a] = std::min(two[0].lo[a], two[1].lo[a]); root.hi[a] = std::max(two[0].hi[a], two[1].hi[a]); }
+        node_area[0] = area(root);
+        for (int b = 0; b < ni; b++) {
+            children_of(b, two);
+            for (int k = 0; k < 2; k++) if (two[k].id >= 0) node_area[two[k].id] = area(two[k]);
+        }
+    }
+    double area_bin = 0.0, area_wide = 0.0;
+    for (int b = 0; b < ni; b++) area_bin += node_area[b];
+    std::vector<MptVec4> wnode;
+    wnode.reserve((size_t)ni * 4);
+    std::vector<int> bin_of;            // wide node -> the binary node it was grown from
+    std::vector<int> depth_of;
+    bin_of.push_back(0); depth_of.push_back(1);
+    int depth = 1;
+    for (size_t w = 0; w < bin_of.size(); w++) {
+        Child ch[4];
+        int cnt = 2;
+        children_of(bin_of[w], ch);
+        area_wide += node_area[bin_of[w]];
+        while (cnt < 4) {
+            int best = -1; float ba = -1.f;
+            for (int k = 0; k < cnt; k++)
+                if (ch[k].id >= 0) { float a = area(ch[k]); if (a > ba) { ba = a; best = k; } }
+            if (best < 0) break;
+            Child two[2];
+            children_of(ch[best].id, two);
+            ch[best] = two[0];
+            ch[cnt++] = two[1];
+        }
+        MptVec4 rec[8];
+        float *f = &rec[0].x;
+        for (int k = 0; k < 32; k++) f[k] = 0.f;
+        int32_t ids[4] = { 0, 0, 0, 0 };
+        for (int k = 0; k < 4; k++) {
+            float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { 1e30f, 1e30f, 1e30f };   // unused child: out of every ray's reach
+            if (k < cnt) {
+                for (int a = 0; a < 3; a++) { lo[a] = ch[k].lo[a]; hi[a] = ch[k].hi[a]; }
+                if (ch[k].id < 0) ids[k] = ch[k].id;
+                else {
+                    ids[k] = (int32_t)bin_of.size();
+                    bin_of.push_back(ch[k].id);
+                    depth_of.push_back(depth_of[w] + 1);
+                    depth = std::max(depth, depth_of[w] + 1);
+                }
+            }
+            for (int a = 0; a < 3; a++) { (&rec[2 * a].x)[k] = lo[a]; (&rec[2 * a + 1].x)[k] = hi[a]; }
+        }
+        rec[6] = { asf(ids[0]), asf(ids[1]), asf(ids[2]), asf(ids[3]) };
+        for (int k = 0; k < 8; k++) wnode.push_back(rec[k]);
+    }
+    // a step pushes up to three entries: 3 x depth + sentinel must fit the LDS levels plus the spill strip
+    if (3 * depth + 2 > 128) return 0;      // too deep (40 LDS levels + 88 spilled): the gather kernel keeps walking the binary tree
+    const size_t nw = bin_of.size();
+    if (nw > c->wnode_cap) {
+        hipFree(c->wnode); c->wnode = nullptr; c->wnode_cap = 0;
+        if (dev_alloc(&c->wnode, nw * 8)) return 1;
+        c->wnode_cap = nw;
+    }
+    HIP_TRY(hipMemcpy(c->wnode, wnode.data(), nw * 8 * sizeof(MptVec4), hipMemcpyHostToDevice));
+    c->wide_nodes = (int)nw; c->wide_depth = depth;
+    c->wide_ratio = area_bin > 0.0 ? (float)(area_wide / area_bin) : 1.f;
+    return 0;
+}
+
 extern "C" int mpt_build_tree(mpt_ctx *c) {
     if (use(c)) return 1;
-    return c->gpu_build ? build_tree_gpu(c) : build_tree_host(c);
+    c->fnode_soa_valid = false;
+    if (c->gpu_build ? build_tree_gpu(c) : build_tree_host(c)) return 1;
+    return make_wide(c);
 }
 
 static int download_tree(mpt_ctx *c) {

@@ -235,27 +235,34 @@ def test_long_interactive_session(fresh):
 
 
 def test_lds_and_gather_kernels_agree_bit_for_bit(fresh):
-    '''the LDS-resident kernel and the gather kernel run the same state machine on the same tree: one
-    film, whichever serves the scene; so do the SAH and the plain-LBVH tree up to equal-depth ties'''
+    '''the LDS-resident kernel and the gather kernel over the binary tree run the same state machine on the
+    same tree: one film, whichever serves the scene; the SAH and the plain-LBVH tree, and the gather kernel over
+    the 4-wide collapse of either, visit the same triangles in another order: equal up to equal-depth ties'''
     from helpers import assert_parity
-    from ptina_amd.things import FilmTable
+    from ptina_amd.things import FilmTable, BVHTree
     from ptina_amd.common import ctx, reset_all
     films = {}
-    for lds, tree in ((1, 1), (0, 1), (1, 0), (0, 0)):
+    for lds, tree, wide in ((1, 1, 0), (0, 1, 0), (1, 0, 0), (0, 0, 0), (0, 1, 1), (0, 0, 1)):
         reset_all()
         eng = _engine(None, scenes.scene_s978(), 96, 80, mode='fast')
         c = ctx()
         c.set_option('lds', lds)
         c.set_option('tree', tree)
-        from ptina_amd.things import BVHTree
+        c.set_option('wide', wide)
         BVHTree().build()
         eng.render(6)
-        films[(lds, tree)] = (FilmTable().get_raw().copy(), FilmTable().get_image().copy(), c.get_option('last_kernel'))
+        films[(lds, tree, wide)] = (FilmTable().get_raw().copy(), FilmTable().get_image().copy(), c.get_option('last_kernel'))
+        if wide:
+            assert c.get_option('wide_nodes') > 0 and 1 < c.get_option('wide_depth') <= c.get_option('fast_depth')
     reset_all()
-    assert films[(1, 1)][2] == 1 and films[(0, 1)][2] == 0
-    assert np.array_equal(films[(1, 1)][0], films[(0, 1)][0])
-    assert np.array_equal(films[(1, 0)][0], films[(0, 0)][0])
-    assert_parity(films[(1, 1)][1], films[(1, 0)][1], *FAST, what='SAH tree vs LBVH')
+    assert films[(1, 1, 0)][2] == 1 and films[(0, 1, 0)][2] == 0 and films[(0, 1, 1)][2] == 2
+    assert np.array_equal(films[(1, 1, 0)][0], films[(0, 1, 0)][0])
+    assert np.array_equal(films[(1, 0, 0)][0], films[(0, 0, 0)][0])
+    assert_parity(films[(1, 1, 0)][1], films[(1, 0, 0)][1], *FAST, what='SAH tree vs LBVH')
+    assert_parity(films[(0, 1, 1)][1], films[(1, 1, 0)][1], *FAST, what='4-wide nodes vs binary tree (SAH)')
+    assert_parity(films[(0, 0, 1)][1], films[(1, 0, 0)][1], *FAST, what='4-wide nodes vs binary tree (LBVH)')
+    for k in ((0, 1, 1), (0, 0, 1)):
+        assert np.all(films[k][0][:, 3] == 6)
 
 
 def test_launch_pipelining_does_not_change_the_film(fresh):
@@ -746,9 +753,11 @@ def test_mid_size_scene_with_environment_vs_oracle(fresh, oracle_mod):
     for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
         reset_all()
         eng = _engine(None, scene, 64, 64, mode=mode, world=world)
+        ctx().set_option('wide', 1)                    # the 4-wide gather kernel, whatever the heuristic would pick
         eng.render(8)
         if mode == 'fast':
-            assert ctx().get_option('last_kernel') == 0
+            ctx().call('mpt_flush')
+            assert ctx().get_option('last_kernel') == 2
         assert_parity(FilmTable().get_image(), ref.get_image(), *bounds(mode), what=f'c4-small {mode}')
     reset_all()
 
@@ -1049,6 +1058,15 @@ def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
     # 8192 pixels at 16 spp over a triangle soup: a handful of pixels whose closest hit flips between two
     # nearly coincident triangles carry the RMSE (measured: 0.10 % outliers, rel-RMSE 2.9e-3, max diff 0.14)
     assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 6e-3, what='C5 1M triangles fast, 8 columns x 16 spp')
+    assert ctx().get_option('last_kernel') == 0           # a soup: the collapse does not pay, the binary tree is walked
+    # the same through the 4-wide collapse of the tree (465 k nodes of 128 B), forced
+    ctx().set_option('wide', 1)
+    FilmTable().clear()
+    ctx().call('mpt_sobol_reset', 64)
+    eng.render(spp)
+    raw = FilmTable().get_raw().reshape(nx, ny, 4)
+    assert ctx().get_option('last_kernel') == 2 and np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 6e-3, what='C5 1M triangles fast over 4-wide nodes, 8 columns x 16 spp')
     reset_all()
     eng = _engine(None, scene, nx, ny, mode='strict', slab=(x0, x1))
     eng.render(spp)
@@ -1077,7 +1095,8 @@ def test_config4_full_scene_with_environment_vs_oracle(fresh, oracle_mod):
     want = ref.get_image()[x0:x1]
     eng = _engine(None, scene, nx, ny, mode='fast', world=world)
     eng.render(spp)
-    assert ctx().get_option('last_kernel') == 0           # gather kernel: the scene does not fit LDS
+    ctx().call('mpt_flush')
+    assert ctx().get_option('last_kernel') == 2           # gather kernel over 4-wide nodes: the scene does not fit LDS
     raw = FilmTable().get_raw().reshape(nx, ny, 4)
     assert np.all(raw[..., 3] == spp) and np.isfinite(raw).all() and raw[..., :3].min() >= 0
     # one pixel next to the environment map's sun lobe differs by 0.79 at 8 spp: it alone is 1.4e-3 of rel-RMSE

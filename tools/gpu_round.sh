@@ -30,6 +30,7 @@ for step in "$@"; do
     timeline)    run timeline 300 python tools/gpu_diag.py timeline ;;
     c3)          run c3 300 python tools/gpu_diag.py c3 ;;
     configs)     run configs 600 python tools/run_configs.py ;;
+    big_ab)      MIPTINA_WIDE=0 run big_bin 400 python tools/run_configs.py C4 C5; MIPTINA_WIDE=1 run big_wide 400 python tools/run_configs.py C4 C5 ;;
     c5sah)       run c5sah 600 python tools/gpu_diag.py c5sah ;;
     probe)       run probe 300 python tools/gpu_diag.py probe ;;
     sync_sweep)  run sync_sweep 300 python tools/gpu_diag.py sync_sweep ;;

@@ -32,10 +32,18 @@ for title, name, kw, n, spp, world in CONFIGS:
     common.reset_all()
     t0 = time.time()
     scene = scenes.get_scene(name, **kw)
+    if os.environ.get('MIPTINA_SAH_MAX'):
+        from ptina_amd.things import init_things
+        init_things(max_filmsize=max(n * n, 1 << 21))
+        ctx().set_option('sah_max', int(os.environ['MIPTINA_SAH_MAX']))
     eng = setup_engine(scene, n, n, mode='fast', world=world, max_filmsize=max(n * n, 1 << 21))
     c = ctx()
     setup_s = time.time() - t0
     c.set_option('batch', 32)
+    for kv in filter(None, os.environ.get('MIPTINA_OPTS', '').split(',')):
+        c.set_option(kv.split('=')[0], int(kv.split('=')[1]))
+    if os.environ.get('MIPTINA_WIDE'):
+        c.set_option('wide', int(os.environ['MIPTINA_WIDE']))
     eng.render(1)
     c.call('mpt_synchronize')
     c.set_option('count', 1)
@@ -56,13 +64,13 @@ for title, name, kw, n, spp, world in CONFIGS:
     bps = algorithmic_bytes(cnt) / cnt['samples']
     ms = n * n * spp / dt / 1e6
     out[title] = {'ntri': int(scene[1].shape[0]), 'setup_s': round(setup_s, 3), 'msamples_s': round(ms, 1),
-                  'ms_per_step': round(dt * 1e3, 3), 'kernel': 'lds' if c.get_option('last_kernel') else 'gather',
+                  'ms_per_step': round(dt * 1e3, 3), 'kernel': ('gather', 'lds', 'gather4')[c.get_option('last_kernel')],
                   'bytes_per_sample': round(bps, 1), 'achieved_GBs': round(bps * ms * 1e6 / 1e9, 1),
                   'pct_of_8TBs': round(bps * ms * 1e6 / 8e12 * 100, 1),
                   'rays_per_sample': round(cnt['rays'] / cnt['samples'], 2),
                   'nodes_per_ray': round(cnt['n_node'] / cnt['rays'], 2), 'tris_per_ray': round(cnt['n_tri'] / cnt['rays'], 2),
                   'mrays_s': round(cnt['rays'] / cnt['samples'] * ms, 1),
-                  'tree_depth': [c.get_option('tree_depth'), c.get_option('fast_depth')]}
+                  'tree_depth': [c.get_option('tree_depth'), c.get_option('fast_depth'), c.get_option('wide_depth')]}
     print(title, json.dumps(out[title]), flush=True)
     json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'configs.json'), 'w'), indent=1)
 common.reset_all()
