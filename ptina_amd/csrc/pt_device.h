@@ -189,7 +189,7 @@ struct Stack {
 
 // scene records served from HBM/L2 through the vector L1 (any scene size)
 struct GlobalScene {
-    static constexpr bool WIDE = false;
+    static constexpr bool WIDE = false, SIGNED_PLANES = false;
     const MptVec4 *fnode, *tgeo;
     int soa_n;                 // node count, for the layout A/B build below
     DEV void node(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &d) const {
@@ -213,7 +213,7 @@ struct GlobalScene {
 // those fetches, not their bytes, are what bounds the big scenes (measured: binary16 boxes at half the bytes
 // bought 3-7 %)
 struct WideScene {
-    static constexpr bool WIDE = true;
+    static constexpr bool WIDE = true, SIGNED_PLANES = false;
     const MptVec4 *wnode, *tgeo;
     DEV void node4(int i, MptVec4 &lx, MptVec4 &hx, MptVec4 &ly, MptVec4 &hy, MptVec4 &lz, MptVec4 &hz, MptVec4 &id) const {
         const MptVec4 *nd = wnode + (size_t)i * 8;
@@ -252,9 +252,27 @@ typedef __attribute__((address_space(3))) short *LdsShortPtr;
 
 DEV MptVec4 lds_ld(LdsVec4Ptr q) { mpt_f4 v = *q; MptVec4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
 
+typedef float mpt_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const mpt_f2 *LdsVec2Ptr;
+typedef __attribute__((address_space(3))) const char *LdsBytePtr;
+
 struct LdsScene {
-    static constexpr bool WIDE = false;
+    static constexpr bool WIDE = false, SIGNED_PLANES = true;
     LdsVec4Ptr fnode, tgeo;
+    // The slab planes of both children picked by the ray's direction signs instead of by min / max: a node
+    // record holds {lo, lo, hi, hi} (child 0, child 1) per axis, so the entry planes of an axis are the 8 bytes at
+    // offset 0 for a ray going up that axis and at offset 8 for one going down, and the exit planes are the
+    // other 8 -- the offsets o* (0 or 8) are per-ray constants.  Seven ds_read_b64 instead of four ds_read_b128,
+    // and 12 v_min / v_max fewer per step.
+    DEV void node_planes(int i, int ox, int oy, int oz, mpt_f2 &nx, mpt_f2 &fx, mpt_f2 &ny, mpt_f2 &fy,
+                         mpt_f2 &nz, mpt_f2 &fz, mpt_f2 &ids) const {
+        LdsBytePtr nd = (LdsBytePtr)(fnode + i * 4);
+        LdsBytePtr ax = nd + ox, ay = nd + oy, az = nd + oz;
+        nx = *(LdsVec2Ptr)ax;        fx = *(LdsVec2Ptr)(nd + (ox ^ 8));
+        ny = *(LdsVec2Ptr)(ay + 16); fy = *(LdsVec2Ptr)(nd + 16 + (oy ^ 8));
+        nz = *(LdsVec2Ptr)(az + 32); fz = *(LdsVec2Ptr)(nd + 32 + (oz ^ 8));
+        ids = *(LdsVec2Ptr)(nd + 48);
+    }
     DEV void node(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &d) const {
         LdsVec4Ptr nd = fnode + i * 4;
         a = lds_ld(nd); b = lds_ld(nd + 1); c = lds_ld(nd + 2); d = lds_ld(nd + 3);

@@ -199,6 +199,7 @@ struct LaneState {
     V3 direct;                 // shadow ray in flight: candidate direct light, added if unoccluded
     // ray being traversed (closest: the path ray; shadow: hitpos -> light)
     V3 to, td, inv, oinv;
+    int offx, offy, offz;      // LDS kernel: 8 where the ray goes down the axis, else 0 (LdsScene::node_planes)
     float tbest;               // closest: best depth so far; shadow: li.dis
     int curr, sp, hidx;        // hidx: leaf slot of the hit so far, -1 = none (closest) / any occluder found (shadow)
     float hu, hv;
@@ -266,6 +267,7 @@ DEV void lane_start_ray(LaneState &L, STACK &stk, V3 o, V3 d, float tmax, bool s
     L.to = o; L.td = d;
     L.inv = v3(m_rcp(d.x), m_rcp(d.y), m_rcp(d.z));
     L.oinv = o * L.inv;
+    L.offx = (__float_as_int(L.inv.x) >> 28) & 8; L.offy = (__float_as_int(L.inv.y) >> 28) & 8; L.offz = (__float_as_int(L.inv.z) >> 28) & 8;
     L.tbest = tmax; L.shadow = shadow ? 1 : 0; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f;
     stk.sp = 0;
     stk.push(STACK::SENTINEL);
@@ -301,13 +303,30 @@ DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, STACK &stk, V3
 //  instead of here -- within noise; per-stage instead of ratio scheduler thresholds -- within +-1 %.)
 template <bool COUNT, class SCENE, class STACK>
 DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
-    MptVec4 a, b, c, d;
-    sc.node(L.curr, a, b, c, d);
-    int id0 = __float_as_int(d.x), id1 = __float_as_int(d.y);
-    if (COUNT) { cnt.n_node++; cnt.n_box += 2; }
+    int id0, id1;
     float tn0, tn1;
-    bool h0 = box_fast(a.x, b.x, c.x, a.z, b.z, c.z, L.inv, L.oinv, L.tbest, &tn0);
-    bool h1 = box_fast(a.y, b.y, c.y, a.w, b.w, c.w, L.inv, L.oinv, L.tbest, &tn1);
+    bool h0, h1;
+    if (COUNT) { cnt.n_node++; cnt.n_box += 2; }
+    if constexpr (SCENE::SIGNED_PLANES) {
+        mpt_f2 nx, fx, ny, fy, nz, fz, ids;
+        sc.node_planes(L.curr, L.offx, L.offy, L.offz, nx, fx, ny, fy, nz, fz, ids);
+        id0 = __float_as_int(ids.x); id1 = __float_as_int(ids.y);
+        tn0 = fmaxf(fmaxf(__builtin_fmaf(nx.x, L.inv.x, -L.oinv.x), __builtin_fmaf(ny.x, L.inv.y, -L.oinv.y)),
+                    fmaxf(__builtin_fmaf(nz.x, L.inv.z, -L.oinv.z), 0.0f));
+        tn1 = fmaxf(fmaxf(__builtin_fmaf(nx.y, L.inv.x, -L.oinv.x), __builtin_fmaf(ny.y, L.inv.y, -L.oinv.y)),
+                    fmaxf(__builtin_fmaf(nz.y, L.inv.z, -L.oinv.z), 0.0f));
+        float tf0 = fminf(fminf(__builtin_fmaf(fx.x, L.inv.x, -L.oinv.x), __builtin_fmaf(fy.x, L.inv.y, -L.oinv.y)),
+                          fminf(__builtin_fmaf(fz.x, L.inv.z, -L.oinv.z), L.tbest));
+        float tf1 = fminf(fminf(__builtin_fmaf(fx.y, L.inv.x, -L.oinv.x), __builtin_fmaf(fy.y, L.inv.y, -L.oinv.y)),
+                          fminf(__builtin_fmaf(fz.y, L.inv.z, -L.oinv.z), L.tbest));
+        h0 = tn0 <= tf0; h1 = tn1 <= tf1;
+    } else {
+        MptVec4 a, b, c, d;
+        sc.node(L.curr, a, b, c, d);
+        id0 = __float_as_int(d.x); id1 = __float_as_int(d.y);
+        h0 = box_fast(a.x, b.x, c.x, a.z, b.z, c.z, L.inv, L.oinv, L.tbest, &tn0);
+        h1 = box_fast(a.y, b.y, c.y, a.w, b.w, c.w, L.inv, L.oinv, L.tbest, &tn1);
+    }
     // a leaf that is the triangle the ray left from is never tested (lbvh.py:329)
     h0 = h0 && (id0 != L.navoid);
     h1 = h1 && (id1 != L.navoid);
@@ -497,6 +516,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     L.sp = 0; L.curr = 0; L.shadow = 0;
     L.result = v3s(0.0f); L.throughput = v3s(0.0f); L.prd = v3s(0.0f); L.direct = v3s(0.0f);
     L.to = v3s(0.0f); L.td = v3s(0.0f); L.inv = v3s(0.0f); L.oinv = v3s(0.0f);
+    L.offx = 0; L.offy = 0; L.offz = 0;
     L.tbest = 0.0f; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f; L.last_brdf_pdf = 0.0f;
     L.navoid = 0; L.depth = 0; L.rng_i = 0; L.rng_k = 0; L.pix = 0; L.frame = 0;
     // Every pass of this loop retires at least one stage for at least one lane, so it ends when the
