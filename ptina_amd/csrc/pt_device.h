@@ -90,13 +90,21 @@ DEV V3 spherical(float h, float p) {                                         // 
     return v3(r * c, r * s, h);
 }
 
-DEV V3 tanspace_mul(V3 nrm, V3 v) {                                          // common.py:213-217
+// tanspace(nrm) @ v, common.py:213-217.  The basis depends on the normal alone: Disney.bounce builds it once
+// for whichever lobe is sampled (the reference's three branches each call tanspace(normal) -- same values)
+struct TanSpace { V3 tan, bitan, nrm; };
+DEV TanSpace tanspace(V3 nrm) {
+    TanSpace t;
     V3 up = v3(233.0f, 666.0f, 512.0f);
-    V3 bitan = normalized(cross(nrm, up));
-    V3 tan = cross(bitan, nrm);
-    return v3(tan.x * v.x + bitan.x * v.y + nrm.x * v.z,
-              tan.y * v.x + bitan.y * v.y + nrm.y * v.z,
-              tan.z * v.x + bitan.z * v.y + nrm.z * v.z);
+    t.bitan = normalized(cross(nrm, up));
+    t.tan = cross(t.bitan, nrm);
+    t.nrm = nrm;
+    return t;
+}
+DEV V3 tanspace_mul(const TanSpace &t, V3 v) {
+    return v3(t.tan.x * v.x + t.bitan.x * v.y + t.nrm.x * v.z,
+              t.tan.y * v.x + t.bitan.y * v.y + t.nrm.y * v.z,
+              t.tan.z * v.x + t.bitan.z * v.y + t.nrm.z * v.z);
 }
 
 // ---------------------------------------------------------------- sampling
@@ -686,6 +694,7 @@ DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V
     float Fi = schlickFresnel(cosi);
     V3 Fs = lerpv(Fi, m.speccolor, v3s(1.0f));
 
+    const TanSpace ts = tanspace(normal);
     Choice choice; choice.pdf = 1.0f; choice.w = samp.z;
     float specrate = lerpf(m.transmission, lerpf(m.metallic, vavg(Fs), 1.0f), 1.0f);
     float coatrate = 0.04f * m.clearcoat;
@@ -695,7 +704,7 @@ DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V
 
     if (choice(coatrate)) {
         float alpha = m.clearcoatAlpha;
-        V3 halfdir = tanspace_mul(normal, sample_GTR1(samp.x, samp.y, alpha));
+        V3 halfdir = tanspace_mul(ts, sample_GTR1(samp.x, samp.y, alpha));
         V3 outdir = reflectv(-indir, halfdir);
 
         float coso = dot(outdir, normal);
@@ -713,7 +722,7 @@ DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V
         }
     } else if (choice(specrate)) {
         float alpha = m.alpha;
-        V3 halfdir = tanspace_mul(normal, sample_GTR2(samp.x, samp.y, alpha));
+        V3 halfdir = tanspace_mul(ts, sample_GTR2(samp.x, samp.y, alpha));
         V3 outdir = reflectv(-indir, halfdir);
 
         float coso = dot_or_zero(outdir, normal);
@@ -749,14 +758,14 @@ DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V
             }
         }
     } else {
-        V3 outdir = tanspace_mul(normal, spherical(m_sqrt(samp.x), samp.y));
+        V3 outdir = tanspace_mul(ts, spherical(m_sqrt(samp.x), samp.y));
 
         V3 halfdir = normalized(indir + outdir);
-        float cosi2 = dot(indir, normal);
+        float cosi2 = cosi;                                                  // disney.py:207 recomputes the same dot product
         float coso = dot(outdir, normal);
         float cosoh = dot_or_zero(halfdir, outdir);
 
-        float Fi2 = schlickFresnel(cosi2);
+        float Fi2 = Fi;                                                      // and the same schlickFresnel(cosi), :212
         float Fo = schlickFresnel(coso);
         float Fd90 = 0.5f + 2.0f * (cosoh * cosoh) * m.roughness;
         float Fd = lerpf(Fi2, 1.0f, Fd90) * lerpf(Fo, 1.0f, Fd90);
