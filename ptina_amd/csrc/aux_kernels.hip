@@ -47,22 +47,26 @@ __global__ __launch_bounds__(256) void sobol_update_kernel(int *__restrict__ X, 
 }
 
 // film[pix] += sample[0][pix], then sample[1][pix], ... : the reference's frame-by-frame
-// accumulation order (filmtable.py:37-39, path.py:93), one sample slab per frame of the batch
+// accumulation order (filmtable.py:37-39, path.py:93), one sample slab per frame of the batch.
+// The slab holds only the columns of this context's share, packed: slab column cc is film column
+// x0 + (cc / stripe_w) * stripe_pitch + cc % stripe_w (one slab: stripe_w = 2^30, so x0 + cc).
 __global__ __launch_bounds__(256) void combine_kernel(MptVec4 *__restrict__ film, const MptVec4 *__restrict__ partial,
-                                                      int nx, int ny, int x0, int x1, int stripe_w,
-                                                      int stripe_pitch, int nchunks) {
-    size_t npix = (size_t)nx * ny;
-    size_t lo = (size_t)x0 * ny, hi = (size_t)x1 * ny;
-    size_t t = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= hi) return;
-    // striped share: only the columns this context rendered carry samples
-    if (((int)(t / ny) - x0) % stripe_pitch >= stripe_w) return;
-    MptVec4 a = film[t];
-    for (int c = 0; c < nchunks; c++) {
-        MptVec4 b = partial[(size_t)c * npix + t];
+                                                      int ny, int x0, int x1, int stripe_w, int stripe_pitch,
+                                                      int ccols, int nframes) {
+    const size_t stride = (size_t)ccols * ny;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= stride) return;
+    int cc = (int)(t / ny), y = (int)(t - (size_t)cc * ny);
+    int s = cc / stripe_w;
+    int x = x0 + s * stripe_pitch + (cc - s * stripe_w);
+    if (x >= x1) return;                               // tile padding past the film's last column
+    const size_t pix = (size_t)x * ny + y;
+    MptVec4 a = film[pix];
+    for (int c = 0; c < nframes; c++) {
+        MptVec4 b = partial[(size_t)c * stride + t];
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    film[t] = a;
+    film[pix] = a;
 }
 
 // FilmTable._get_image, filmtable.py:53-63 : out[x][y] = rgb / w, w -> 1; empty -> (0.9, 0.4, 0.9, 0)
@@ -132,12 +136,12 @@ MPT_KERNEL_API hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P
     return hipGetLastError();
 }
 
-MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
-                                         int stripe_w, int stripe_pitch, int nchunks, hipStream_t stream) {
-    size_t n = (size_t)(x1 - x0) * ny;
+MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int ny, int x0, int x1,
+                                         int stripe_w, int stripe_pitch, int ccols, int nframes, hipStream_t stream) {
+    size_t n = (size_t)ccols * ny;
     if (n == 0) return hipSuccess;
     int grid = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(combine_kernel, dim3(grid), dim3(256), 0, stream, film, partial, nx, ny, x0, x1, stripe_w, stripe_pitch, nchunks);
+    hipLaunchKernelGGL(combine_kernel, dim3(grid), dim3(256), 0, stream, film, partial, ny, x0, x1, stripe_w, stripe_pitch, ccols, nframes);
     return hipGetLastError();
 }
 

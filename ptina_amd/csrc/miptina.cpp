@@ -681,7 +681,10 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     p.tile_w_shift = c->tile_w_shift; p.tile_h_shift = c->tile_h_shift;
     if (fast) {
         // one float4 per sample: [frame][pixel]; the combine pass sums frames in order
-        size_t need = (size_t)B * c->nx * c->ny;
+        // ... of this context's share only: its columns packed side by side, padded to whole work-item tiles
+        const int ccols = tile_cols * tw;
+        p.partial_stride = ccols * c->ny;
+        size_t need = (size_t)B * (size_t)ccols * c->ny;
         // every slot of the ring at once: an allocation synchronises the device, so it must not
         // happen again on the second, third, ... batch of a run
         for (int q = 0; q < c->cur_depth; q++)
@@ -777,7 +780,8 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         // ordered after this render; the next batch, on the other stream, is not
         HIP_TRY(hipEventRecord(c->ev_render[k], rs));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_render[k], 0));
-        HIP_TRY(mpt_launch_combine(c->film[0], c->partial2[k], c->nx, c->ny, c->x0, c->x1, p.stripe_w, p.stripe_pitch, B, c->stream));
+        HIP_TRY(mpt_launch_combine(c->film[0], c->partial2[k], c->ny, c->x0, c->x1, p.stripe_w, p.stripe_pitch,
+                                   p.partial_stride / std::max(c->ny, 1), B, c->stream));
         HIP_TRY(hipEventRecord(c->ev_free[k], c->stream));
         // Ahead of time, on the aux stream: the Sobol points and zeroed queue heads of the NEXT batch, assuming it
         // has as many frames as this one and uses the next ring slot (the sampler's future is deterministic; its

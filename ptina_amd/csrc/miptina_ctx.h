@@ -28,9 +28,8 @@ MPT_KERNEL_API hipError_t mpt_launch_preview_fast(const MptRenderParams *, int g
 MPT_KERNEL_API hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
                                               int keep, int write_x, hipStream_t);
-MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int nx, int ny, int x0, int x1,
-                                         int stripe_w, int stripe_pitch,
-                                         int nchunks, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int ny, int x0, int x1,
+                                         int stripe_w, int stripe_pitch, int ccols, int nframes, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_transpose_nodes(const MptVec4 *in, MptVec4 *out, int ni, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_probe(double *out, int threads, size_t lds_bytes, hipStream_t);

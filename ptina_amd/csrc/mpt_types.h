@@ -61,7 +61,8 @@ struct MptRenderParams {
     float sobol_inv_dim;                    // 1 / sobol_dim (quotient estimate of the draw index reduction)
     int32_t nitems, tile_w_shift, tile_h_shift, pad2;   // fast build: (2^w x 2^h tile, chunk) work items of this launch
     // columns rendered: x = x0 + s*stripe_pitch + w, w < stripe_w, x < x1 (one contiguous slab: stripe_w = 2^30)
-    int32_t stripe_w, stripe_pitch, pad3, pad4;
+    int32_t stripe_w, stripe_pitch;
+    int32_t partial_stride, pad4;           // float4 per frame of the sample slab = (tile-padded columns of the share) * ny
     float world_fac[4];
     float v2w[16];
     const MptVec4 *snode;
@@ -77,7 +78,7 @@ struct MptRenderParams {
     MptVec4 *film0;                          // pass 0 (path) / unused by preview
     MptVec4 *film1;                          // pass 1 (albedo)
     MptVec4 *film2;                          // pass 2 (normal)
-    MptVec4 *partial;                        // fast build: per-sample radiance [nframes][nx*ny]
+    MptVec4 *partial;                        // fast build: per-sample radiance [nframes][columns of the share][ny]
     unsigned long long *counters;            // mpt_counters when counting, else unused
     unsigned int *work_counter;              // persistent kernels: 8 per-range item counters
     int *stack_spill;                        // wide kernel: 88 overflow stack entries per lane of the grid

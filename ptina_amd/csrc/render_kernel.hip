@@ -182,7 +182,7 @@ DEV void trace_pixel(const MptRenderParams &p, const TR &tr, int i, int j, int f
 // added iff nothing was hit and the closest-hit traversal of the next bounce starts at once, so
 // there is one shading stage per bounce and the order of additions into `result` is the
 // reference's (path.py:31-56).  Rays, samples and sums do not depend on the schedule: each sample's
-// radiance goes to p.partial[frame][pixel] and the combine pass adds frames in order.
+// radiance goes to p.partial[frame][column of the share][y] and the combine pass adds frames in order.
 enum { ST_NODE = 0, ST_LEAF = 1, ST_DONE = 2, ST_NEW = 3, ST_DEAD = 4 };   // DONE: this lane's ray is finished
 
 // Per-lane state: live across the whole loop, so every word costs a VGPR for the kernel's lifetime.
@@ -289,7 +289,7 @@ DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, STACK &stk, V3
         if (p.n < 2) L.st = ST_DONE;
     } else {
         MptVec4 o; o.x = L.result.x; o.y = L.result.y; o.z = L.result.z; o.w = 1.0f;
-        p.partial[(size_t)L.frame * ((size_t)p.nx * p.ny) + L.pix] = o;      // path.py:93, summed by combine
+        p.partial[(size_t)L.frame * (size_t)p.partial_stride + L.pix] = o;   // path.py:93, summed by combine
         L.st = ST_NEW;
     }
 }
@@ -509,7 +509,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     const int tws = p.tile_w_shift, ths = p.tile_h_shift, tps = tws + ths;
     const int t8y = (p.ny + (1 << ths) - 1) >> ths;
     int S = 0, next = 0;                            // wave-uniform: current pool = 64*frames samples; next unassigned
-    int ti = 0, tj = 0, f0 = 0;
+    int ti = 0, tj = 0, f0 = 0, tx_cur = 0;
     bool more = true;
     LaneState L;
     L.st = ST_NEW;
@@ -565,7 +565,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                     int tile = item / p.nchunks, chunk = item - tile * p.nchunks;
                     int tx = tile / t8y, ty = tile - tx * t8y;
                     int tps_x = p.stripe_w >> tws, st = tx / tps_x;      // stripe of this tile column
-                    ti = p.x0 + st * p.stripe_pitch + ((tx - st * tps_x) << tws); tj = ty << ths;
+                    ti = p.x0 + st * p.stripe_pitch + ((tx - st * tps_x) << tws); tj = ty << ths; tx_cur = tx;
                     f0 = chunk * p.chunk;
                     S = (min(f0 + p.chunk, p.nframes) - f0) << tps;
                     next = 0;
@@ -582,7 +582,8 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                         int i = ti + (q >> ths), j = tj + (q & ((1 << ths) - 1));
                         if (i < p.x1 && j < p.ny) {
                             L.frame = f0 + (smp >> tps);
-                            L.pix = i * p.ny + j;
+                            // slot in this launch's sample slab: the columns of the share packed side by side
+                            L.pix = ((tx_cur << tws) + (q >> ths)) * p.ny + j;
                             lane_begin<COUNT>(p, L, stk, i, j, cnt);
                         }
                     }
