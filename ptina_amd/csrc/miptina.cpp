@@ -11,6 +11,12 @@
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told
 // otherwise) and streams that share one are serialised, so ask for more before the runtime starts --
 // eight of our own plus room for what RCCL creates -- unless the user has chosen a value.
+// The runtime reads the variable when it initialises: this constructor runs at dlopen, which is early enough in
+// every process that loads libmiptina before touching HIP (the Python package does).  Where HIP is already up --
+// another HIP user in the process, or rocprofv3 --pmc, whose preloaded tool initialises the GPU first -- the
+// request has no effect and streams fold onto 4 hardware queues: launches of a multi-GPU share then overlap
+// less (G = 4 is slower than G = 1 there), results do not change.  Export GPU_MAX_HW_QUEUES
+// yourself in such a process.
 __attribute__((constructor)) static void mpt_want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
 
 // ------------------------------------------------------------------ errors

@@ -215,6 +215,9 @@ DEV Rng lane_rng(const MptRenderParams &p, const LaneState &L) {
 // Python's floor-mod of the proxy counter by the table size (sobol.py:123), without an integer division:
 // an estimate of the quotient from the float reciprocal, then the remainder is put right exactly
 DEV int reduce_mod_dim(int h, int dim, float inv_dim) {
+    // the float estimate is off by |h| / dim * 2^-23 at most: below one for tables of >= 1024 dimensions (the
+    // reference's has 21201); smaller ones take the division (wave-uniform branch)
+    if (dim < 1024) return pymod(h, dim);
     int q = (int)floorf((float)h * inv_dim);                       // within +-1 of floor(h / dim)
     int r = (int)((unsigned)h - (unsigned)q * (unsigned)dim);      // exact modulo 2^32, and the true remainder is small
     if (r < 0) r += dim;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs a sequence of GPU steps on the gpurun box, each under its own timeout; a step that fails
 # an assertion does not stop the sequence, a step that TIMES OUT does (no GPU work after a hang).
-# usage: tools/gpu_round.sh step1 step2 ...   (steps: diag diag_parity diag_timing tests bench prof smoke)
+# usage: tools/gpu_round.sh step1 step2 ...   (steps: see the case list; ABLIBS='a b' ... ablibs benches ptina_amd/libmiptina_a.so, _b.so)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 run() {  # name seconds command...
@@ -36,11 +36,7 @@ for step in "$@"; do
     sync_sweep)  run sync_sweep 300 python tools/gpu_diag.py sync_sweep ;;
     ubench)      run ubench 200 tools/microbench/valu_microbench --json ;;
     ubench_pmc)  run ubench_pmc 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/ubench_pmc -- tools/microbench/valu_microbench ;;
-    bench_noslp) MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_noslp.so run bench_noslp 300 python bench.py --no-pmc --no-cpu-baseline ;;
     bench_quick) run bench_quick 300 python bench.py --no-pmc --no-cpu-baseline ;;
-    bench_ab)    MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_ab.so run bench_ab 300 python bench.py --no-pmc --no-cpu-baseline ;;
-    bench_ab2)   MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_ab2.so run bench_ab2 300 python bench.py --no-pmc --no-cpu-baseline ;;
-    bench_ab3)   MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_ab3.so run bench_ab3 300 python bench.py --no-pmc --no-cpu-baseline ;;
     ablibs)      for L in $ABLIBS; do MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_$L.so run ab_$L 300 python bench.py --no-pmc --no-cpu-baseline; done ;;
     tests_fast)  run tests_fast 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'fast_build or strict_build or full_size or batching or pipelining or lds_and_gather or lobes or ordered' ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
