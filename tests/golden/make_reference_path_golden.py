@@ -2,23 +2,25 @@
 '''
 End-to-end cross-check vectors: the reference's OWN renderer source -- PathEngine._render / do_render /
 path_trace (engine/path.py:18-93), LinearBVH build + intersect (tree/lbvh.py), GlobalStack (stack.py),
-ModelPool / MaterialPool / LightPool / WorldLight / Camera / FilmTable / SobolSampler -- imported from
+ModelPool / MaterialPool / ImagePool / LightPool / WorldLight / Camera / FilmTable / SobolSampler -- imported from
 /root/reference and executed as plain Python on numpy scalars, with the `taichi` stand-in of
 tests/golden/taichi_standin providing fields (numpy storage), i32 wrap-around and Matrix.  Small films of
-two scenes are rendered with exams/benchmark.py's call sequence in single and double precision; the raw
+three scenes are rendered with exams/benchmark.py's call sequence in single and double precision; the raw
 film sums, the LBVH arrays and the Sobol state go to tests/golden/reference_path.npz, and
 tests/test_reference_path_cpu.py holds the C oracle to them.
 
 Build container only; takes a few minutes (the Sobol update is a Python loop over 21201 dimensions).
 
 What is emulated rather than executed (all of it Taichi's compile-time machinery, none of it renderer math):
-  * kernel-scope builtins: Taichi rewrites int / min / max inside kernels to element-wise casts and
-    ti.min / ti.max; here those three names are bound in ptina.common's namespace before the other modules
-    star-import it (scalars behave exactly like the Python builtins; int() yields an i32 that wraps);
+  * kernel-scope builtins: Taichi rewrites int / float / min / max inside kernels to element-wise casts and
+    ti.min / ti.max; here those names are bound in the namespaces of the modules whose @ti.func bodies use them
+    (ptina.common, ptina.sampling, ptina.tree.lbvh), after every module -- host code included -- has been imported
+    (scalars behave exactly like the Python builtins; int() yields an i32 that wraps);
   * the `subscript` protocol of is_taichi_class objects (ModelPool()[i], FilmTable()[id, x, y]): mapped to
     __getitem__ / __setitem__;
-  * ModelPool.from_numpy writes field elements through `self[i][k] = ...` (an lvalue only inside Taichi):
-    the vertex / mtlid arrays are stored into the fields directly;
+  * ModelPool.from_numpy / ImagePool.from_numpy write field elements through `self[i][k] = ...` (an lvalue only
+    inside Taichi): the vertex / mtlid / texel arrays are stored into the fields directly (image ids and base offsets
+    come from the reference's own allocators);
   * pysobol (un-vendored dependency, absent): a module of that name serving the same public Joe-Kuo
     new-joe-kuo-6.21201 table from ptina_amd/data/joe_kuo_21201.npz in pysobol's flat [s, a, m_1..m_s] format;
   * the double-precision run gets the f32-rounded scene parameters the oracle's C API takes (camera matrix,
@@ -49,14 +51,31 @@ CASES = {
     # name: (scene key, film nx, ny, spp)
     's34_default_light': ('s34', 14, 12, 3),
     's34_lobes_two_lights': ('lobes', 12, 10, 2),
+    's34_textures_env': ('textured', 12, 10, 2),
 }
 
 
 def scene_of(key):
+    '''-> (scene, lights or None for the default light, world (fac, tex))'''
     sys.path.insert(0, ROOT)
     from ptina_amd import scenes
     if key == 's34':
-        return scenes.scene_s34(), None
+        return scenes.scene_s34(), None, ([0.1, 0.1, 0.1, 0.1], -1)
+    if key == 'textured':
+        # image.py:137-148 + common.py:183-192 (wrap-around bilinear), mtllib.py:30-38 (factor x texel),
+        # light/world.py:22-29 + common.py:234-239 (equirect environment with the Blender axis swap)
+        v, m, mats, _ = scenes.scene_s34()
+        rng = np.random.default_rng(5)
+        checker = np.ones((8, 8, 3), np.float32)
+        checker[::2, 1::2] = 0.2
+        checker[1::2, ::2] = 0.2
+        mats = [list(x) for x in mats]
+        mats[0][0] = ([1.0, 0.9, 0.8], 1)                  # walls: base colour x checker
+        mats[3][0] = ([0.9, 0.9, 1.0], 1)
+        mats[3][2] = (0.9, 2)                              # roughness x grey noise
+        mats[4][1] = (0.8, 2)                              # metallic x grey noise
+        images = [scenes.env_image(32, 16), checker, rng.uniform(0.3, 1.0, (5, 7)).astype(np.float32)]
+        return (v, m, mats, images), None, ([1.0, 1.0, 1.0, 1.0], 0)
     # every Disney lobe on the two boxes + an area light and a point light (first-hit `break`, light index pick)
     v, m, mats, _ = scenes.scene_s34()
     mats = list(mats)
@@ -67,7 +86,7 @@ def scene_of(key):
     point = np.eye(4)
     point[:3, 3] = (-1.2, 2.5, 1.0)
     lights = [(area, np.array([12.0, 11.0, 9.0]), 0.7, 'AREA'), (point, np.array([20.0, 20.0, 24.0]), 0.3, 'POINT')]
-    return (v, m, mats, []), lights
+    return (v, m, mats, []), lights, ([0.1, 0.1, 0.1, 0.1], -1)
 
 
 def child(prec):
@@ -92,22 +111,31 @@ def child(prec):
     sys.modules['pysobol.data'] = pysobol.data
 
     import ptina.common as C
-    C.int, C.min, C.max = ti.ti_int, ti.min, ti.max      # kernel-scope builtins (float() only occurs in the texture path)
     from ptina.things import init_things, Stack, Camera, BVHTree, ImagePool, ModelPool, LightPool, WorldLight, \
         MaterialPool, FilmTable
     from ptina.engine.path import PathEngine
     from ptina.sampling.sobol import SobolSampler
+    from ptina.image import Image
     import ptina.sampling as SAMP
+    import ptina.tree.lbvh as LBVH
+    import ptina.tools.matrix  # noqa: F401  (host code, imported lazily by Camera(): must star-import common BEFORE the names below exist)
+    # kernel-scope builtins, bound only in the modules whose @ti.func bodies use them (host code keeps Python's):
+    # common.py ifloor / iceil / clamp / bilerp, sampling wanghash*, lbvh getBoundingBox / genAABBSubstep
+    C.int, C.float, C.min, C.max = ti.ti_int, ti.ti_float, ti.min, ti.max
+    SAMP.int = ti.ti_int
+    LBVH.min, LBVH.max = ti.min, ti.max
     assert SAMP.wanghash2(3, 5) == -1977258872 and isinstance(SAMP.wanghash2(3, 5), ti.I32)
 
     # the `subscript` protocol of is_taichi_class objects
     ModelPool.__getitem__ = lambda self, i: self.subscript(i)
     FilmTable.__getitem__ = lambda self, ix: self.subscript(*ix)
     FilmTable.__setitem__ = lambda self, ix, v: self.root.__setitem__((ix[0], ix[1] * self.ny + ix[2]), v)
+    ImagePool.__getitem__ = lambda self, ix: self.subscript(*ix)
+    Image.__getitem__ = lambda self, I: self.subscript(*I)
 
     out = {}
     t0 = time.time()
-    init_things(max_faces=2**8, max_texels=2**8, max_materials=2**4, max_textures=2**2, max_lights=2**3,
+    init_things(max_faces=2**8, max_texels=2**10, max_materials=2**4, max_textures=2**2, max_lights=2**3,
                 max_filmsize=2**10, max_filmpasses=3)
     eng = PathEngine()                        # SobolSampler(): vgrid + reset (64 skipped updates)
     sob = SobolSampler()
@@ -117,7 +145,7 @@ def child(prec):
     sobol_state = (sob.X.to_numpy(), sob.P.to_numpy(), int(sob.time[None]))
 
     for name, (key, nx, ny, spp) in CASES.items():
-        scene, lights = scene_of(key)
+        scene, lights, world = scene_of(key)
         vertices, mtlids, materials, images = scene
         # rewind the sampler to its state after reset() (what a fresh process would have)
         sob.X.from_numpy(sobol_state[0])
@@ -130,6 +158,24 @@ def child(prec):
         ModelPool().mtlids.from_numpy(np.asarray(mtlids, np.int32))
         ModelPool().nfaces[None] = n
         MaterialPool().load(materials)
+        # ImagePool.load / load_one, image.py:69-96: same conversions, ids and base offsets from the reference's
+        # allocators; the texels go into the field directly (from_numpy writes through lvalue subscripts)
+        pool = ImagePool()
+        pool.mman.reset()
+        pool.idman.reset()
+        for arr in images:
+            arr = np.asarray(arr)
+            if arr.dtype == np.uint8:
+                arr = arr.astype(np.float32) / 255
+            if arr.ndim == 2:
+                arr = arr[:, :, None]
+            if arr.shape[2] == 1:
+                arr = np.stack([arr[:, :, 0]] * 3, axis=2)
+            if arr.shape[2] == 3:
+                arr = np.concatenate([arr, np.ones(arr.shape[:2] + (1,))], axis=2)
+            iid = pool.new(arr.shape[0], arr.shape[1])
+            base = int(pool.base[iid])
+            pool.root.data[base:base + arr.shape[0] * arr.shape[1]] = arr.astype(np.float32).reshape(-1, 4)
         BVHTree().build()
         Camera().set_perspective(np.array([
             [1.73205081e+00, 0.00000000e+00, 0.00000000e+00, 1.01348227e-02],
@@ -137,7 +183,7 @@ def child(prec):
             [0.00000000e+00, -1.00020002e-05, -1.00020002e+00, 5.27350023e+00],
             [0.00000000e+00, -1.00000000e-05, -1.00000000e+00, 5.37243564e+00],
         ]))                                   # exams/benchmark.py:18-23
-        WorldLight().set([0.1, 0.1, 0.1, 0.1], -1)
+        WorldLight().set(*world)
         if lights is not None:
             LightPool().clear()
             for l in lights:
