@@ -224,6 +224,13 @@ def child(prec):
         film = FilmTable().root.to_numpy()[0, :nx * ny].astype(np.float64)
         assert np.all(film[:, 3] == spp)
         out[f'{name}/film'] = film
+        # PreviewEngine.render, engine/preview.py:18-41: albedo -> pass 1, shading normal -> pass 2, two frames
+        from ptina.engine.preview import PreviewEngine
+        for _ in range(2):
+            PreviewEngine().render()
+        root = FilmTable().root.to_numpy()
+        out[f'{name}/preview_albedo'] = root[1, :nx * ny].astype(np.float64)
+        out[f'{name}/preview_normal'] = root[2, :nx * ny].astype(np.float64)
         out[f'{name}/size'] = np.array([nx, ny, spp], np.int64)
         out[f'{name}/sobol_time'] = np.int64(sob.time[None])
         print(prec, name, 'rendered in %.0f s; mean radiance' % (time.time() - t1), film[:, :3].mean() / spp, flush=True)

@@ -68,7 +68,15 @@ def test_oracle_renders_what_the_reference_source_renders(gold, oracle_mod, prec
     worst = float(err.max())
     print(f'{prec} {name}: worst relative difference of a pixel sum {worst:.2e}, mean radiance {want[:, :3].mean() / spp:.4f}')
     assert worst <= (1e-12 if prec == 'f64' else 1e-4), f'{prec} {name}: worst relative difference {worst:.2e}'
-    assert int(gold[f'{prec}/{name}/sobol_time']) == 64 + 1 + spp
+    assert int(gold[f'{prec}/{name}/sobol_time']) == 64 + 1 + spp + 2      # recorded after the two preview frames below
+    # ---- engine/preview.py:18-41, two more frames on the same sampler: albedo -> pass 1, normal -> pass 2
+    o.render_preview()
+    o.render_preview()
+    for pas, key in ((1, 'preview_albedo'), (2, 'preview_normal')):
+        got, ref = o.get_film_real(pas).astype(np.float64), gold[f'{prec}/{name}/{key}']
+        assert np.array_equal(got[:, 3], ref[:, 3]) and np.all(got[:, 3] == 2)
+        e = float(np.abs(got[:, :3] - ref[:, :3]).max())
+        assert e <= (1e-12 if prec == 'f64' else 2e-6), f'{prec} {name} {key}: max difference {e:.2e}'
 
 
 def test_cases_exercise_the_interesting_paths(gold):
