@@ -135,7 +135,7 @@ def child(prec):
 
     out = {}
     t0 = time.time()
-    init_things(max_faces=2**8, max_texels=2**10, max_materials=2**4, max_textures=2**2, max_lights=2**3,
+    init_things(max_faces=2**10, max_texels=2**10, max_materials=2**4, max_textures=2**2, max_lights=2**3,
                 max_filmsize=2**10, max_filmpasses=3)
     eng = PathEngine()                        # SobolSampler(): vgrid + reset (64 skipped updates)
     sob = SobolSampler()
@@ -235,6 +235,22 @@ def child(prec):
         out[f'{name}/sobol_time'] = np.int64(sob.time[None])
         print(prec, name, 'rendered in %.0f s; mean radiance' % (time.time() - t1), film[:, :3].mean() / spp, flush=True)
 
+    # tree/lbvh.py:169-305 alone on the 978-triangle benchmark scene (build only: a render would take hours here)
+    if prec == 'f32':
+        from ptina_amd import scenes
+        vertices, mtlids, _, _ = scenes.scene_s978()
+        n = mtlids.shape[0]
+        ModelPool().vertices.from_numpy(np.asarray(vertices, np.float32).reshape(-1))
+        ModelPool().mtlids.from_numpy(np.asarray(mtlids, np.int32))
+        ModelPool().nfaces[None] = n
+        BVHTree().build()
+        tree = BVHTree()
+        out['s978/tree/child'] = tree.child.to_numpy()[:n - 1].astype(np.int64)
+        out['s978/tree/leaf'] = tree.leaf.to_numpy()[:n].astype(np.int64)
+        out['s978/tree/mc'] = tree.mc.to_numpy()[:n].astype(np.int64)
+        out['s978/tree/bmin'] = tree.bmin.to_numpy()[:n - 1].astype(np.float64)
+        out['s978/tree/bmax'] = tree.bmax.to_numpy()[:n - 1].astype(np.float64)
+        assert len(set(out['s978/tree/mc'].tolist())) == n, 'S978 is expected to have distinct Morton codes'
     np.savez_compressed(os.path.join(HERE, f'_reference_path_{prec}.npz'), **out)
 
 

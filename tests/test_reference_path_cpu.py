@@ -87,3 +87,19 @@ def test_cases_exercise_the_interesting_paths(gold):
         assert lum.max() > 2.5 * lum.min() and lum.max() > 1.0, name
     scene, lights, _ = G.scene_of('lobes')
     assert {l[3] for l in lights} == {'AREA', 'POINT'}
+
+
+def test_lbvh_of_the_benchmark_scene_is_the_reference_sources(gold, oracle_mod):
+    '''tree/lbvh.py:169-305 run by the reference's own source on the 978-triangle scene of BASELINE configs[1]:
+    Morton codes, leaf order, children and boxes equal the oracle's (tests/test_parity_gpu.py holds the
+    device-built tree to the oracle's in turn)'''
+    from helpers import setup_oracle
+    from ptina_amd import scenes
+    scene = scenes.scene_s978()
+    o = setup_oracle(oracle_mod, scene, 16, 16, threads=1)
+    n = scene[1].shape[0]
+    t = o.get_tree(n)
+    for k in ('mc', 'leaf', 'child'):
+        assert np.array_equal(t[k].astype(np.int64), gold[f'f32/s978/tree/{k}']), k
+    for k in ('bmin', 'bmax'):
+        assert np.array_equal(t[k].astype(np.float64), gold[f'f32/s978/tree/{k}']), k
