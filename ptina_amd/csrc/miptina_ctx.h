@@ -92,7 +92,8 @@ struct mpt_ctx {
     int fast_depth = 0;                  // tree the fast build walks (SAH or LBVH)
     int tree_kind = 1;                   // fast build: 1 = SAH re-partition of the LBVH's leaves, 0 = the LBVH itself
     int gpu_build = 1;                   // 1 = LBVH built on the device (lbvh_build.hip), 0 = host build
-    int sah_max = 1 << 18;               // above this many faces the fast build walks the LBVH itself
+    int sah_max = 1 << 22;               // above this many faces the fast build walks the LBVH itself (the threaded host
+                                         // SAH pass takes ~0.2 s at 1 M faces; it was 1.5 s on one core, hence 2^18 in round 1)
     bool host_tree_valid = false;        // h_child/h_leaf/... mirror the device tree (lazily downloaded)
     // device-side build workspace
     float *d_verts = nullptr; int *d_mtlids = nullptr; size_t d_model_cap = 0;

@@ -2,6 +2,8 @@
 // SAH re-partition for the fast build, and the glue around the device build (lbvh_build.hip).
 
 #include "miptina_ctx.h"
+#include <atomic>
+#include <thread>
 
 // ------------------------------------------------------------------ LBVH build (tree/lbvh.py:169-305)
 // Same algorithm as the reference (30-bit Morton codes of centroids, sorted, Karras hierarchy,
@@ -131,6 +133,41 @@ struct SahBuild {
         return m;
     }
 
+    std::atomic<int> adepth{0};
+
+    // A range [b, e) of k leaf slots becomes a subtree of exactly k - 1 internal nodes, so in DFS pre-order the
+    // node of the range is `me`, its left subtree starts at me + 1 and its right subtree at me + (m - b): the
+    // numbering needs no shared counter, subtrees touch disjoint parts of idx / child / blo / bhi, and the big
+    // ones are built by threads of their own (1 M leaves: 1.5 s on one core).  The result does not depend on
+    // how the work was split.
+    void build_range(int b, int e, int me, int dep, int spawn_levels) {
+        for (;;) {
+            int d0 = adepth.load(std::memory_order_relaxed);
+            while (dep > d0 && !adepth.compare_exchange_weak(d0, dep, std::memory_order_relaxed)) {}
+            float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (int t = b; t < e; t++)
+                for (int q = 0; q < 3; q++) { l[q] = std::min(l[q], lo[(size_t)idx[t] * 3 + q]); h[q] = std::max(h[q], hi[(size_t)idx[t] * 3 + q]); }
+            for (int q = 0; q < 3; q++) { blo[(size_t)me * 3 + q] = l[q]; bhi[(size_t)me * 3 + q] = h[q]; }
+            const int m = split(b, e);
+            const int left = me + 1, right = me + (m - b);
+            if (m - b == 1) child[(size_t)me * 2 + 0] = ~idx[b]; else child[(size_t)me * 2 + 0] = left;
+            if (e - m == 1) child[(size_t)me * 2 + 1] = ~idx[m]; else child[(size_t)me * 2 + 1] = right;
+            const bool has_l = m - b > 1, has_r = e - m > 1;
+            if (has_l && has_r) {
+                if (spawn_levels > 0 && std::min(m - b, e - m) > 16384) {
+                    std::thread th([=] { build_range(b, m, left, dep + 1, spawn_levels - 1); });
+                    build_range(m, e, right, dep + 1, spawn_levels - 1);
+                    th.join();
+                    return;
+                }
+                build_range(b, m, left, dep + 1, 0);          // the smaller worlds recurse; depth is bounded by the tree's
+                b = m; me = right; dep += 1; spawn_levels = 0;
+            } else if (has_l) { e = m; me = left; dep += 1; }
+            else if (has_r) { b = m; me = right; dep += 1; }
+            else return;
+        }
+    }
+
     void run() {
         const int ni = n > 1 ? n - 1 : 0;
         child.assign((size_t)std::max(ni, 1) * 2, 0);
@@ -140,26 +177,9 @@ struct SahBuild {
         for (int i = 0; i < n; i++) idx[i] = i;
         depth = 0;
         if (ni == 0) return;
-        struct Item { int b, e, parent, which, depth; };
-        std::vector<Item> st;
-        st.push_back({ 0, n, -1, 0, 1 });
-        int next_node = 0;
-        while (!st.empty()) {
-            Item it = st.back(); st.pop_back();
-            int me = next_node++;
-            if (it.parent >= 0) child[(size_t)it.parent * 2 + it.which] = me;
-            depth = std::max(depth, it.depth);
-            float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
-            for (int t = it.b; t < it.e; t++)
-                for (int q = 0; q < 3; q++) { l[q] = std::min(l[q], lo[(size_t)idx[t] * 3 + q]); h[q] = std::max(h[q], hi[(size_t)idx[t] * 3 + q]); }
-            for (int q = 0; q < 3; q++) { blo[(size_t)me * 3 + q] = l[q]; bhi[(size_t)me * 3 + q] = h[q]; }
-            int m = split(it.b, it.e);
-            // right first on the stack so the left subtree gets the next indices (pre-order)
-            if (it.e - m == 1) child[(size_t)me * 2 + 1] = ~idx[m];
-            else st.push_back({ m, it.e, me, 1, it.depth + 1 });
-            if (m - it.b == 1) child[(size_t)me * 2 + 0] = ~idx[it.b];
-            else st.push_back({ it.b, m, me, 0, it.depth + 1 });
-        }
+        adepth.store(0);
+        build_range(0, n, 0, 1, 5);                            // up to 2^5 subtrees in flight
+        depth = adepth.load();
     }
 };
 
