@@ -78,8 +78,8 @@ void mpt_destroy(mpt_ctx *ctx);
  * persistent kernel when the scene fits a CU's 160 KiB LDS, default; 0 = always gather from HBM/L2).
  * "tree" (fast build: 1 = SAH re-partition of the LBVH's leaves, default; 0 = walk the LBVH itself;
  * takes effect at the next mpt_build_tree), "tile_w_shift"/"tile_h_shift" (work-item tile 2^w x 2^h pixels),
- * "wide" (scenes that do not fit LDS: 1 = walk the fast tree collapsed into 4-wide nodes, 0 = the binary tree,
- * -1 = decide by the expected number of fetches per ray, default), "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
+ * "wide" (scenes that do not fit LDS: 1 = walk the fast tree collapsed into 4-wide nodes, default; 0 = the
+ * binary tree), "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
  * walks the LBVH itself; default 2^22), "grid_div" (each launch takes 1/G of the CUs so that G launches are resident
  * in different phases; 0 = choose by samples per lane, default), "pipe_depth" (batches in flight,
  * 2..6; 0 = auto), "lds_block" (lanes per persistent workgroup of the LDS kernel, diagnostics),

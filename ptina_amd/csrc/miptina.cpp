@@ -277,8 +277,7 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
     } else if (k == "node_soa") {
         c->node_soa = value ? 1 : 0;
     } else if (k == "wide") {
-        if (value < -1 || value > 1) return fail("wide must be -1 (auto), 0 or 1");
-        c->use_wide = value;
+        c->use_wide = value ? 1 : 0;
     } else if (k == "tree") {
         if (value != 0 && value != 1) return fail("tree must be 0 (LBVH) or 1 (SAH)");
         if (value != c->tree_kind) { c->tree_kind = value; c->tree_valid = false; }
@@ -721,10 +720,10 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     const int usable_cus = std::max(c->num_cus - reserve, 1);
     const int launch_cus = std::max(usable_cus / std::max(c->cur_div, 1), 1);   // G launches never claim more than usable_cus
     // scenes that do not fit LDS walk the 4-wide nodes (option "wide"; built by mpt_build_tree unless too deep)
-    // A wide step costs 2.3x the VALU instructions of a binary one (four box tests and a sorting network: ~135
-    // against 58) and the kernel is issue-bound, so the collapse pays only where it removes more than half of
-    // the expected fetches (MI355X: 99 k-triangle mesh, ratio 0.46: +10 %; 1 M-triangle soup, 0.51: -7 %).
-    const bool wide_pays = c->use_wide == 1 || (c->use_wide < 0 && c->wide_ratio <= 0.48f);
+    // A wide step costs ~2x the VALU instructions of a binary one (four slab tests and a sorting network) and makes
+    // half the dependent fetches; with the planes picked by direction sign it wins on both big configurations
+    // (MI355X: C4 963 -> 1135 Msamples/s, C5 494 -> 520), so it is the default wherever the collapse was built.
+    const bool wide_pays = c->use_wide != 0;
     const bool wide_kernel = fast && !lds_kernel && wide_pays && c->wide_nodes > 0;
     int wide_blocks = 0;
     if (wide_kernel) {

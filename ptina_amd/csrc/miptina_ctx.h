@@ -110,8 +110,8 @@ struct mpt_ctx {
     MptVec4 *wnode = nullptr; size_t wnode_cap = 0;   // 4-wide nodes of the fast tree (gather kernel), 8 float4 each
     int wide_nodes = 0, wide_depth = 0;               // 0 nodes: not built (scene fits LDS, or too deep)
     float wide_ratio = 1.f;                           // expected fetches per ray, wide / binary (surface-area sums)
-    int use_wide = -1;                                // option "wide": 1 walk the 4-wide nodes when the scene does not fit LDS,
-                                                      // 0 the binary tree, -1 decide by wide_ratio (mpt_flush)
+    int use_wide = 1;                                 // option "wide": 1 walk the 4-wide nodes when the scene does not fit LDS
+                                                      // (default), 0 the binary tree
     int *stack_spill = nullptr; size_t stack_spill_cap = 0;
     int node_soa = 0;                                 // option "node_soa" (layout A/B): binary gather kernel reads an SoA transpose
     MptVec4 *fnode_soa = nullptr; size_t fnode_soa_cap = 0; bool fnode_soa_valid = false;

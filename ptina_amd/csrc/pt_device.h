@@ -189,6 +189,7 @@ DEV bool box_strict(V3 lo, V3 hi, V3 ro, V3 rd) {
 // dwords (conflict-free); replaces GlobalStack's [thread][level] rows in global memory, stack.py:10-60
 struct Stack {
     static constexpr int SENTINEL = (int)0x80000000;   // bottom-of-stack marker (never a node or leaf id)
+    static constexpr int PLANE_OFF = 0;                // (the binary gather kernel takes min / max of both planes)
     int *base;                 // &lds[threadIdx.x]
     int sp;
     DEV void push(int v) { base[sp * MPT_BLOCK] = v; sp++; }
@@ -223,9 +224,15 @@ struct GlobalScene {
 struct WideScene {
     static constexpr bool WIDE = true, SIGNED_PLANES = false;
     const MptVec4 *wnode, *tgeo;
-    DEV void node4(int i, MptVec4 &lx, MptVec4 &hx, MptVec4 &ly, MptVec4 &hy, MptVec4 &lz, MptVec4 &hz, MptVec4 &id) const {
-        const MptVec4 *nd = wnode + (size_t)i * 8;
-        lx = nd[0]; hx = nd[1]; ly = nd[2]; hy = nd[3]; lz = nd[4]; hz = nd[5]; id = nd[6];
+    // entry (n*) and exit (f*) planes of the four children, picked by the ray's direction signs: o* is 0 for a ray
+    // going up the axis and 16 (bytes: the next float4) for one going down -- still seven dwordx4 gathers
+    DEV void node4(int i, int ox, int oy, int oz, MptVec4 &nx, MptVec4 &fx, MptVec4 &ny, MptVec4 &fy, MptVec4 &nz,
+                   MptVec4 &fz, MptVec4 &id) const {
+        const char *nd = (const char *)(wnode + (size_t)i * 8);
+        nx = *(const MptVec4 *)(nd + ox);      fx = *(const MptVec4 *)(nd + (ox ^ 16));
+        ny = *(const MptVec4 *)(nd + 32 + oy); fy = *(const MptVec4 *)(nd + 32 + (oy ^ 16));
+        nz = *(const MptVec4 *)(nd + 64 + oz); fz = *(const MptVec4 *)(nd + 64 + (oz ^ 16));
+        id = *(const MptVec4 *)(nd + 96);
     }
     DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2, MptVec4 &g3) const {
         const MptVec4 *g = tgeo + (size_t)slot * 4;
@@ -237,6 +244,7 @@ struct WideScene {
 // levels live in LDS like Stack's, the (rare) rest in a per-lane strip of global memory
 struct SpillStack {
     static constexpr int SENTINEL = (int)0x80000000;
+    static constexpr int PLANE_OFF = 16;               // bytes between the lo and hi float4 of an axis in a wide record
     static constexpr int CAP = 40, SPILL = 88;    // 40 levels x 256 lanes x 4 B = 40 KiB of LDS: four workgroups per CU
     int *base;                 // &lds[threadIdx.x]
     int *spill;                // this lane's SPILL entries
@@ -295,6 +303,7 @@ struct LdsScene {
 #define MPT_LDS_BLOCK 1024
 struct Stack16 {
     static constexpr int SENTINEL = -32768;            // leaf ids are ~slot >= -32767 (n < 32768)
+    static constexpr int PLANE_OFF = 8;                // bytes between the {lo, lo} and {hi, hi} pairs of an axis in LDS
     LdsShortPtr base;          // &lds16[threadIdx.x]
     int sp;
     DEV void push(int v) { base[sp * MPT_LDS_BLOCK] = (short)v; sp++; }

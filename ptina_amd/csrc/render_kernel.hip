@@ -199,7 +199,7 @@ struct LaneState {
     V3 direct;                 // shadow ray in flight: candidate direct light, added if unoccluded
     // ray being traversed (closest: the path ray; shadow: hitpos -> light)
     V3 to, td, inv, oinv;
-    int offx, offy, offz;      // LDS kernel: 8 where the ray goes down the axis, else 0 (LdsScene::node_planes)
+    int offx, offy, offz;      // byte offset of the entry planes of each axis in a node record (LDS and wide kernels)
     float tbest;               // closest: best depth so far; shadow: li.dis
     int curr, sp, hidx;        // hidx: leaf slot of the hit so far, -1 = none (closest) / any occluder found (shadow)
     float hu, hv;
@@ -270,7 +270,10 @@ DEV void lane_start_ray(LaneState &L, STACK &stk, V3 o, V3 d, float tmax, bool s
     L.to = o; L.td = d;
     L.inv = v3(m_rcp(d.x), m_rcp(d.y), m_rcp(d.z));
     L.oinv = o * L.inv;
-    L.offx = (__float_as_int(L.inv.x) >> 28) & 8; L.offy = (__float_as_int(L.inv.y) >> 28) & 8; L.offz = (__float_as_int(L.inv.z) >> 28) & 8;
+    // which of an axis' two planes the ray enters through: offset of that plane in the node record
+    L.offx = __float_as_int(L.inv.x) < 0 ? STACK::PLANE_OFF : 0;
+    L.offy = __float_as_int(L.inv.y) < 0 ? STACK::PLANE_OFF : 0;
+    L.offz = __float_as_int(L.inv.z) < 0 ? STACK::PLANE_OFF : 0;
     L.tbest = tmax; L.shadow = shadow ? 1 : 0; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f;
     stk.sp = 0;
     stk.push(STACK::SENTINEL);
@@ -344,20 +347,23 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     L.st = classify<STACK>(next);
 }
 
-// The same step through a 4-wide node: four box tests on one 128-B record, the children that are hit sorted
+// The same step through a 4-wide node: four slab tests (planes picked by the ray's direction signs) on one 128-B
+// record, the children that are hit sorted
 // by entry distance (a five-comparator network on (distance bits, id) pairs; a miss sorts last), the nearest
 // taken next and the others pushed farthest first.
 template <bool COUNT, class SCENE, class STACK>
 DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
-    MptVec4 lx, hx, ly, hy, lz, hz, idv;
-    sc.node4(L.curr, lx, hx, ly, hy, lz, hz, idv);
+    MptVec4 nx, fx, ny, fy, nz, fz, idv;
+    sc.node4(L.curr, L.offx, L.offy, L.offz, nx, fx, ny, fy, nz, fz, idv);
     int id0 = __float_as_int(idv.x), id1 = __float_as_int(idv.y), id2 = __float_as_int(idv.z), id3 = __float_as_int(idv.w);
     if (COUNT) { cnt.n_node++; cnt.n_box += 4; }
-    float t0, t1, t2, t3;
-    bool h0 = box_fast(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, L.inv, L.oinv, L.tbest, &t0);
-    bool h1 = box_fast(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, L.inv, L.oinv, L.tbest, &t1);
-    bool h2 = box_fast(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, L.inv, L.oinv, L.tbest, &t2);
-    bool h3 = box_fast(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, L.inv, L.oinv, L.tbest, &t3);
+#define MPT_SLAB(c, tn, h)                                                                                              \
+    float tn = fmaxf(fmaxf(__builtin_fmaf(nx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(ny.c, L.inv.y, -L.oinv.y)),          \
+                     fmaxf(__builtin_fmaf(nz.c, L.inv.z, -L.oinv.z), 0.0f));                                             \
+    bool h = tn <= fminf(fminf(__builtin_fmaf(fx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(fy.c, L.inv.y, -L.oinv.y)),      \
+                         fminf(__builtin_fmaf(fz.c, L.inv.z, -L.oinv.z), L.tbest));
+    MPT_SLAB(x, t0, h0) MPT_SLAB(y, t1, h1) MPT_SLAB(z, t2, h2) MPT_SLAB(w, t3, h3)
+#undef MPT_SLAB
     // entry distances are >= 0, so their bit patterns order like the values; a miss (or the triangle the ray
     // left from, lbvh.py:329) gets the largest key
     const unsigned MISS = 0xffffffffu;

@@ -753,7 +753,6 @@ def test_mid_size_scene_with_environment_vs_oracle(fresh, oracle_mod):
     for mode, tol in (('strict', 1e-4), ('fast', 1e-3)):
         reset_all()
         eng = _engine(None, scene, 64, 64, mode=mode, world=world)
-        ctx().set_option('wide', 1)                    # the 4-wide gather kernel, whatever the heuristic would pick
         eng.render(8)
         if mode == 'fast':
             ctx().call('mpt_flush')
@@ -1058,15 +1057,15 @@ def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
     # 8192 pixels at 16 spp over a triangle soup: a handful of pixels whose closest hit flips between two
     # nearly coincident triangles carry the RMSE (measured: 0.10 % outliers, rel-RMSE 2.9e-3, max diff 0.14)
     assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 6e-3, what='C5 1M triangles fast, 8 columns x 16 spp')
-    assert ctx().get_option('last_kernel') == 0           # a soup: the collapse does not pay, the binary tree is walked
-    # the same through the 4-wide collapse of the tree (465 k nodes of 128 B), forced
-    ctx().set_option('wide', 1)
+    assert ctx().get_option('last_kernel') == 2           # gather kernel over the 4-wide collapse (465 k nodes of 128 B)
+    # the same through the binary tree (option wide = 0)
+    ctx().set_option('wide', 0)
     FilmTable().clear()
     ctx().call('mpt_sobol_reset', 64)
     eng.render(spp)
     raw = FilmTable().get_raw().reshape(nx, ny, 4)
-    assert ctx().get_option('last_kernel') == 2 and np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
-    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 6e-3, what='C5 1M triangles fast over 4-wide nodes, 8 columns x 16 spp')
+    assert ctx().get_option('last_kernel') == 0 and np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 6e-3, what='C5 1M triangles fast over the binary tree, 8 columns x 16 spp')
     reset_all()
     eng = _engine(None, scene, nx, ny, mode='strict', slab=(x0, x1))
     eng.render(spp)
