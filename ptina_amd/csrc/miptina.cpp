@@ -108,7 +108,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail("stream");
-    if (dev_alloc(&c->mats, c->caps.max_materials)) return bail("materials");
+    if (dev_alloc(&c->mats, (size_t)c->caps.max_materials + 1)) return bail("materials");   // + the default material's record
     if (dev_alloc(&c->images, c->caps.max_textures)) return bail("images");
     if (dev_alloc(&c->lights, MPT_MAX_LIGHTS)) return bail("lights");
     if (dev_alloc(&c->d_counters, 12)) return bail("counters");
@@ -141,9 +141,13 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), c->stream);
     hipMemsetAsync(c->d_work, 0, 16 * sizeof(unsigned int), c->stream);
     {   // unset materials: factor 0 (field-zero, mtllib.py:12-13), texture -1 (deviation Q6)
-        std::vector<MptMaterial> z(c->caps.max_materials);
+        std::vector<MptMaterial> z((size_t)c->caps.max_materials + 1);
         for (auto &m : z) { memset(&m, 0, sizeof m); for (int k = 0; k < 12; k++) m.tex[k] = -1; }
+        // record max_materials: the default material of mtllib.py:82-93 (mtlid -1)
+        const float dflt[14] = { 0.8f, 0.8f, 0.8f, 0.0f, 0.4f, 0.5f, 0.4f, 0.0f, 0.0f, 0.4f, 0.0f, 0.5f, 0.0f, 1.45f };
+        memcpy(z.back().p, dflt, sizeof dflt);
         hipMemcpyAsync(c->mats, z.data(), z.size() * sizeof(MptMaterial), hipMemcpyHostToDevice, c->stream);
+        mpt_launch_derive_materials(c->mats, (int)z.size(), c->stream);
         hipStreamSynchronize(c->stream);
     }
     for (int i = 0; i < 16; i++) c->v2w[i] = c->w2v[i] = (i % 5 == 0) ? 1.f : 0.f;
@@ -432,6 +436,7 @@ extern "C" int mpt_load_materials(mpt_ctx *c, const float *fac, const int32_t *t
         }
     }
     if (m) HIP_TRY(hipMemcpyAsync(c->mats, h.data(), (size_t)m * sizeof(MptMaterial), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(mpt_launch_derive_materials(c->mats, m, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -582,6 +587,7 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     memcpy(p.v2w, c->v2w, sizeof p.v2w);
     p.wnode = c->wnode; p.stack_spill = c->stack_spill;
     p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade;
+    p.default_mtl = c->caps.max_materials;
     p.mats = c->mats; p.lights = c->lights; p.images = c->images; p.texels = c->texels;
     p.P = c->sP;
     p.film0 = c->film[0]; p.film1 = c->film[1]; p.film2 = c->film[2];

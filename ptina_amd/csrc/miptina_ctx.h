@@ -21,6 +21,7 @@
 // kernel launchers (render_kernel.hip x2, aux_kernels.hip)
 MPT_KERNEL_API hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_derive_materials(MptMaterial *mats, int count, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int *blocks);
 MPT_KERNEL_API hipError_t mpt_launch_render_wide(const MptRenderParams *, int blocks, int count, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);

@@ -17,7 +17,8 @@
 //                           hoisted: {v0.xyz, D} {u.xyz, uu} {v.xyz, uv} {n.xyz, vv}
 //   tshade float4[n*4]      per-leaf-slot shading data: {n0.xyz, n1.x} {n1.yz, n2.xy} {n2.z, uv0.xy, uv1.x}
 //                           {uv1.y, uv2.xy, mtlid}
-//   mats   MptMaterial[m]   the 12 Disney parameters of mtllib.py:44-56 packed in 128 B
+//   mats   MptMaterial[m+1] the 12 Disney parameters of mtllib.py:44-56 + the terms derived from them, 160 B; the
+//                           last record is the default material of mtllib.py:82-93 (mtlid -1)
 //   P      float[B][dim]    Sobol points of the B frames of a batch (sobol.py:82-83 keeps one)
 //   film   float4[passes][nx*ny], element x*ny + y (filmtable.py:14,37-39)
 #pragma once
@@ -42,6 +43,9 @@ struct MptMaterial {
     int32_t tex[12];           // per parameter texture id, -1 = none
     int32_t any_tex;           // 1 if any tex != -1
     int32_t pad[3];
+    float d[8];                // fast build, untextured materials: what Disney.__init__ derives from the parameters
+                               // (disney.py:36-50) -- speccolor[3], sheencolor[3], alpha, clearcoatAlpha -- computed
+                               // once per material by derive_materials_kernel with the same device code
 };
 
 struct MptLight {              // light/__init__.py:14-18
@@ -62,7 +66,8 @@ struct MptRenderParams {
     int32_t nitems, tile_w_shift, tile_h_shift, pad2;   // fast build: (2^w x 2^h tile, chunk) work items of this launch
     // columns rendered: x = x0 + s*stripe_pitch + w, w < stripe_w, x < x1 (one contiguous slab: stripe_w = 2^30)
     int32_t stripe_w, stripe_pitch;
-    int32_t partial_stride, pad4;           // float4 per frame of the sample slab = (tile-padded columns of the share) * ny
+    int32_t partial_stride;
+    int32_t default_mtl;                    // index of the default material's record in mats (fast build)           // float4 per frame of the sample slab = (tile-padded columns of the share) * ny
     float world_fac[4];
     float v2w[16];
     const MptVec4 *snode;

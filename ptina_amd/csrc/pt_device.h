@@ -570,6 +570,45 @@ DEV void disney_init(Disney &m) {                                            // 
 }
 
 // MaterialPool.get + ParameterPair.get, mtllib.py:30-38,79-95
+#if !MPT_STRICT
+// Production build: every material, the default one included (record default_mtl), is one record; untextured
+// ones carry the derived terms of Disney.__init__ ready-made (bit for bit what disney_init computes: the same
+// device function filled them in), so a bounce costs six 16-B gathers and no per-hit re-derivation.
+DEV void material_get(const MptRenderParams &p, int mtlid, float tu, float tv, Disney &m) {
+    const MptMaterial *mt = p.mats + (mtlid == -1 ? p.default_mtl : mtlid);
+    const MptVec4 *q = (const MptVec4 *)mt;
+    MptVec4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], d0 = q[8], d1 = q[9];
+    float v[14] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y };
+    const bool textured = __float_as_int(q3.z) != 0;                           // p[14] mirrors any_tex
+    if (textured) {
+#pragma unroll 1
+        for (int k = 0; k < 12; k++) {
+            int texid = mt->tex[k];
+            if (texid != -1) {
+                MptVec4 t = image_sample(p, texid, tu, tv);
+                if (k == 0) { v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; }
+                else {
+                    switch (k) {                                               // scalar parameters take .x of fac * texel (mtllib.py:83-93)
+                    case 1: v[3] *= t.x; break; case 2: v[4] *= t.x; break; case 3: v[5] *= t.x; break;
+                    case 4: v[6] *= t.x; break; case 5: v[7] *= t.x; break; case 6: v[8] *= t.x; break;
+                    case 7: v[9] *= t.x; break; case 8: v[10] *= t.x; break; case 9: v[11] *= t.x; break;
+                    case 10: v[12] *= t.x; break; default: v[13] *= t.x; break;
+                    }
+                }
+            }
+        }
+    }
+    m.basecolor = v3(v[0], v[1], v[2]);
+    m.metallic = v[3]; m.roughness = v[4]; m.specular = v[5]; m.specularTint = v[6];
+    m.subsurface = v[7]; m.sheen = v[8]; m.sheenTint = v[9]; m.clearcoat = v[10];
+    m.clearcoatGloss = v[11]; m.transmission = v[12]; m.ior = v[13];
+    if (textured) disney_init(m);
+    else {
+        m.speccolor = v3(d0.x, d0.y, d0.z); m.sheencolor = v3(d0.w, d1.x, d1.y);
+        m.alpha = d1.z; m.clearcoatAlpha = d1.w;
+    }
+}
+#else
 DEV void material_get(const MptRenderParams &p, int mtlid, float tu, float tv, Disney &m) {
     if (mtlid == -1) {
         m.basecolor = v3s(0.8f);
@@ -607,6 +646,7 @@ DEV void material_get(const MptRenderParams &p, int mtlid, float tu, float tv, D
     }
     disney_init(m);
 }
+#endif
 
 DEV V3 disney_brdf(const Disney &m, V3 normal, float sign, V3 indir, V3 outdir) {   // disney.py:53-106
     float etai = 1.0f, etao = m.ior;

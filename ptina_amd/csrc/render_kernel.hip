@@ -784,6 +784,30 @@ MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *p, int gr
 #endif
 
 #if !MPT_STRICT
+// Disney.__init__'s derived terms (disney.py:36-50) of every material record, once per upload: the production
+// material fetch then reads them instead of re-deriving them at every hit (same device function: same bits)
+__global__ void derive_materials_kernel(MptMaterial *mats, int count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    MptMaterial *mt = mats + i;
+    Disney m;
+    m.basecolor = v3(mt->p[0], mt->p[1], mt->p[2]);
+    m.metallic = mt->p[3]; m.roughness = mt->p[4]; m.specular = mt->p[5]; m.specularTint = mt->p[6];
+    m.subsurface = mt->p[7]; m.sheen = mt->p[8]; m.sheenTint = mt->p[9]; m.clearcoat = mt->p[10];
+    m.clearcoatGloss = mt->p[11]; m.transmission = mt->p[12]; m.ior = mt->p[13];
+    disney_init(m);
+    mt->d[0] = m.speccolor.x; mt->d[1] = m.speccolor.y; mt->d[2] = m.speccolor.z;
+    mt->d[3] = m.sheencolor.x; mt->d[4] = m.sheencolor.y; mt->d[5] = m.sheencolor.z;
+    mt->d[6] = m.alpha; mt->d[7] = m.clearcoatAlpha;
+    mt->p[14] = __int_as_float(mt->any_tex);
+}
+
+MPT_KERNEL_API hipError_t mpt_launch_derive_materials(MptMaterial *mats, int count, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(derive_materials_kernel, dim3((count + 63) / 64), dim3(64), 0, stream, mats, count);
+    return hipGetLastError();
+}
+
 // persistent workgroups over 4-wide nodes; `grid` = number of CUs (scaled here by the blocks each CU can hold);
 // *blocks = workgroups launched (the spill strip must hold blocks x 256 lanes x SpillStack::SPILL entries)
 MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int *blocks) {
