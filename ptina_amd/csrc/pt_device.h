@@ -62,7 +62,11 @@ DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 DEV float norm_sqr(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 DEV V3 normalized(V3 a) { return a * m_rnorm(norm_sqr(a)); }
+#if MPT_STRICT
 DEV float vavg(V3 a) { return m_div(a.x + a.y + a.z, 3.0f); }                 // common.py:73-77
+#else
+DEV float vavg(V3 a) { return (a.x + a.y + a.z) * 0.33333334f; }              // a constant, not a v_rcp_f32 per call
+#endif
 DEV bool any_gt0(V3 a) { return a.x > 0.0f || a.y > 0.0f || a.z > 0.0f; }
 DEV bool any_ne0(V3 a) { return a.x != 0.0f || a.y != 0.0f || a.z != 0.0f; }
 DEV float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }   // common.py:163-165
@@ -737,7 +741,9 @@ DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V
 
     float etai = 1.0f, etao = m.ior;
     if (sign < 0.0f) { etai = m.ior; etao = 1.0f; }
+#if MPT_STRICT
     float eta = m_div(etai, etao);
+#endif
 
     float cosi = dot(indir, normal);
     float Fi = schlickFresnel(cosi);
@@ -751,7 +757,13 @@ DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V
     specrate = lerpf(specrate, 0.1f, 1.0f);
     if (coatrate != 0.0f) coatrate = lerpf(coatrate, 0.1f, 1.0f);
 
-    if (choice(coatrate)) {
+#if MPT_STRICT
+    const bool coat = choice(coatrate);
+#else
+    // without a clearcoat the first Choice is the identity (w < 0 never holds, w = (w - 0) / (1 - 0), pdf *= 1)
+    const bool coat = coatrate != 0.0f && choice(coatrate);
+#endif
+    if (coat) {
         float alpha = m.clearcoatAlpha;
         V3 halfdir = tanspace_mul(ts, sample_GTR1(samp.x, samp.y, alpha));
         V3 outdir = reflectv(-indir, halfdir);
@@ -790,6 +802,9 @@ DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V
                     result.color = vdivs(m.basecolor * fdf * m.transmission, choice.pdf);
                 } else {
                     V3 T;
+#if !MPT_STRICT
+                    const float eta = m_div(etai, etao);                     // only this branch needs it
+#endif
                     if (refractv(-indir, halfdir, eta, &T)) {
                         result.outdir = T;
                         result.pdf = Ds * (1.0f - fdf);
