@@ -351,8 +351,12 @@ def run_rank(args, rank, world, pmc, pmc_source):
         clock_hz = c.get_option('clock_khz') * 1e3 or 2.4e9
         if pmc is None and world == 1:
             pmc, pmc_source = committed_pmc(kernel)
-        roof, hbm = roofline_blocks(pmc if world == 1 else None, pmc_source if world == 1 else 'N > 1: not collected',
-                                    kernel, avg_kernel_s, clock_hz, concurrent)
+        try:
+            roof, hbm = roofline_blocks(pmc if world == 1 else None, pmc_source if world == 1 else 'N > 1: not collected',
+                                        kernel, avg_kernel_s, clock_hz, concurrent)
+        except Exception as e:                # an incomplete counter set must not cost the run its result line
+            roof, hbm = roofline_blocks(None, f'counters unusable ({type(e).__name__}: {e})', kernel, avg_kernel_s,
+                                        clock_hz, concurrent)
         samples_per_launch = cnt['samples'] / W
         out = {
             'metric': 'Msamples/sec (pixels x spp / s), 512x512x32spp cornell-monkey (978 tri)',
