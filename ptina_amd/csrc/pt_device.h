@@ -759,10 +759,6 @@ DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V
 
 #if MPT_STRICT
     const bool coat = choice(coatrate);
-#else
-    // without a clearcoat the first Choice is the identity (w < 0 never holds, w = (w - 0) / (1 - 0), pdf *= 1)
-    const bool coat = coatrate != 0.0f && choice(coatrate);
-#endif
     if (coat) {
         float alpha = m.clearcoatAlpha;
         V3 halfdir = tanspace_mul(ts, sample_GTR1(samp.x, samp.y, alpha));
@@ -802,9 +798,6 @@ DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V
                     result.color = vdivs(m.basecolor * fdf * m.transmission, choice.pdf);
                 } else {
                     V3 T;
-#if !MPT_STRICT
-                    const float eta = m_div(etai, etao);                     // only this branch needs it
-#endif
                     if (refractv(-indir, halfdir, eta, &T)) {
                         result.outdir = T;
                         result.pdf = Ds * (1.0f - fdf);
@@ -847,6 +840,85 @@ DEV BsdfSample disney_bounce(const Disney &m, V3 normal, float sign, V3 indir, V
         result.pdf = MPT_INV_PI;
         result.color = vdivs(diffuse * MPT_PI * (1.0f - m.metallic) * (1.0f - m.transmission), choice.pdf);
     }
+#else
+    // Production build: the three lobes of disney.py:136-231 share what they have in common.  Each lane first
+    // picks its lobe (same Choice sequence), then ONE tangent-space direction is sampled with the lobe's own
+    // polar cosine (the branches' sample_GTR1 / sample_GTR2 / cosine sampling differ in nothing else), ONE set of
+    // cosines and Schlick terms is formed, and only the lobe-specific weights diverge.  Per lane the operations
+    // and their order are those of the branches above; a wave whose lanes sit in two lobes issues the shared part
+    // once instead of twice.
+    // without a clearcoat the first Choice is the identity (w < 0 never holds, w = (w - 0) / (1 - 0), pdf *= 1)
+    const bool coat = coatrate != 0.0f && choice(coatrate);
+    const bool spec = !coat && choice(specrate);
+    float hz;                                                                 // cosine of the sampled direction to the normal
+    if (coat) {                                                               // sample_GTR1, microfacet.py:69-71
+        float a = m.clearcoatAlpha;
+        hz = m_div(m_sqrt(m_pow(a, 2.0f - 2.0f * samp.x) - 1.0f), a * a - 1.0f);
+    } else if (spec) {                                                        // sample_GTR2, :75-77
+        hz = m_sqrt(m_div(1.0f - samp.x, 1.0f - samp.x * (1.0f - m.alpha * m.alpha)));
+    } else {
+        hz = m_sqrt(samp.x);                                                  // cosine-weighted hemisphere, disney.py:203
+    }
+    const V3 sdir = tanspace_mul(ts, spherical(hz, samp.y));
+    V3 halfdir, outdir;
+    if (coat || spec) { halfdir = sdir; outdir = reflectv(-indir, halfdir); }
+    else { outdir = sdir; halfdir = normalized(indir + outdir); }
+    const float coso_raw = dot(outdir, normal);
+    const float cosh_ = dot_or_zero(halfdir, normal);
+    const float cosoh = dot_or_zero(halfdir, outdir);
+    const float Foh = schlickFresnel(cosoh);
+    if (coat) {
+        if (cosoh > 0.0f) {
+            float Dr = GTR1(cosh_, m.clearcoatAlpha);
+            float Fr = lerpf(Foh, 0.04f, 1.0f);
+            result.outdir = outdir;
+            float partial = m_div(m.clearcoat * Fr * coso_raw, cosoh);
+            result.pdf = Dr * partial;
+            result.color = v3s(m_div(partial, choice.pdf));
+        }
+    } else if (spec) {
+        const float coso = fmaxf(0.0f, coso_raw);
+        if (cosoh > 0.0f && coso > 0.0f && cosh_ > 0.0f) {
+            float Ds = GTR2(cosh_, m.alpha);
+            if (choice(m.transmission)) {
+                float fdf = dielectricFresnel(etao, etai, cosoh);
+                float reflrate = lerpf(fdf, 0.2f, 1.0f);
+                if (choice(reflrate)) {
+                    result.outdir = outdir;
+                    result.pdf = Ds * fdf;
+                    result.color = vdivs(m.basecolor * fdf * m.transmission, choice.pdf);
+                } else {
+                    V3 T;
+                    const float eta = m_div(etai, etao);                     // only this branch needs it
+                    if (refractv(-indir, halfdir, eta, &T)) {
+                        result.outdir = T;
+                        result.pdf = Ds * (1.0f - fdf);
+                        result.color = vdivs(m.basecolor * (1.0f - fdf) * m.transmission, choice.pdf);
+                    }
+                }
+            } else {
+                V3 Fs2 = lerpv(Foh, m.speccolor, v3s(1.0f));
+                result.outdir = outdir;
+                float partial = m_div(0.5f, cosoh * smithGGX(coso, m.alpha));
+                result.pdf = Ds * vavg(Fs2) * partial;
+                result.color = vdivs(Fs2 * partial * (1.0f - m.transmission), choice.pdf);
+            }
+        }
+    } else {
+        const float coso = coso_raw;
+        float Fo = schlickFresnel(coso);
+        float Fd90 = 0.5f + 2.0f * (cosoh * cosoh) * m.roughness;
+        float Fd = lerpf(Fi, 1.0f, Fd90) * lerpf(Fo, 1.0f, Fd90);
+        float Fss90 = (cosoh * cosoh) * m.roughness;
+        float Fss = lerpf(Fi, 1.0f, Fss90) * lerpf(Fo, 1.0f, Fss90);
+        float ss = 1.25f * (Fss * (m_rcp(cosi + coso) - 0.5f) + 0.5f);
+        V3 Fsheen = m.sheencolor * (Foh * m.sheen);
+        V3 diffuse = m.basecolor * (MPT_INV_PI * lerpf(m.subsurface, Fd, ss)) + Fsheen;
+        result.outdir = outdir;
+        result.pdf = MPT_INV_PI;
+        result.color = vdivs(diffuse * MPT_PI * (1.0f - m.metallic) * (1.0f - m.transmission), choice.pdf);
+    }
+#endif
     return result;
 }
 
