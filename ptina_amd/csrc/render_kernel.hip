@@ -394,6 +394,12 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     if (COUNT) cnt.n_tri++;
     MptVec4 g0, g1, g2, g3;
     sc.tri(slot, g0, g1, g2, g3);
+#if MPT_LEAF_UPFRONT
+    // all four record loads issued before the first test: left alone the compiler sinks each into the nested branch
+    // that needs it, and a LEAF step becomes three LDS round trips in a row
+    asm volatile("" : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w));
+    asm volatile("" : "+v"(g2.x), "+v"(g2.y), "+v"(g2.z), "+v"(g2.w), "+v"(g3.x), "+v"(g3.y), "+v"(g3.z), "+v"(g3.w));
+#endif
     float dd, su, sv;
     if (tri_test(g0, g1, g2, g3, L.to, L.td, &dd, &su, &sv)) {
         if (L.shadow) {
@@ -486,7 +492,26 @@ DEV void lane_begin(const MptRenderParams &p, LaneState &L, STACK &stk, int i, i
     lane_next_bounce<COUNT>(p, L, stk, ro, cnt);
 }
 
+#ifndef MPT_NODE_REP
+#define MPT_NODE_REP 2        // extra NODE steps per decision (MI355X: 0 / 1 / 2 / 3 -> 4.03 / 3.85 / 3.72 / 3.72 ms with one extra LEAF step)
+#endif
+#ifndef MPT_LEAF_REP
+#define MPT_LEAF_REP 1        // extra LEAF steps per decision (0 / 1 / 2 -> 3.83 / 3.72 / 3.77 ms with two extra NODE steps)
+#endif
+// Diagnostic build (-DMPT_X_STAMPS=1, counting kernels only): the shader-clock cycles each wave spends in each
+// stage, accumulated into the counters named in MPT_STAMP_END instead of their usual meaning (tools/gpu_diag.py stamps)
+#if MPT_X_STAMPS
+#define MPT_STAMP_BEGIN unsigned long long stamp_t0 = 0; if (COUNT) { __builtin_amdgcn_sched_barrier(0); stamp_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define MPT_STAMP_END(acc) if (COUNT) { __builtin_amdgcn_sched_barrier(0); acc += __builtin_amdgcn_s_memtime() - stamp_t0; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MPT_STAMP_BEGIN
+#define MPT_STAMP_END(acc)
+#endif
 DEV int wave_count(bool pred) { return (int)__builtin_popcountll(__ballot(pred)); }
+DEV int wave_count32(bool pred) {            // the same in two 32-bit halves: stays on the scalar unit when compared
+    unsigned long long m = __ballot(pred);
+    return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
+}
 
 // Work items = (8x8 pixel tile, chunk of frames), tile-major, split into 8 contiguous ranges with
 // one counter each.  A wave starts on the range of its XCD (blocks b, b+8, ... share an XCD) and
@@ -519,7 +544,12 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     const int t8y = (p.ny + (1 << ths) - 1) >> ths;
     int S = 0, next = 0;                            // wave-uniform: current pool = 64*frames samples; next unassigned
     int ti = 0, tj = 0, f0 = 0, tx_cur = 0;
+    int ndead = 0;                                  // wave-uniform: lanes that have left for good
     bool more = true;
+#if MPT_X_STAMPS
+    unsigned long long acc_node = 0, acc_leaf = 0, acc_sdone = 0, acc_shade = 0, acc_new = 0;
+    const unsigned long long stamp_start = __builtin_amdgcn_s_memtime();
+#endif
     LaneState L;
     L.st = ST_NEW;
     L.sp = 0; L.curr = 0; L.shadow = 0;
@@ -538,31 +568,64 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
         }
         // ---- traversal mode: tight loop while the lanes that are traversing outnumber the waiting ones
         for (;;) {
-            int cn = wave_count(L.st == ST_NODE);
-            int cl = wave_count(L.st == ST_LEAF);
-            int cw = wave_count(L.st == ST_DONE || L.st == ST_NEW);
-            // leave when the waiting lanes outnumber the traversing ones 2 : 1 (best of the ratios tried on MI355X;
-            // a compile-time constant: as a launch parameter it cost two s_mul and two SGPRs in this loop)
-            if (cn + cl == 0 || (cn + cl) * 2 < cw) break;
+            // The decision in front of every step is a chain VALU compare -> scalar count -> scalar compare ->
+            // branch that a wave cannot overlap with anything of its own (stamped: a fifth of its cycles went
+            // there), so it is kept short: two ballots, counts in 32-bit scalar registers (a 64-bit popcount makes
+            // the compiler compare on the VALU), the waiting lanes by subtraction, one branch per condition.
+            const int cn = wave_count32(L.st == ST_NODE);
+            const int cl = wave_count32(L.st == ST_LEAF);
+            const int trav = cn + cl;
+            if (trav == 0) break;
+            // leave when the waiting lanes (DONE or NEW: everything alive that is not traversing) outnumber the
+            // traversing ones 2 : 1 (best of the ratios tried on MI355X)
+            if (trav * 2 < 64 - ndead - trav) break;
+            MPT_STAMP_BEGIN
             if (cn >= cl) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
                 if (L.st == ST_NODE) {
                     if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
                     else stage_node<COUNT>(sc, stk, L, cnt);
                 }
+#if MPT_NODE_REP
+                // further steps for the lanes that are still at a node, without counting again: the three ballots
+                // and the decision chain in front of every step cost a wave about as many cycles as half a step
+                if constexpr (!SCENE::WIDE) {
+#pragma unroll
+                    for (int rep = 0; rep < MPT_NODE_REP; rep++) {
+                        if (__ballot(L.st == ST_NODE) == 0ull) break;
+                        if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
+                        if (L.st == ST_NODE) stage_node<COUNT>(sc, stk, L, cnt);
+                    }
+                }
+#endif
+                MPT_STAMP_END(acc_node)
             } else {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
                 if (L.st == ST_LEAF) stage_leaf<COUNT>(sc, stk, L, cnt);
+#if MPT_LEAF_REP
+#pragma unroll
+                for (int rep = 0; rep < MPT_LEAF_REP; rep++) {
+                    if (__ballot(L.st == ST_LEAF) == 0ull) break;
+                    if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
+                    if (L.st == ST_LEAF) stage_leaf<COUNT>(sc, stk, L, cnt);
+                }
+#endif
+                MPT_STAMP_END(acc_leaf)
             }
         }
         // ---- shading mode
         if (wave_count(L.st == ST_DONE && L.shadow) != 0) {
+            MPT_STAMP_BEGIN
             if (L.st == ST_DONE && L.shadow) stage_shadow_done<COUNT>(p, L, stk, cnt);
+            MPT_STAMP_END(acc_sdone)
         }
         if (wave_count(L.st == ST_DONE && !L.shadow) != 0) {
             if (COUNT && (threadIdx.x & 63) == 0) cnt.it_shade++;
+            MPT_STAMP_BEGIN
             if (L.st == ST_DONE && !L.shadow) stage_shade<COUNT>(p, L, stk, cnt);
+            MPT_STAMP_END(acc_shade)
         }
+        MPT_STAMP_BEGIN
         unsigned long long m_new = __ballot(L.st == ST_NEW);
         if (m_new != 0ull) {
             if (next >= S && more) {                // pool drained: fetch the next work item right away,
@@ -600,10 +663,21 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 next += (int)__builtin_popcountll(m_new);
             } else if (!more) {
                 if (L.st == ST_NEW) L.st = ST_DEAD;  // nothing left anywhere: those lanes are done
+                ndead += (int)__builtin_popcountll(m_new);
             }
         }
-        if (wave_count(L.st != ST_DEAD) == 0) break;
+        MPT_STAMP_END(acc_new)
+        if (ndead == 64) break;
     }
+#if MPT_X_STAMPS
+    if (COUNT) {       // the stage cycles (in units of 256) replace the work counters of this diagnostic build
+        const bool l0 = (threadIdx.x & 63) == 0;
+        const unsigned long long total = __builtin_amdgcn_s_memtime() - stamp_start;
+        cnt.n_box = l0 ? (unsigned)(acc_node >> 8) : 0u; cnt.n_tri = l0 ? (unsigned)(acc_leaf >> 8) : 0u;
+        cnt.n_draws = l0 ? (unsigned)(acc_sdone >> 8) : 0u; cnt.n_shade = l0 ? (unsigned)(acc_shade >> 8) : 0u;
+        cnt.bounces = l0 ? (unsigned)(acc_new >> 8) : 0u; cnt.n_node = l0 ? (unsigned)(total >> 8) : 0u;
+    }
+#endif
 }
 #endif
 

@@ -454,8 +454,37 @@ def sync_sweep(name='s978', spp=32, n=512, steps=15):
     common.reset_all()
 
 
+def stamps(name='s978', spp=32, n=512):
+    '''needs a library built with -DMPT_X_STAMPS=1 (MIPTINA_LIB): shader-clock shares of the stages of the
+    counting LDS kernel, per wave: NODE steps, LEAF steps, shadow-ray restarts, SHADE, NEW (+ pull), the rest
+    (loop headers, ballots)'''
+    common.reset_all()
+    eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
+    c = ctx()
+    c.set_option('batch', spp)
+    eng.render(spp)
+    c.call('mpt_synchronize')
+    c.set_option('count', 1)
+    c.call('mpt_reset_counters')
+    eng.render(spp)
+    k = c.counters()
+    c.set_option('count', 0)
+    tot = k['n_node']
+    res = {'node': k['n_box'] / tot, 'leaf': k['n_tri'] / tot, 'shadow_done': k['n_draws'] / tot, 'shade': k['n_shade'] / tot,
+           'new': k['bounces'] / tot}
+    res['rest'] = 1.0 - sum(res.values())
+    res['stages_per_64_samples'] = {s: k['it_' + s] / k['samples'] * 64 for s in ('node', 'leaf', 'shade', 'new')}
+    res['cycles_per_stage'] = {s: v * 256 / max(k['it_' + s], 1) for s, v in (('node', k['n_box']), ('leaf', k['n_tri']), ('shade', k['n_shade']), ('new', k['bounces']))}
+    print('stamps', json.dumps(res), flush=True)
+    out['stamps'] = res
+    save()
+    common.reset_all()
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'stamps' in what:
+        stamps()
     if 'sync_sweep' in what:
         sync_sweep()
     if 'probe' in what:
