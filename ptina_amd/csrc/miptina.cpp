@@ -666,9 +666,11 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     // LDS-resident kernel: node + triangle records + a 16-bit stack of (depth+1) levels x 1024
     // lanes must fit the CU's 160 KiB; ids must fit int16
     const int lds_stack = c->fast_depth + 1;            // sentinel + one pending sibling (node or leaf) per level
-    const size_t lds_bytes = ((size_t)(c->nfaces - 1) * 4 + (size_t)c->nfaces * 4) * sizeof(MptVec4) +
-                             (size_t)lds_stack * 1024 * sizeof(short);
-    const bool lds_kernel = fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && lds_bytes <= 160 * 1024;
+    // + the material records (96 B each, the default one last) and one byte per triangle naming its record
+    const size_t lds_bytes = ((size_t)(c->nfaces - 1) * 4 + (size_t)c->nfaces * 4 + (size_t)(c->caps.max_materials + 1) * 6) * sizeof(MptVec4) +
+                             (((size_t)c->nfaces + 15) & ~(size_t)15) + (size_t)lds_stack * 1024 * sizeof(short);
+    const bool lds_kernel = fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && c->caps.max_materials < 256 &&
+                            lds_bytes <= 160 * 1024;
     int chunk = B, nchunks = 1;
     const int tw = 1 << c->tile_w_shift, th = 1 << c->tile_h_shift;
     int tile_cols = 0;

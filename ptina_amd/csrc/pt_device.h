@@ -146,6 +146,27 @@ DEV bool tri_test(MptVec4 g0, MptVec4 g1, MptVec4 g2, MptVec4 g3, V3 ro, V3 rd, 
     V3 v0 = ld3(g0), u = ld3(g1), v = ld3(g2), norm = ld3(g3);
     float D = g0.w, uu = g1.w, uv = g2.w, vv = g3.w;
     float b = dot(norm, rd);
+#if !MPT_STRICT
+    // Production build: the whole test straight through and the reference's four conditions combined at the end.
+    // In a wave the nested form runs every level anyway (some lane always gets that far), each level behind its
+    // own exec-mask juggling and its own wait for the record words it needs; the flat form is one wait and no
+    // branches.  Lanes that fail an early condition compute garbage (infinities, NaNs) that the flags discard.
+    {
+        V3 w0 = ro - v0;
+        float a = -dot(norm, w0);
+        float r = m_div(a, b);
+        V3 ip = ro + rd * r;
+        V3 w = ip - v0;
+        float wu = dot(w, u);
+        float wv = dot(w, v);
+        float rD = m_rcp(D);
+        float s = (uv * wv - vv * wu) * rD;
+        float t = (uv * wu - uu * wv) * rD;
+        bool ok = fabsf(b) >= MPT_EPS && r > 0.0f && 0.0f <= s && s <= 1.0f && 0.0f <= t && s + t <= 1.0f;
+        *depth = r; *s_ = s; *t_ = t;
+        return ok;
+    }
+#else
     bool hit = false;
     if (fabsf(b) >= MPT_EPS) {
         V3 w0 = ro - v0;
@@ -165,6 +186,7 @@ DEV bool tri_test(MptVec4 g0, MptVec4 g1, MptVec4 g2, MptVec4 g3, V3 ro, V3 rd, 
         }
     }
     return hit;
+#endif
 }
 
 // Box.intersect, geometries.py:24-46
@@ -202,7 +224,7 @@ struct Stack {
 
 // scene records served from HBM/L2 through the vector L1 (any scene size)
 struct GlobalScene {
-    static constexpr bool WIDE = false, SIGNED_PLANES = false;
+    static constexpr bool WIDE = false, SIGNED_PLANES = false, LDS_MATS = false;
     const MptVec4 *fnode, *tgeo;
     int soa_n;                 // node count, for the layout A/B build below
     DEV void node(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &d) const {
@@ -226,7 +248,7 @@ struct GlobalScene {
 // those fetches, not their bytes, are what bounds the big scenes (measured: binary16 boxes at half the bytes
 // bought 3-7 %)
 struct WideScene {
-    static constexpr bool WIDE = true, SIGNED_PLANES = false;
+    static constexpr bool WIDE = true, SIGNED_PLANES = false, LDS_MATS = false;
     const MptVec4 *wnode, *tgeo;
     // entry (n*) and exit (f*) planes of the four children, picked by the ray's direction signs: o* is 0 for a ray
     // going up the axis and 16 (bytes: the next float4) for one going down -- still seven dwordx4 gathers
@@ -276,9 +298,17 @@ typedef float mpt_f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const mpt_f2 *LdsVec2Ptr;
 typedef __attribute__((address_space(3))) const char *LdsBytePtr;
 
+typedef __attribute__((address_space(3))) const unsigned char *LdsU8Ptr;
+#define MPT_LDS_MAT_VEC4 6      // float4 of a material record kept in LDS: p[0..15] and the derived terms d[0..7]
+
 struct LdsScene {
-    static constexpr bool WIDE = false, SIGNED_PLANES = true;
+    static constexpr bool WIDE = false, SIGNED_PLANES = true, LDS_MATS = true;
     LdsVec4Ptr fnode, tgeo;
+    // The material records (parameters + derived terms, 96 B each, the default material last) and one byte per
+    // leaf slot naming the record: SHADE reads its material out of LDS while the shading record of the triangle is
+    // still on its way from L2, instead of gathering it from L2 after that record has arrived (it holds the id).
+    LdsVec4Ptr mats;
+    LdsU8Ptr mtl;
     // The slab planes of both children picked by the ray's direction signs instead of by min / max: a node
     // record holds {lo, lo, hi, hi} (child 0, child 1) per axis, so the entry planes of an axis are the 8 bytes at
     // offset 0 for a ray going up that axis and at offset 8 for one going down, and the exit planes are the
@@ -578,10 +608,10 @@ DEV void disney_init(Disney &m) {                                            // 
 // Production build: every material, the default one included (record default_mtl), is one record; untextured
 // ones carry the derived terms of Disney.__init__ ready-made (bit for bit what disney_init computes: the same
 // device function filled them in), so a bounce costs six 16-B gathers and no per-hit re-derivation.
-DEV void material_get(const MptRenderParams &p, int mtlid, float tu, float tv, Disney &m) {
-    const MptMaterial *mt = p.mats + (mtlid == -1 ? p.default_mtl : mtlid);
-    const MptVec4 *q = (const MptVec4 *)mt;
-    MptVec4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], d0 = q[8], d1 = q[9];
+// q0..q3, d0, d1: the record's float4 0-3 and 8-9, from wherever the caller keeps them; mt: the record in
+// global memory (texture ids, read by textured materials only)
+DEV void material_from(const MptRenderParams &p, const MptMaterial *mt, MptVec4 q0, MptVec4 q1, MptVec4 q2, MptVec4 q3,
+                       MptVec4 d0, MptVec4 d1, float tu, float tv, Disney &m) {
     float v[14] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y };
     const bool textured = __float_as_int(q3.z) != 0;                           // p[14] mirrors any_tex
     if (textured) {
@@ -611,6 +641,11 @@ DEV void material_get(const MptRenderParams &p, int mtlid, float tu, float tv, D
         m.speccolor = v3(d0.x, d0.y, d0.z); m.sheencolor = v3(d0.w, d1.x, d1.y);
         m.alpha = d1.z; m.clearcoatAlpha = d1.w;
     }
+}
+DEV void material_get(const MptRenderParams &p, int mtlid, float tu, float tv, Disney &m) {
+    const MptMaterial *mt = p.mats + (mtlid == -1 ? p.default_mtl : mtlid);
+    const MptVec4 *q = (const MptVec4 *)mt;
+    material_from(p, mt, q[0], q[1], q[2], q[3], q[8], q[9], tu, tv, m);
 }
 #else
 DEV void material_get(const MptRenderParams &p, int mtlid, float tu, float tv, Disney &m) {
@@ -1058,4 +1093,32 @@ DEV void get_geometries(const MptRenderParams &p, const Hit &hit, V3 ro, V3 rd, 
     if (sign < 0.0f) nrm = -nrm;
     *normal = nrm;
     material_get(p, __float_as_int(s3.w), tu, tv, mat);
+}
+
+// the same with the material served by the scene (LDS-resident kernel)
+template <class SCENE>
+DEV void get_geometries_in(const MptRenderParams &p, const SCENE &sc, const Hit &hit, V3 ro, V3 rd, V3 *hitpos, V3 *normal,
+                           Disney &mat) {
+#if !MPT_STRICT
+    if constexpr (SCENE::LDS_MATS) {
+        const MptVec4 *s = p.tshade + (size_t)hit.index * 4;
+        MptVec4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
+        const int rec = sc.mtl[hit.index];
+        LdsVec4Ptr q = sc.mats + rec * MPT_LDS_MAT_VEC4;
+        MptVec4 q0 = lds_ld(q), q1 = lds_ld(q + 1), q2 = lds_ld(q + 2), q3 = lds_ld(q + 3), d0 = lds_ld(q + 4), d1 = lds_ld(q + 5);
+        float u = hit.u, v = hit.v;
+        float wx = 1.0f - u - v, wy = u, wz = v;
+        V3 vn0 = v3(s0.x, s0.y, s0.z), vn1 = v3(s0.w, s1.x, s1.y), vn2 = v3(s1.z, s1.w, s2.x);
+        V3 nrm = normalized(vn0 * wx + vn1 * wy + vn2 * wz);
+        float tu = wx * s2.y + wy * s2.w + wz * s3.y;
+        float tv = wx * s2.z + wy * s3.x + wz * s3.z;
+        *hitpos = ro + rd * hit.depth;
+        float sign = -dot(rd, nrm);
+        if (sign < 0.0f) nrm = -nrm;
+        *normal = nrm;
+        material_from(p, p.mats + rec, q0, q1, q2, q3, d0, d1, tu, tv, mat);
+        return;
+    }
+#endif
+    get_geometries(p, hit, ro, rd, hitpos, normal, mat);
 }

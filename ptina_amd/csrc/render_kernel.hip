@@ -425,8 +425,8 @@ DEV void stage_shadow_done(const MptRenderParams &p, LaneState &L, STACK &stk, C
 
 // path.py:31-62 for one bounce.  On entry L.to / L.prd are the path ray r.o / r.d and
 // (L.hidx >= 0, L.tbest, L.hidx, L.hu, L.hv) the closest hit.
-template <bool COUNT, class STACK>
-DEV void stage_shade(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cnt) {
+template <bool COUNT, class SCENE, class STACK>
+DEV void stage_shade(const MptRenderParams &p, const SCENE &sc, LaneState &L, STACK &stk, Cnt &cnt) {
     V3 ro = L.to, rd = L.prd;
     const bool was_hit = L.hidx >= 0;
     float hdepth = was_hit ? L.tbest : MPT_INF;
@@ -444,7 +444,7 @@ DEV void stage_shade(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cn
     L.navoid = ~L.hidx;
     Hit hit; hit.hit = 1; hit.depth = hdepth; hit.index = L.hidx; hit.u = L.hu; hit.v = L.hv;
     V3 hitpos, normal; Disney mat;
-    get_geometries(p, hit, ro, rd, &hitpos, &normal, mat);
+    get_geometries_in(p, sc, hit, ro, rd, &hitpos, &normal, mat);
     if (COUNT) { cnt.n_shade++; cnt.n_draws += 6; }
     float sign = -dot(rd, normal);                                           // path.py:44-46 (never negative)
     if (sign < 0.0f) normal = -normal;
@@ -622,7 +622,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
         if (wave_count(L.st == ST_DONE && !L.shadow) != 0) {
             if (COUNT && (threadIdx.x & 63) == 0) cnt.it_shade++;
             MPT_STAMP_BEGIN
-            if (L.st == ST_DONE && !L.shadow) stage_shade<COUNT>(p, L, stk, cnt);
+            if (L.st == ST_DONE && !L.shadow) stage_shade<COUNT>(p, sc, L, stk, cnt);
             MPT_STAMP_END(acc_shade)
         }
         MPT_STAMP_BEGIN
@@ -733,16 +733,27 @@ __global__ __launch_bounds__(MPT_BLOCK, 4) void render_kernel_wide(const MptRend
 }
 
 // ---------------------------------------------------------------- LDS-resident persistent kernel
-// dynamic LDS: [ (n-1)*4 node float4 | n*4 triangle float4 | lds_stack x 1024 int16 ]
+// dynamic LDS: [ (n-1)*4 node float4 | n*4 triangle float4 | (default_mtl+1)*6 material float4 |
+//                n material-record bytes, padded to 16 | lds_stack x 1024 int16 ]     (mpt_lds_scene_bytes)
 template <bool COUNT>
 __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRenderParams p) {
     extern __shared__ __attribute__((aligned(16))) MptVec4 smem[];
-    const int nnode4 = (p.n - 1) * 4, ntri4 = p.n * 4;
+    const int nnode4 = (p.n - 1) * 4, ntri4 = p.n * 4, nmat4 = (p.default_mtl + 1) * MPT_LDS_MAT_VEC4;
+    const int nmtl4 = (p.n + 15) >> 4;
     unsigned long long *tl = p.timeline ? p.timeline + 4 * (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
     if (tl && (threadIdx.x & 63) == 0) tl[0] = wall_clock64();
     {   // one copy of the scene per CU: coalesced 16-B loads, ds_write_b128
         for (int k = threadIdx.x; k < nnode4; k += blockDim.x) smem[k] = p.fnode[k];
         for (int k = threadIdx.x; k < ntri4; k += blockDim.x) smem[nnode4 + k] = p.tgeo[k];
+        for (int k = threadIdx.x; k < nmat4; k += blockDim.x) {
+            const int rec = k / MPT_LDS_MAT_VEC4, w = k - rec * MPT_LDS_MAT_VEC4;
+            smem[nnode4 + ntri4 + k] = ((const MptVec4 *)(p.mats + rec))[w < 4 ? w : w + 4];
+        }
+        unsigned char *mtl = (unsigned char *)(smem + nnode4 + ntri4 + nmat4);
+        for (int k = threadIdx.x; k < p.n; k += blockDim.x) {
+            const int id = __float_as_int(p.tshade[(size_t)k * 4 + 3].w);
+            mtl[k] = (unsigned char)(id == -1 ? p.default_mtl : id);
+        }
     }
     __syncthreads();
     if (tl && (threadIdx.x & 63) == 0) tl[1] = wall_clock64();
@@ -750,8 +761,10 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
     LdsScene sc;
     sc.fnode = (LdsVec4Ptr)(void *)smem;
     sc.tgeo = (LdsVec4Ptr)(void *)(smem + nnode4);
+    sc.mats = (LdsVec4Ptr)(void *)(smem + nnode4 + ntri4);
+    sc.mtl = (LdsU8Ptr)(void *)(smem + nnode4 + ntri4 + nmat4);
     Stack16 stk;
-    stk.base = (LdsShortPtr)(void *)(smem + nnode4 + ntri4) + threadIdx.x;
+    stk.base = (LdsShortPtr)(void *)(smem + nnode4 + ntri4 + nmat4 + nmtl4) + threadIdx.x;
     stk.sp = 0;
     Cnt cnt = {};
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
