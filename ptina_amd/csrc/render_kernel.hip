@@ -474,23 +474,32 @@ DEV void stage_shade(const MptRenderParams &p, const SCENE &sc, LaneState &L, ST
     }
 }
 
-// do_render up to the camera ray, path.py:82-90
-template <bool COUNT, class STACK>
-DEV void lane_begin(const MptRenderParams &p, LaneState &L, STACK &stk, int i, int j, Cnt &cnt) {
-    L.rng_i = wanghash2(i, j);                                               // path.py:72-73
-    L.rng_k = reduce_mod_dim(L.rng_i, p.sobol_dim, p.sobol_inv_dim);
-    float jit[2];
-    lane_draws<2>(p, L, jit);                                                // random2: dx then dy, path.py:87
-    float dx = jit[0], dy = jit[1];
-    float x = m_div((float)i + dx, (float)p.nx) * 2.0f - 1.0f;
-    float y = m_div((float)j + dy, (float)p.ny) * 2.0f - 1.0f;
-    V3 ro;
-    camera_generate(p, x, y, &ro, &L.prd);
-    L.navoid = 0; L.depth = 0;
-    L.result = v3s(0.0f); L.throughput = v3s(1.0f); L.last_brdf_pdf = 0.0f;
-    if (COUNT) { cnt.samples++; cnt.n_draws += 2; }
-    lane_next_bounce<COUNT>(p, L, stk, ro, cnt);
+// do_render up to the camera ray, path.py:82-90, in two halves.  A wave prepares the primary rays of the next 64
+// samples of its work item with all lanes on (lane l: sample base + l) and keeps them in eight registers; a lane
+// whose path has ended fetches the ray of the sample it is handed with ds_bpermute.  Lanes finish a few at a time
+// (a NEW pass found 6 of 64 lanes waiting on average), so the hash, the two Sobol loads and the camera
+// transform ran at a tenth of the vector width when every lane prepared its own.
+struct PrimaryPool {
+    V3 ro, rd;
+    int rng_i, rng_k;          // the pixel's proxy after the two jitter draws; rng_k < 0: no such pixel (tile past the edge)
+};
+DEV void pool_prepare(const MptRenderParams &p, PrimaryPool &pp, bool inside, int i, int j, int frame) {
+    pp.ro = v3s(0.0f); pp.rd = v3s(0.0f); pp.rng_i = 0; pp.rng_k = -1;
+    if (inside) {
+        LaneState T;
+        T.frame = frame;
+        T.rng_i = wanghash2(i, j);                                           // path.py:72-73
+        T.rng_k = reduce_mod_dim(T.rng_i, p.sobol_dim, p.sobol_inv_dim);
+        float jit[2];
+        lane_draws<2>(p, T, jit);                                            // random2: dx then dy, path.py:87
+        float x = m_div((float)i + jit[0], (float)p.nx) * 2.0f - 1.0f;
+        float y = m_div((float)j + jit[1], (float)p.ny) * 2.0f - 1.0f;
+        camera_generate(p, x, y, &pp.ro, &pp.rd);
+        pp.rng_i = T.rng_i; pp.rng_k = T.rng_k;
+    }
 }
+DEV float lane_from(float v, int byte_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_lane, __float_as_int(v))); }
+DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(byte_lane, v); }
 
 #ifndef MPT_NODE_REP
 #define MPT_NODE_REP 2        // extra NODE steps per decision (MI355X: 0 / 1 / 2 / 3 -> 4.03 / 3.85 / 3.72 / 3.72 ms with one extra LEAF step)
@@ -546,6 +555,9 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     int ti = 0, tj = 0, f0 = 0, tx_cur = 0;
     int ndead = 0;                                  // wave-uniform: lanes that have left for good
     bool more = true;
+    PrimaryPool pool;                               // lane l: primary ray of sample pool_base + l of the current item
+    pool.ro = v3s(0.0f); pool.rd = v3s(0.0f); pool.rng_i = 0; pool.rng_k = -1;
+    int pool_base = -64;
 #if MPT_X_STAMPS
     unsigned long long acc_node = 0, acc_leaf = 0, acc_sdone = 0, acc_shade = 0, acc_new = 0;
     const unsigned long long stamp_start = __builtin_amdgcn_s_memtime();
@@ -640,27 +652,40 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                     ti = p.x0 + st * p.stripe_pitch + ((tx - st * tps_x) << tws); tj = ty << ths; tx_cur = tx;
                     f0 = chunk * p.chunk;
                     S = (min(f0 + p.chunk, p.nframes) - f0) << tps;
-                    next = 0;
+                    next = 0; pool_base = -64;
                 }
             }
             if (next < S) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_new++;
-                // idle lanes take the next consecutive samples (neighbouring pixels of one frame)
-                int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_new >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_new, 0u));
-                if (L.st == ST_NEW) {
-                    int smp = next + rank;
-                    if (smp < S) {
-                        int q = smp & ((1 << tps) - 1);
-                        int i = ti + (q >> ths), j = tj + (q & ((1 << ths) - 1));
-                        if (i < p.x1 && j < p.ny) {
-                            L.frame = f0 + (smp >> tps);
-                            // slot in this launch's sample slab: the columns of the share packed side by side
-                            L.pix = ((tx_cur << tws) + (q >> ths)) * p.ny + j;
-                            lane_begin<COUNT>(p, L, stk, i, j, cnt);
-                        }
-                    }
+                const int lane = threadIdx.x & 63;
+                if (next >= pool_base + 64) {       // wave-uniform: the pool is used up (or belongs to the last item)
+                    pool_base = next;
+                    const int smp = pool_base + lane;
+                    const int q = smp & ((1 << tps) - 1);
+                    const int i = ti + (q >> ths), j = tj + (q & ((1 << ths) - 1));
+                    pool_prepare(p, pool, smp < S && i < p.x1 && j < p.ny, i, j, f0 + (smp >> tps));
                 }
-                next += (int)__builtin_popcountll(m_new);
+                // idle lanes take the next consecutive samples (neighbouring pixels of one frame)
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_new >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_new, 0u));
+                const int smp = next + rank;
+                const int pool_end = min(S, pool_base + 64);
+                const int src = ((smp - pool_base) & 63) << 2;                 // every lane fetches: bpermute reads active lanes only
+                V3 ro = v3(lane_from(pool.ro.x, src), lane_from(pool.ro.y, src), lane_from(pool.ro.z, src));
+                V3 rd = v3(lane_from(pool.rd.x, src), lane_from(pool.rd.y, src), lane_from(pool.rd.z, src));
+                const int rng_i = lane_from(pool.rng_i, src), rng_k = lane_from(pool.rng_k, src);
+                if (L.st == ST_NEW && smp < pool_end && rng_k >= 0) {
+                    const int q = smp & ((1 << tps) - 1);
+                    L.frame = f0 + (smp >> tps);
+                    // slot in this launch's sample slab: the columns of the share packed side by side
+                    L.pix = ((tx_cur << tws) + (q >> ths)) * p.ny + (tj + (q & ((1 << ths) - 1)));
+                    L.rng_i = rng_i; L.rng_k = rng_k; L.prd = rd;
+                    L.navoid = 0; L.depth = 0;
+                    L.result = v3s(0.0f); L.throughput = v3s(1.0f); L.last_brdf_pdf = 0.0f;
+                    if (COUNT) { cnt.samples++; cnt.n_draws += 2; }
+                    lane_next_bounce<COUNT>(p, L, stk, ro, cnt);
+                }
+                // NEW lanes beyond the pool's end keep waiting: the next pass prepares the next 64 samples
+                next = min(next + (int)__builtin_popcountll(m_new), pool_end);
             } else if (!more) {
                 if (L.st == ST_NEW) L.st = ST_DEAD;  // nothing left anywhere: those lanes are done
                 ndead += (int)__builtin_popcountll(m_new);
