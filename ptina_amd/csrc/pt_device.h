@@ -964,6 +964,20 @@ DEV float power_heuristic(float a, float b) {                                // 
 }
 
 // ---------------------------------------------------------------- lights
+#if !MPT_STRICT && defined(__HIP_DEVICE_COMPILE__)     // (the host pass only parses this file)
+// Production build: the light records are read through the constant address space, so a wave-uniform index (the
+// loop of lights_hit; the one light of a one-light scene in lights_sample) becomes scalar loads through the
+// scalar cache instead of a 64-lane gather of one address that the stage then waits a full L2 round trip for
+typedef const __attribute__((address_space(4))) MptLight *LightPtr;
+DEV LightPtr lights_const(const MptLight *g) {
+    LightPtr q = (LightPtr)(const void *)g;
+    asm("" : "+s"(q));         // forget that this was a global pointer (or the compiler turns the reads back into global loads)
+    return q;
+}
+#define MPT_LIGHTS(p) lights_const((p).lights)
+#else
+#define MPT_LIGHTS(p) ((p).lights)
+#endif
 DEV V3 axes_mul(const MptLight &L, V3 v) {
     return v3(L.ax0.x * v.x + L.ax0.y * v.y + L.ax0.z * v.z,
               L.ax1.x * v.x + L.ax1.y * v.y + L.ax1.z * v.z,
@@ -975,7 +989,7 @@ struct LightHit { bool hit; float dis, pdf; V3 color; };
 DEV LightHit lights_hit(const MptRenderParams &p, V3 ro, V3 rd) {            // light/__init__.py:51-81
     LightHit ret; ret.hit = false; ret.dis = MPT_INF; ret.pdf = 0.0f; ret.color = v3s(0.0f);
     for (int i = 0; i < p.nlights; i++) {
-        MptLight L = p.lights[i];
+        MptLight L = MPT_LIGHTS(p)[i];
         int type = __float_as_int(L.pos_type.w);
         V3 pos = ld3(L.pos_type);
         float size = L.color_size.w;
@@ -1005,45 +1019,59 @@ DEV LightHit lights_hit(const MptRenderParams &p, V3 ro, V3 rd) {            // 
 
 struct LightSample { float dis; V3 dir; float pdf; V3 color; };
 
+DEV LightSample light_sample_one(const MptLight &L, V3 hitpos, V3 samp) {      // light/__init__.py:90-121
+    LightSample ret;
+    int type = __float_as_int(L.pos_type.w);
+    V3 color = ld3(L.color_size);
+    V3 pos = ld3(L.pos_type);
+    float size = L.color_size.w;
+
+    V3 litpos = v3s(MPT_INF);
+    V3 norm = v3s(0.0f);
+    float area = 0.0f;
+    if (type == 1) {
+        V3 disp = spherical(samp.x, samp.y);
+        litpos = pos + disp * size;
+        area = MPT_PI * (size * size);
+    } else if (type == 2) {
+        V3 disp = axes_mul(L, v3(samp.x * 2.0f - 1.0f, samp.y * 2.0f - 1.0f, 0.0f));
+        norm = axes_mul(L, v3(0.0f, 0.0f, 1.0f));
+        litpos = pos + disp * size;
+        area = 4.0f * (size * size);
+    }
+    V3 toli = litpos - hitpos;
+    float d2 = norm_sqr(toli);
+#if MPT_STRICT
+    float dis = sqrtf(d2);
+    V3 dir = vdivs(toli, dis);
+    float pdf = dis * dis / area;
+#else
+    float rdis = __builtin_amdgcn_rsqf(d2);
+    float dis = d2 * rdis;
+    V3 dir = toli * rdis;
+    float pdf = dis * dis * __builtin_amdgcn_rcpf(area);
+#endif
+    color = vdivs(color, pdf);
+    if (any_ne0(norm)) color = color * dot_or_zero(norm, dir);
+    ret.dis = dis; ret.dir = dir; ret.pdf = pdf; ret.color = color;
+    return ret;
+}
+
 DEV LightSample lights_sample(const MptRenderParams &p, V3 hitpos, V3 samp) {   // light/__init__.py:83-121
     LightSample ret; ret.dis = MPT_INF; ret.dir = v3s(0.0f); ret.pdf = 0.0f; ret.color = v3s(0.0f);
+#if !MPT_STRICT
+    // one light: samp.z < 1 (a Sobol point), so floor(samp.z * 1) is 0 -- the record is read with scalar loads and
+    // its fields are scalar operands of the arithmetic (own copy of the code, so that nothing merges the two reads)
+    if (p.nlights == 1) {
+        const MptLight L = MPT_LIGHTS(p)[0];
+        return light_sample_one(L, hitpos, samp);
+    }
+#endif
     if (p.nlights != 0) {
         int i = (int)floorf(samp.z * (float)p.nlights);
         i = min(max(i, 0), min(p.nlights, MPT_MAX_LIGHTS - 1));
-        MptLight L = p.lights[i];
-        int type = __float_as_int(L.pos_type.w);
-        V3 color = ld3(L.color_size);
-        V3 pos = ld3(L.pos_type);
-        float size = L.color_size.w;
-
-        V3 litpos = v3s(MPT_INF);
-        V3 norm = v3s(0.0f);
-        float area = 0.0f;
-        if (type == 1) {
-            V3 disp = spherical(samp.x, samp.y);
-            litpos = pos + disp * size;
-            area = MPT_PI * (size * size);
-        } else if (type == 2) {
-            V3 disp = axes_mul(L, v3(samp.x * 2.0f - 1.0f, samp.y * 2.0f - 1.0f, 0.0f));
-            norm = axes_mul(L, v3(0.0f, 0.0f, 1.0f));
-            litpos = pos + disp * size;
-            area = 4.0f * (size * size);
-        }
-        V3 toli = litpos - hitpos;
-        float d2 = norm_sqr(toli);
-#if MPT_STRICT
-        float dis = sqrtf(d2);
-        V3 dir = vdivs(toli, dis);
-        float pdf = dis * dis / area;
-#else
-        float rdis = __builtin_amdgcn_rsqf(d2);
-        float dis = d2 * rdis;
-        V3 dir = toli * rdis;
-        float pdf = dis * dis * __builtin_amdgcn_rcpf(area);
-#endif
-        color = vdivs(color, pdf);
-        if (any_ne0(norm)) color = color * dot_or_zero(norm, dir);
-        ret.dis = dis; ret.dir = dir; ret.pdf = pdf; ret.color = color;
+        const MptLight L = MPT_LIGHTS(p)[i];
+        ret = light_sample_one(L, hitpos, samp);
     }
     return ret;
 }
@@ -1095,30 +1123,37 @@ DEV void get_geometries(const MptRenderParams &p, const Hit &hit, V3 ro, V3 rd, 
     material_get(p, __float_as_int(s3.w), tu, tv, mat);
 }
 
-// the same with the material served by the scene (LDS-resident kernel)
-template <class SCENE>
-DEV void get_geometries_in(const MptRenderParams &p, const SCENE &sc, const Hit &hit, V3 ro, V3 rd, V3 *hitpos, V3 *normal,
-                           Disney &mat) {
 #if !MPT_STRICT
+// Production SHADE: the shading record is fetched by the caller ahead of everything else in the stage (its
+// round trip to L2 then overlaps the light tests instead of following them), the material comes from the scene
+// (LDS-resident kernel) or from the record's material id
+struct ShadeRec { MptVec4 s0, s1, s2, s3; };
+DEV ShadeRec shade_rec_load(const MptRenderParams &p, int slot) {
+    const MptVec4 *s = p.tshade + (size_t)slot * 4;
+    ShadeRec r; r.s0 = s[0]; r.s1 = s[1]; r.s2 = s[2]; r.s3 = s[3];
+    return r;
+}
+template <class SCENE>
+DEV void get_geometries_rec(const MptRenderParams &p, const SCENE &sc, const ShadeRec &r, const Hit &hit, V3 ro, V3 rd,
+                            V3 *hitpos, V3 *normal, Disney &mat) {
+    const MptVec4 s0 = r.s0, s1 = r.s1, s2 = r.s2, s3 = r.s3;
+    float u = hit.u, v = hit.v;
+    float wx = 1.0f - u - v, wy = u, wz = v;
+    V3 vn0 = v3(s0.x, s0.y, s0.z), vn1 = v3(s0.w, s1.x, s1.y), vn2 = v3(s1.z, s1.w, s2.x);
+    V3 nrm = normalized(vn0 * wx + vn1 * wy + vn2 * wz);
+    float tu = wx * s2.y + wy * s2.w + wz * s3.y;
+    float tv = wx * s2.z + wy * s3.x + wz * s3.z;
+    *hitpos = ro + rd * hit.depth;
+    float sign = -dot(rd, nrm);
+    if (sign < 0.0f) nrm = -nrm;
+    *normal = nrm;
     if constexpr (SCENE::LDS_MATS) {
-        const MptVec4 *s = p.tshade + (size_t)hit.index * 4;
-        MptVec4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
         const int rec = sc.mtl[hit.index];
         LdsVec4Ptr q = sc.mats + rec * MPT_LDS_MAT_VEC4;
         MptVec4 q0 = lds_ld(q), q1 = lds_ld(q + 1), q2 = lds_ld(q + 2), q3 = lds_ld(q + 3), d0 = lds_ld(q + 4), d1 = lds_ld(q + 5);
-        float u = hit.u, v = hit.v;
-        float wx = 1.0f - u - v, wy = u, wz = v;
-        V3 vn0 = v3(s0.x, s0.y, s0.z), vn1 = v3(s0.w, s1.x, s1.y), vn2 = v3(s1.z, s1.w, s2.x);
-        V3 nrm = normalized(vn0 * wx + vn1 * wy + vn2 * wz);
-        float tu = wx * s2.y + wy * s2.w + wz * s3.y;
-        float tv = wx * s2.z + wy * s3.x + wz * s3.z;
-        *hitpos = ro + rd * hit.depth;
-        float sign = -dot(rd, nrm);
-        if (sign < 0.0f) nrm = -nrm;
-        *normal = nrm;
         material_from(p, p.mats + rec, q0, q1, q2, q3, d0, d1, tu, tv, mat);
-        return;
+    } else {
+        material_get(p, __float_as_int(s3.w), tu, tv, mat);
     }
-#endif
-    get_geometries(p, hit, ro, rd, hitpos, normal, mat);
 }
+#endif

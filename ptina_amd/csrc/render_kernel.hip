@@ -430,6 +430,15 @@ DEV void stage_shade(const MptRenderParams &p, const SCENE &sc, LaneState &L, ST
     V3 ro = L.to, rd = L.prd;
     const bool was_hit = L.hidx >= 0;
     float hdepth = was_hit ? L.tbest : MPT_INF;
+    // everything the stage gathers from L2 is asked for first: the shading record of the triangle and the six
+    // Sobol numbers of the bounce (path.py:48,58: light triple, then BSDF triple) -- one round trip, under the
+    // light tests, instead of three in a row
+    ShadeRec rec = {};
+    float u[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    if (was_hit) {
+        rec = shade_rec_load(p, L.hidx);
+        lane_draws<6>(p, L, u);
+    }
     LightHit lit = lights_hit(p, ro, rd);
     if (lit.hit && (!was_hit || lit.dis < hdepth)) {
         float mis = power_heuristic(L.last_brdf_pdf, lit.pdf);
@@ -444,13 +453,11 @@ DEV void stage_shade(const MptRenderParams &p, const SCENE &sc, LaneState &L, ST
     L.navoid = ~L.hidx;
     Hit hit; hit.hit = 1; hit.depth = hdepth; hit.index = L.hidx; hit.u = L.hu; hit.v = L.hv;
     V3 hitpos, normal; Disney mat;
-    get_geometries_in(p, sc, hit, ro, rd, &hitpos, &normal, mat);
+    get_geometries_rec(p, sc, rec, hit, ro, rd, &hitpos, &normal, mat);
     if (COUNT) { cnt.n_shade++; cnt.n_draws += 6; }
     float sign = -dot(rd, normal);                                           // path.py:44-46 (never negative)
     if (sign < 0.0f) normal = -normal;
 
-    float u[6];                                                              // path.py:48,58: light triple, then BSDF triple
-    lane_draws<6>(p, L, u);
     LightSample li = lights_sample(p, hitpos, v3(u[0], u[1], u[2]));
     bool want_shadow = any_gt0(li.color);
     L.direct = v3s(0.0f);
@@ -501,6 +508,10 @@ DEV void pool_prepare(const MptRenderParams &p, PrimaryPool &pp, bool inside, in
 DEV float lane_from(float v, int byte_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_lane, __float_as_int(v))); }
 DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(byte_lane, v); }
 
+#ifndef MPT_LEAVE_A
+#define MPT_LEAVE_A 2    // leave traversal mode when traversing * A < waiting * B
+#define MPT_LEAVE_B 1
+#endif
 #ifndef MPT_NODE_REP
 #define MPT_NODE_REP 2        // extra NODE steps per decision (MI355X: 0 / 1 / 2 / 3 -> 4.03 / 3.85 / 3.72 / 3.72 ms with one extra LEAF step)
 #endif
@@ -590,7 +601,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             if (trav == 0) break;
             // leave when the waiting lanes (DONE or NEW: everything alive that is not traversing) outnumber the
             // traversing ones 2 : 1 (best of the ratios tried on MI355X)
-            if (trav * 2 < 64 - ndead - trav) break;
+            if (trav * MPT_LEAVE_A < (64 - ndead - trav) * MPT_LEAVE_B) break;
             MPT_STAMP_BEGIN
             if (cn >= cl) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;

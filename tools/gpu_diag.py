@@ -454,6 +454,36 @@ def sync_sweep(name='s978', spp=32, n=512, steps=15):
     common.reset_all()
 
 
+def readback(name='s978', spp=32, n=512, rounds=50):
+    '''what the end of a step costs on an otherwise idle GPU: get_image() (resolve kernel + D2H + the numpy
+    array) against resolve + synchronize alone'''
+    common.reset_all()
+    eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
+    c = ctx()
+    c.set_option('batch', spp)
+    eng.render(spp)
+    FilmTable().get_image()
+    res = {}
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        FilmTable().get_image()
+    res['get_image_us'] = (time.perf_counter() - t0) / rounds * 1e6
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        c.call('mpt_resolve', 0)
+        c.call('mpt_synchronize')
+    res['resolve_sync_us'] = (time.perf_counter() - t0) / rounds * 1e6
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        c.call('mpt_synchronize')
+    res['sync_only_us'] = (time.perf_counter() - t0) / rounds * 1e6
+    res['image_bytes'] = n * n * 16
+    print('readback', json.dumps(res), flush=True)
+    out['readback'] = res
+    save()
+    common.reset_all()
+
+
 def stamps(name='s978', spp=32, n=512):
     '''needs a library built with -DMPT_X_STAMPS=1 (MIPTINA_LIB): shader-clock shares of the stages of the
     counting LDS kernel, per wave: NODE steps, LEAF steps, shadow-ray restarts, SHADE, NEW (+ pull), the rest
@@ -485,6 +515,8 @@ if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
     if 'stamps' in what:
         stamps()
+    if 'readback' in what:
+        readback()
     if 'sync_sweep' in what:
         sync_sweep()
     if 'probe' in what:

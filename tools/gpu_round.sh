@@ -33,6 +33,7 @@ for step in "$@"; do
     big_ab)      MIPTINA_WIDE=0 run big_bin 400 python tools/run_configs.py C4 C5; MIPTINA_WIDE=1 run big_wide 400 python tools/run_configs.py C4 C5 ;;
     c5sah)       run c5sah 600 python tools/gpu_diag.py c5sah ;;
     probe)       run probe 300 python tools/gpu_diag.py probe ;;
+    readback)    run readback 200 python tools/gpu_diag.py readback ;;
     sync_sweep)  run sync_sweep 300 python tools/gpu_diag.py sync_sweep ;;
     ubench)      run ubench 200 tools/microbench/valu_microbench --json ;;
     ubench_pmc)  run ubench_pmc 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/ubench_pmc -- tools/microbench/valu_microbench ;;
