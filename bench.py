@@ -175,6 +175,13 @@ def roofline_blocks(pmc, source, kernel, avg_kernel_s, clock_hz, concurrent):
     return roof, hbm
 
 
+def algorithmic_flops(c):
+    '''~30 flop per box test (6 divides included), ~60 per triangle test, 150-300 per shaded
+    hit (225 taken), of the traversal actually run (counting build).  Unlike the executed-instruction figures of
+    `roofline` this one does not fall when an optimisation removes instructions: it is work / time.'''
+    return 30.0 * c['n_box'] + 60.0 * c['n_tri'] + 225.0 * c['n_shade']
+
+
 def algorithmic_bytes(c):
     '''film float4 read+write, 4 B per Sobol draw, 32 B per box test
     (bmin+bmax+children), 40 B per triangle test (leaf id + 3 positions), and per shaded hit 64 B
@@ -377,6 +384,13 @@ def run_rank(args, rank, world, pmc, pmc_source):
                             'GB/s': round(algorithmic_bytes(cnt) / W * concurrent / avg_kernel_s / 1e9, 1),
                             'note': 'SURVEY 8(d) bytes of the traversal actually run (counting build), served from LDS: '
                                     'NOT an HBM figure and not a roofline fraction'},
+            'algorithmic_flops': {'flop_per_sample': round(algorithmic_flops(cnt) / max(cnt['samples'], 1), 1),
+                                  'TFLOP/s': round(algorithmic_flops(cnt) / W * concurrent / avg_kernel_s / 1e12, 3),
+                                  'peak': round(2 * N_SIMD * SIMD_LANES * clock_hz / 1e12, 1),
+                                  'frac': round(algorithmic_flops(cnt) / W * concurrent / avg_kernel_s / (2 * N_SIMD * SIMD_LANES * clock_hz), 4),
+                                  'note': 'SURVEY 8(d) per-unit flops (30 / box test, 60 / triangle test, 225 / shaded hit) x the '
+                                          'counted units of one launch / its duration, against the f32 vector FMA peak: '
+                                          'rises with speed whatever the instruction count, unlike roofline.frac'},
             'counters_per_sample': {k: round(v / max(cnt['samples'], 1), 3) for k, v in cnt.items() if k != 'samples'},
             'mrays_per_s': round(cnt['rays'] / W * concurrent / avg_kernel_s / 1e6, 1),
             'samples_per_launch': int(samples_per_launch),
