@@ -254,11 +254,14 @@ struct WideScene {
     // going up the axis and 16 (bytes: the next float4) for one going down -- still seven dwordx4 gathers
     DEV void node4(int i, int ox, int oy, int oz, MptVec4 &nx, MptVec4 &fx, MptVec4 &ny, MptVec4 &fy, MptVec4 &nz,
                    MptVec4 &fz, MptVec4 &id) const {
-        const char *nd = (const char *)(wnode + (size_t)i * 8);
-        nx = *(const MptVec4 *)(nd + ox);      fx = *(const MptVec4 *)(nd + (ox ^ 16));
-        ny = *(const MptVec4 *)(nd + 32 + oy); fy = *(const MptVec4 *)(nd + 32 + (oy ^ 16));
-        nz = *(const MptVec4 *)(nd + 64 + oz); fz = *(const MptVec4 *)(nd + 64 + (oz ^ 16));
-        id = *(const MptVec4 *)(nd + 96);
+        // 32-bit byte offsets from the (scalar) array base: one v_add_u32 per gather instead of a 64-bit add
+        // (the host keeps the array below 2 GiB: mpt_build_tree)
+        const char *base = (const char *)wnode;
+        const unsigned o = (unsigned)i << 7;
+        nx = *(const MptVec4 *)(base + (o + (unsigned)ox));      fx = *(const MptVec4 *)(base + (o + (unsigned)(ox ^ 16)));
+        ny = *(const MptVec4 *)(base + 32 + (o + (unsigned)oy)); fy = *(const MptVec4 *)(base + 32 + (o + (unsigned)(oy ^ 16)));
+        nz = *(const MptVec4 *)(base + 64 + (o + (unsigned)oz)); fz = *(const MptVec4 *)(base + 64 + (o + (unsigned)(oz ^ 16)));
+        id = *(const MptVec4 *)(base + 96 + o);
     }
     DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2, MptVec4 &g3) const {
         const MptVec4 *g = tgeo + (size_t)slot * 4;

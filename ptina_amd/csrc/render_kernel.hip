@@ -376,13 +376,25 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     MPT_CSWAP(k0, id0, k1, id1) MPT_CSWAP(k2, id2, k3, id3) MPT_CSWAP(k0, id0, k2, id2) MPT_CSWAP(k1, id1, k3, id3)
     MPT_CSWAP(k1, id1, k2, id2)
 #undef MPT_CSWAP
-    stk.sp = L.sp;
-    if (k3 != MISS) stk.push(id3);
-    if (k2 != MISS) stk.push(id2);
-    if (k1 != MISS) stk.push(id1);
     int next = id0;
-    if (k0 == MISS) next = stk.pop();
-    L.sp = stk.sp;
+    if (__ballot(L.sp > STACK::CAP - 3) == 0ull) {
+        // no lane of the wave is within three entries of the LDS part of its stack (the rule, not the exception):
+        // the three pushes are plain stores at a running index -- a store that is not wanted lands on the slot
+        // the next one overwrites -- instead of three divergent regions with a spill test each
+        int sp = L.sp;
+        stk.base[sp * MPT_BLOCK] = id3; sp += k3 != MISS ? 1 : 0;
+        stk.base[sp * MPT_BLOCK] = id2; sp += k2 != MISS ? 1 : 0;
+        stk.base[sp * MPT_BLOCK] = id1; sp += k1 != MISS ? 1 : 0;
+        if (k0 == MISS) { sp--; next = stk.base[sp * MPT_BLOCK]; }           // sorted: then nothing was pushed
+        L.sp = sp;
+    } else {
+        stk.sp = L.sp;
+        if (k3 != MISS) stk.push(id3);
+        if (k2 != MISS) stk.push(id2);
+        if (k1 != MISS) stk.push(id1);
+        if (k0 == MISS) next = stk.pop();
+        L.sp = stk.sp;
+    }
     L.curr = next;
     L.st = classify<STACK>(next);
 }

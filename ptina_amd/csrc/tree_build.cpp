@@ -580,6 +580,7 @@ static int make_wide(mpt_ctx *c) {
     // a step pushes up to three entries: 3 x depth + sentinel must fit the LDS levels plus the spill strip
     if (3 * depth + 2 > 128) return 0;      // too deep (40 LDS levels + 88 spilled): the gather kernel keeps walking the binary tree
     const size_t nw = bin_of.size();
+    if (nw * 8 * sizeof(MptVec4) >= ((size_t)1 << 31)) return 0;   // the kernel addresses the records with 32-bit byte offsets
     if (nw > c->wnode_cap) {
         hipFree(c->wnode); c->wnode = nullptr; c->wnode_cap = 0;
         if (dev_alloc(&c->wnode, nw * 8)) return 1;
