@@ -353,7 +353,7 @@ def run_rank(args, rank, world, pmc, pmc_source):
         total = NX * NY * SPP * args.steps
         avg_kernel_s = kms / 1e3 / max(nlaunch, 1)
         # small launches (N > 1 shares) take 1/G of the CUs each and G of them are resident at once
-        concurrent = max(c.get_option('cur_div'), 1)
+        concurrent = max(c.get_option('last_div'), 1)
         kernel = render_kernel_name(args.mode, c.get_option('last_kernel'))
         clock_hz = c.get_option('clock_khz') * 1e3 or 2.4e9
         if pmc is None and world == 1:

@@ -81,13 +81,14 @@ void mpt_destroy(mpt_ctx *ctx);
  * "wide" (scenes that do not fit LDS: 1 = walk the fast tree collapsed into 4-wide nodes, default; 0 = the
  * binary tree), "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
  * walks the LBVH itself; default 2^22), "grid_div" (each launch takes 1/G of the CUs so that G launches are resident
- * in different phases; 0 = choose by samples per lane, default), "pipe_depth" (batches in flight,
+ * in different phases; 0 = choose by samples per lane, and the whole chip for a launch that finds nothing else in flight: default), "pipe_depth" (batches in flight,
  * 2..6; 0 = auto), "lds_block" (lanes per persistent workgroup of the LDS kernel, diagnostics),
  * "timeline" (1 = record mpt_get_timeline data), "reserve_cus" (CUs every persistent render launch leaves
  * unclaimed, default 0; measured to be of no use to foreign kernels while launches overlap, kept for experiments).
  * read-only: "tree_depth", "fast_depth", "wide_nodes", "wide_depth", "wide_ratio_permille", "pending", "last_kernel" (0 = gather over
  * the binary tree, 1 = LDS-resident, 2 = gather over 4-wide nodes), "num_cus",
- * "cur_div", "cur_depth" (what the last launch used) */
+ * "cur_div", "cur_depth" (the ring the last launch belonged to: G launches of 1/G of the CUs, that many batches in
+ * flight), "last_div" (what the last launch really took: 1 when it found the ring idle, else cur_div) */
 int mpt_set_option(mpt_ctx *ctx, const char *key, int value);
 int mpt_get_option(mpt_ctx *ctx, const char *key, int *value);
 

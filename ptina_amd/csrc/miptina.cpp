@@ -316,6 +316,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "grid_div") *value = c->grid_div;
     else if (k == "cur_depth") *value = c->cur_depth;
     else if (k == "cur_div") *value = c->cur_div;
+    else if (k == "last_div") *value = c->last_div;
     else if (k == "last_kernel") *value = c->last_kernel;
     else if (k == "num_cus") *value = c->num_cus;
     else if (k == "reserve_cus") *value = c->reserve_cus;
@@ -726,7 +727,21 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     // read-back (bench.py's `value`) has no other launch in flight when its gather starts.
     const int reserve = std::max(c->reserve_cus, 0);
     const int usable_cus = std::max(c->num_cus - reserve, 1);
-    const int launch_cus = std::max(usable_cus / std::max(c->cur_div, 1), 1);   // G launches never claim more than usable_cus
+    // A launch that finds the ring idle has no other launch to share the chip with -- a step that ends with a
+    // read-back (bench.py's `value`, an interactive frame) is one launch at a time -- so it takes every CU; 1/G of
+    // them would only make it G times longer.  Launches issued while others are still in flight take 1/G each.
+    int launch_div = std::max(c->cur_div, 1);
+    if (fast && launch_div > 1 && c->grid_div <= 0) {
+        bool ring_idle = true;
+        for (int q = 0; q < c->cur_depth && ring_idle; q++) {
+            hipError_t st = hipEventQuery(c->ev_render[q]);
+            if (st == hipErrorNotReady) ring_idle = false;
+            else if (st != hipSuccess) HIP_TRY(st);
+        }
+        if (ring_idle) launch_div = 1;
+    }
+    c->last_div = launch_div;
+    const int launch_cus = std::max(usable_cus / launch_div, 1);   // G launches never claim more than usable_cus
     // scenes that do not fit LDS walk the 4-wide nodes (option "wide"; built by mpt_build_tree unless too deep)
     // A wide step costs ~2x the VALU instructions of a binary one (four slab tests and a sorting network) and makes
     // half the dependent fetches; with the planes picked by direction sign it wins on both big configurations

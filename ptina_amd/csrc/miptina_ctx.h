@@ -74,6 +74,7 @@ struct mpt_ctx {
     int num_cus = 256;
     int clock_khz = 0;                   // hipDeviceProp_t.clockRate: peak shader clock (roofline peaks in bench.py)
     int tile_w_shift = 3, tile_h_shift = 3;   // work-item tile 2^w x 2^h pixels
+    int last_div = 1;                    // share of the chip the last launch took: 1/last_div of the CUs
     int last_kernel = 0;                 // 0 gather kernel, 1 LDS-resident kernel (what the last flush launched)
 
     // film

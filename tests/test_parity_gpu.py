@@ -291,6 +291,27 @@ def test_launch_pipelining_does_not_change_the_film(fresh):
         assert np.array_equal(film, ref), key
 
 
+def test_a_launch_that_finds_the_gpu_idle_takes_the_whole_chip(fresh):
+    '''small shares render as G launches on 1/G of the CUs each, so that G of them overlap -- but a step that
+    ends with a read-back has one launch in flight at a time: that launch must not be confined to 1/G of the
+    chip (a 1/8 share of the benchmark film took 1.69 ms that way instead of 0.90)'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx
+    eng = _engine(None, scenes.scene_s978(), 512, 512, mode='fast')
+    c = ctx()
+    c.set_option('batch', 8)
+    c.call('mpt_set_stripes', 16, 0, 8)
+    for _ in range(3):
+        eng.render(8)
+        FilmTable().get_image()                     # blocks: nothing is in flight when the next launch is issued
+        assert c.get_option('cur_div') == 4         # the ring is laid out for four overlapping launches ...
+        assert c.get_option('last_div') == 1        # ... and this one found it idle
+    c.set_option('grid_div', 4)                     # an explicit G is honoured as given
+    eng.render(8)
+    FilmTable().get_image()
+    assert c.get_option('last_div') == 4
+
+
 def test_lights_and_area_light_parity(fresh, oracle_mod):
     from helpers import setup_oracle, assert_parity
     from ptina_amd.things import FilmTable

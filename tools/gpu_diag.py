@@ -224,6 +224,39 @@ def slabs(name='s978', spp=32, n=512, steps=20, tiles=((3, 3),), lds=(1, 0)):
     return res
 
 
+def shares_sync(name='s978', spp=32, n=512, steps=20):
+    '''what ONE rank of N does per benchmark step when the step ends with a read-back (bench.py's `value`:
+    one launch at a time): its stripes' share rendered, resolved and read back, without the gather'''
+    res = {}
+    for parts, forced in ((1, 0), (2, 0), (2, 2), (4, 0), (4, 2), (8, 0), (8, 4)):
+        common.reset_all()
+        eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
+        c = ctx()
+        c.set_option('batch', spp)
+        if forced:
+            c.set_option('grid_div', forced)      # what the samples-per-lane rule alone would pick (before: always)
+        if parts > 1:
+            c.call('mpt_set_stripes', 16, 0, parts)
+        for _ in range(3):
+            eng.render(spp)
+            FilmTable().get_image()
+        c.kernel_time()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.render(spp)
+            FilmTable().get_image()
+        dt = (time.perf_counter() - t0) / steps * 1e3
+        kms, nl = c.kernel_time()
+        key = f'{parts}' + (f' grid_div={forced}' if forced else '')
+        res[key] = {'step_ms': round(dt, 4), 'kernel_ms': round(kms / max(nl, 1), 4), 'last_div': c.get_option('last_div'),
+                    'cur_div': c.get_option('cur_div'), 'speedup_vs_1': None}
+        res[key]['speedup_vs_1'] = round(res.get('1', res[key])['step_ms'] / dt, 3)
+        print('shares_sync', key, json.dumps(res[key]), flush=True)
+    out['shares_sync'] = res
+    save()
+    common.reset_all()
+
+
 def blk(name='s978', spp=32, n=512, steps=20, opt='lds_block', values=(1024, 768, 512, 256)):
     '''an option (threads per persistent workgroup, reserved CUs) vs launch size: pipelined step and solo kernel time'''
     res = {}
@@ -517,6 +550,8 @@ if __name__ == '__main__':
         stamps()
     if 'readback' in what:
         readback()
+    if 'shares_sync' in what:
+        shares_sync()
     if 'sync_sweep' in what:
         sync_sweep()
     if 'probe' in what:
