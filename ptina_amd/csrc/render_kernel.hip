@@ -527,6 +527,9 @@ DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(by
 #ifndef MPT_NODE_REP
 #define MPT_NODE_REP 2        // extra NODE steps per decision (MI355X: 0 / 1 / 2 / 3 -> 4.03 / 3.85 / 3.72 / 3.72 ms with one extra LEAF step)
 #endif
+#ifndef MPT_WIDE_REP
+#define MPT_WIDE_REP 0        // extra 4-wide NODE steps per decision (gather kernels)
+#endif
 #ifndef MPT_LEAF_REP
 #define MPT_LEAF_REP 1        // extra LEAF steps per decision (0 / 1 / 2 -> 3.83 / 3.72 / 3.77 ms with two extra NODE steps)
 #endif
@@ -632,6 +635,16 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                         if (L.st == ST_NODE) stage_node<COUNT>(sc, stk, L, cnt);
                     }
                 }
+#if MPT_WIDE_REP
+                else {
+#pragma unroll
+                    for (int rep = 0; rep < MPT_WIDE_REP; rep++) {
+                        if (__ballot(L.st == ST_NODE) == 0ull) break;
+                        if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
+                        if (L.st == ST_NODE) stage_node4<COUNT>(sc, stk, L, cnt);
+                    }
+                }
+#endif
 #endif
                 MPT_STAMP_END(acc_node)
             } else {

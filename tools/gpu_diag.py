@@ -235,6 +235,8 @@ def shares_sync(name='s978', spp=32, n=512, steps=20):
         c.set_option('batch', spp)
         if forced:
             c.set_option('grid_div', forced)      # what the samples-per-lane rule alone would pick (before: always)
+        for kv in filter(None, os.environ.get('MIPTINA_OPTS', '').split(',')):
+            c.set_option(kv.split('=')[0], int(kv.split('=')[1]))
         if parts > 1:
             c.call('mpt_set_stripes', 16, 0, parts)
         for _ in range(3):

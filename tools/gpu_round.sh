@@ -43,6 +43,7 @@ for step in "$@"; do
     tests_fast)  run tests_fast 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'fast_build or strict_build or full_size or batching or pipelining or lds_and_gather or lobes or ordered or idle' ;;
     tests_big)   run tests_big 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'config5 or config4 or mid_size or large_scene or lds_and_gather or where_the_tree' ;;
     big_wide)    MIPTINA_WIDE=1 run big_wide 400 python tools/run_configs.py C4 C5 ;;
+    big_ablibs)  for L in $ABLIBS; do MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_$L.so run big_$L 400 python tools/run_configs.py C4 C5; done ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
     tests_all)   run tests_all 900 python -m pytest tests -m gpu -q ;;
     bench)       run bench 600 python bench.py ;;
