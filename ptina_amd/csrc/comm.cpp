@@ -110,17 +110,26 @@ extern "C" int mpt_comm_gather_film(mpt_ctx *c, int pass, int root) {
     };
     std::vector<std::pair<size_t, size_t>> pc;
     NCCL_TRY(g_rccl.GroupStart());
+    ncclResult_t bad = ncclSuccess;                // a failing call must not leave the group open
     if (c->rank == root) {
-        for (int r = 0; r < R; r++) {
+        for (int r = 0; r < R && bad == ncclSuccess; r++) {
             if (r == root) continue;
             pieces(r, pc);
-            for (auto &q : pc) NCCL_TRY(g_rccl.Recv(c->film[pass] + q.first, q.second * 4, ncclFloat, r, c->comm, c->stream));
+            for (auto &q : pc) {
+                bad = g_rccl.Recv(c->film[pass] + q.first, q.second * 4, ncclFloat, r, c->comm, c->stream);
+                if (bad != ncclSuccess) break;
+            }
         }
     } else {
         pieces(c->rank, pc);
-        for (auto &q : pc) NCCL_TRY(g_rccl.Send(c->film[pass] + q.first, q.second * 4, ncclFloat, root, c->comm, c->stream));
+        for (auto &q : pc) {
+            bad = g_rccl.Send(c->film[pass] + q.first, q.second * 4, ncclFloat, root, c->comm, c->stream);
+            if (bad != ncclSuccess) break;
+        }
     }
-    NCCL_TRY(g_rccl.GroupEnd());
+    ncclResult_t ended = g_rccl.GroupEnd();
+    if (bad != ncclSuccess) return fail("ncclSend/ncclRecv of the film gather failed: %s", g_rccl.GetErrorString(bad));
+    NCCL_TRY(ended);
     return 0;
 }
 

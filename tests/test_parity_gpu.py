@@ -157,6 +157,35 @@ def test_batching_does_not_change_the_film(fresh, mode):
     assert np.all(films[0][:, 3] == 16)
 
 
+def test_work_item_shape_does_not_change_the_film(fresh):
+    '''work items are (tile, frames) pieces of the launch; a wave prepares the primary rays of 64 consecutive
+    samples of its item at a time: items of 16, 32, 64, 128 and 192 samples (the last one of a launch shorter),
+    on a film whose edges cut tiles, all give the same film bit for bit -- LDS-resident and gather kernels'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    nx, ny = 52, 43
+    films = {}
+    for lds in (1, 0):
+        for tw, th, chunk in ((3, 3, 1), (3, 3, 2), (3, 3, 3), (3, 2, 1), (2, 2, 1), (2, 2, 7), (1, 0, 1)):
+            reset_all()
+            eng = _engine(None, scenes.scene_s978(), nx, ny, mode='fast')
+            c = ctx()
+            c.set_option('lds', lds)
+            c.set_option('batch', 8)
+            c.set_option('tile_w_shift', tw)
+            c.set_option('tile_h_shift', th)
+            c.set_option('chunk', chunk)
+            eng.render(8)
+            eng.render(3)
+            c.call('mpt_flush')
+            films[(lds, tw, th, chunk)] = FilmTable().get_raw().copy()
+    reset_all()
+    ref = films[(1, 3, 3, 1)]
+    assert np.all(ref.reshape(nx, ny, 4)[..., 3] == 11)
+    for key, film in films.items():
+        assert np.array_equal(film, ref), key
+
+
 def test_slabs_reassemble_bit_identically(fresh):
     '''two column slabs rendered separately == the full film (what the multi-GPU path relies on)'''
     from ptina_amd.things import FilmTable
