@@ -79,7 +79,8 @@ void mpt_destroy(mpt_ctx *ctx);
  * "tree" (fast build: 1 = SAH re-partition of the LBVH's leaves, default; 0 = walk the LBVH itself;
  * takes effect at the next mpt_build_tree), "tile_w_shift"/"tile_h_shift" (work-item tile 2^w x 2^h pixels),
  * "wide" (scenes that do not fit LDS: 1 = walk the fast tree collapsed into 4-wide nodes, default; 0 = the
- * binary tree), "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
+ * binary tree), "wide_quant" (1 = the 4-wide nodes as 64-byte records with 8-bit child boxes rounded outwards: four
+ * gathers per step, default; 0 = 128-byte records with the exact boxes: seven), "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
  * walks the LBVH itself; default 2^22), "grid_div" (each launch takes 1/G of the CUs so that G launches are resident
  * in different phases; 0 = choose by samples per lane, and the whole chip for a launch that finds nothing else in flight: default), "pipe_depth" (batches in flight,
  * 2..6; 0 = auto), "lds_block" (lanes per persistent workgroup of the LDS kernel, diagnostics),

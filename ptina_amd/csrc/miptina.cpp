@@ -177,7 +177,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     for (auto &ev : c->event_pool) hipEventDestroy(ev);
     for (int p = 0; p < 3; p++) hipFree(c->film[p]);
     hipFree(c->resolved); hipFree(c->exported);
-    hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade); hipFree(c->wnode); hipFree(c->stack_spill); hipFree(c->fnode_soa);
+    hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade); hipFree(c->wnode); hipFree(c->qnode); hipFree(c->stack_spill); hipFree(c->fnode_soa);
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
@@ -282,6 +282,8 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->node_soa = value ? 1 : 0;
     } else if (k == "wide") {
         c->use_wide = value ? 1 : 0;
+    } else if (k == "wide_quant") {
+        c->use_quant = value ? 1 : 0;
     } else if (k == "tree") {
         if (value != 0 && value != 1) return fail("tree must be 0 (LBVH) or 1 (SAH)");
         if (value != c->tree_kind) { c->tree_kind = value; c->tree_valid = false; }
@@ -321,6 +323,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "num_cus") *value = c->num_cus;
     else if (k == "reserve_cus") *value = c->reserve_cus;
     else if (k == "wide") *value = c->use_wide;
+    else if (k == "wide_quant") *value = c->use_quant;
     else if (k == "wide_nodes") *value = c->wide_nodes;
     else if (k == "wide_ratio_permille") *value = (int)(c->wide_ratio * 1000.f + 0.5f);
     else if (k == "wide_depth") *value = c->wide_depth;
@@ -586,7 +589,7 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     p.ntiles = p.tiles_x * p.tiles_y;
     memcpy(p.world_fac, c->world_fac, sizeof p.world_fac);
     memcpy(p.v2w, c->v2w, sizeof p.v2w);
-    p.wnode = c->wnode; p.stack_spill = c->stack_spill;
+    p.wnode = c->wnode; p.qnode = c->qnode; p.stack_spill = c->stack_spill;
     p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade;
     p.default_mtl = c->caps.max_materials;
     p.mats = c->mats; p.lights = c->lights; p.images = c->images; p.texels = c->texels;
@@ -750,7 +753,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     const bool wide_kernel = fast && !lds_kernel && wide_pays && c->wide_nodes > 0;
     int wide_blocks = 0;
     if (wide_kernel) {
-        HIP_TRY(mpt_wide_blocks(launch_cus, c->count, &wide_blocks));
+        HIP_TRY(mpt_wide_blocks(launch_cus, c->count, c->use_quant, &wide_blocks));
         const size_t need_spill = (size_t)wide_blocks * MPT_BLOCK * 88;   // SpillStack::SPILL entries per lane
         if (need_spill > c->stack_spill_cap) {
             HIP_TRY(hipDeviceSynchronize());
@@ -792,7 +795,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     HIP_TRY(hipEventRecord(e0, rs));
     if (!fast) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, rs));
     else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, launch_cus, c->lds_block ? c->lds_block : 1024, lds_bytes, c->count, rs));
-    else if (wide_kernel) HIP_TRY(mpt_launch_render_wide(&p, wide_blocks, c->count, rs));
+    else if (wide_kernel) HIP_TRY(mpt_launch_render_wide(&p, wide_blocks, c->count, c->use_quant, rs));
     else HIP_TRY(mpt_launch_render_fast(&p, launch_cus, stack, c->count, rs));
     c->last_kernel = lds_kernel ? 1 : wide_kernel ? 2 : 0;
     HIP_TRY(hipEventRecord(e1, rs));

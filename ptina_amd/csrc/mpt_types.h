@@ -8,6 +8,10 @@
 //                           register pairs v_pk_fma_f32 wants:
 //                           {c0.lo.x, c1.lo.x, c0.hi.x, c1.hi.x} {..y..} {..z..} {id0, id1, -, -}
 //                           id >= 0: internal node index; id < 0: leaf, slot = ~id
+//   qnode  float4[nw*4]     quantised 4-wide node (the production gather kernel): {origin.xyz, scale.x} {scale.yz, lo_x, hi_x}
+//                           {lo_y, hi_y, lo_z, hi_z} {ids}: a plane of child c is origin + byte c of the word * scale, boxes
+//                           rounded outwards; four 16-B gathers per step instead of seven (the gathers are what the big
+//                           scenes wait for, whatever their width)
 //   wnode  float4[nw*8]     4-wide traversal node (gather kernel): the binary tree collapsed so that one 128-B
 //                           record holds four child boxes, component by component with the four children side
 //                           by side: {lo.x[4]} {hi.x[4]} {lo.y[4]} {hi.y[4]} {lo.z[4]} {hi.z[4]} {id[4]} {-};
@@ -73,6 +77,7 @@ struct MptRenderParams {
     const MptVec4 *snode;
     const MptVec4 *fnode;
     const MptVec4 *wnode;                    // 4-wide traversal nodes (scenes that do not fit LDS), or null
+    const MptVec4 *qnode;                    // the same nodes with the child boxes quantised to 8 bits (64-B records), or null
     const MptVec4 *tgeo;
     const MptVec4 *tshade;
     const MptMaterial *mats;

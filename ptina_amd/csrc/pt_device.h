@@ -224,7 +224,7 @@ struct Stack {
 
 // scene records served from HBM/L2 through the vector L1 (any scene size)
 struct GlobalScene {
-    static constexpr bool WIDE = false, SIGNED_PLANES = false, LDS_MATS = false;
+    static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false;
     const MptVec4 *fnode, *tgeo;
     int soa_n;                 // node count, for the layout A/B build below
     DEV void node(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &d) const {
@@ -248,7 +248,7 @@ struct GlobalScene {
 // those fetches, not their bytes, are what bounds the big scenes (measured: binary16 boxes at half the bytes
 // bought 3-7 %)
 struct WideScene {
-    static constexpr bool WIDE = true, SIGNED_PLANES = false, LDS_MATS = false;
+    static constexpr bool WIDE = true, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false;
     const MptVec4 *wnode, *tgeo;
     // entry (n*) and exit (f*) planes of the four children, picked by the ray's direction signs: o* is 0 for a ray
     // going up the axis and 16 (bytes: the next float4) for one going down -- still seven dwordx4 gathers
@@ -262,6 +262,48 @@ struct WideScene {
         ny = *(const MptVec4 *)(base + 32 + (o + (unsigned)oy)); fy = *(const MptVec4 *)(base + 32 + (o + (unsigned)(oy ^ 16)));
         nz = *(const MptVec4 *)(base + 64 + (o + (unsigned)oz)); fz = *(const MptVec4 *)(base + 64 + (o + (unsigned)(oz ^ 16)));
         id = *(const MptVec4 *)(base + 96 + o);
+#if MPT_X_DUP_NODE_LOADS
+        // sensitivity A/B (same film): three of the seven gathers issued twice (ordinary cached loads through an
+        // offset the compiler cannot see through) -- what do the gathers themselves cost?
+        // (1: as 16-byte gathers; 2: as 4-byte gathers of their first word)
+        {
+            unsigned o2 = o;
+            asm volatile("" : "+v"(o2));
+#if MPT_X_DUP_NODE_LOADS == 1
+            const MptVec4 a = *(const MptVec4 *)(base + (o2 + (unsigned)(ox ^ 16)));
+            const MptVec4 b = *(const MptVec4 *)(base + 32 + (o2 + (unsigned)(oy ^ 16)));
+            const MptVec4 c = *(const MptVec4 *)(base + 64 + (o2 + (unsigned)(oz ^ 16)));
+            fx.x = a.x == fx.x ? fx.x : a.x; fx.y = a.y == fx.y ? fx.y : a.y; fx.z = a.z == fx.z ? fx.z : a.z; fx.w = a.w == fx.w ? fx.w : a.w;
+            fy.x = b.x == fy.x ? fy.x : b.x; fy.y = b.y == fy.y ? fy.y : b.y; fy.z = b.z == fy.z ? fy.z : b.z; fy.w = b.w == fy.w ? fy.w : b.w;
+            fz.x = c.x == fz.x ? fz.x : c.x; fz.y = c.y == fz.y ? fz.y : c.y; fz.z = c.z == fz.z ? fz.z : c.z; fz.w = c.w == fz.w ? fz.w : c.w;
+#else
+            const float a = *(const float *)(base + (o2 + (unsigned)(ox ^ 16)));
+            const float b = *(const float *)(base + 32 + (o2 + (unsigned)(oy ^ 16)));
+            const float c = *(const float *)(base + 64 + (o2 + (unsigned)(oz ^ 16)));
+            fx.x = a == fx.x ? fx.x : a; fy.x = b == fy.x ? fy.x : b; fz.x = c == fz.x ? fz.x : c;
+#endif
+        }
+#endif
+    }
+    DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2, MptVec4 &g3) const {
+        const MptVec4 *g = tgeo + (size_t)slot * 4;
+        g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3];
+    }
+};
+
+// The same 4-wide nodes in 64 bytes: the child boxes as 8-bit offsets from the node's own box (rounded outwards by
+// the builder), so a step is FOUR 16-B gathers instead of seven.  Measured on MI355X with duplicated gathers: every
+// extra gather instruction per step costs these kernels 7-9 % whatever its width (4 B or 16 B) -- what they wait
+// for is the number of divergent gathers, not bytes -- and the 36 extra VALU instructions of the decode are free
+// at 34-43 % issue utilisation.
+struct QuantScene {
+    static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false;
+    const MptVec4 *qnode, *tgeo;
+    DEV void node4q(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &id) const {
+        const char *base = (const char *)qnode;
+        const unsigned o = (unsigned)i << 6;
+        a = *(const MptVec4 *)(base + o); b = *(const MptVec4 *)(base + 16 + o);
+        c = *(const MptVec4 *)(base + 32 + o); id = *(const MptVec4 *)(base + 48 + o);
     }
     DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2, MptVec4 &g3) const {
         const MptVec4 *g = tgeo + (size_t)slot * 4;
@@ -305,7 +347,7 @@ typedef __attribute__((address_space(3))) const unsigned char *LdsU8Ptr;
 #define MPT_LDS_MAT_VEC4 6      // float4 of a material record kept in LDS: p[0..15] and the derived terms d[0..7]
 
 struct LdsScene {
-    static constexpr bool WIDE = false, SIGNED_PLANES = true, LDS_MATS = true;
+    static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = true, LDS_MATS = true;
     LdsVec4Ptr fnode, tgeo;
     // The material records (parameters + derived terms, 96 B each, the default material last) and one byte per
     // leaf slot naming the record: SHADE reads its material out of LDS while the shading record of the triangle is

@@ -353,17 +353,46 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
 // taken next and the others pushed farthest first.
 template <bool COUNT, class SCENE, class STACK>
 DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
-    MptVec4 nx, fx, ny, fy, nz, fz, idv;
-    sc.node4(L.curr, L.offx, L.offy, L.offz, nx, fx, ny, fy, nz, fz, idv);
-    int id0 = __float_as_int(idv.x), id1 = __float_as_int(idv.y), id2 = __float_as_int(idv.z), id3 = __float_as_int(idv.w);
+    int id0, id1, id2, id3;
+    float t0, t1, t2, t3;
+    bool h0, h1, h2, h3;
     if (COUNT) { cnt.n_node++; cnt.n_box += 4; }
+    if constexpr (SCENE::QUANT) {
+        MptVec4 ra, rb, rc, idv;
+        sc.node4q(L.curr, ra, rb, rc, idv);
+        id0 = __float_as_int(idv.x); id1 = __float_as_int(idv.y); id2 = __float_as_int(idv.z); id3 = __float_as_int(idv.w);
+        // plane = origin + q * scale, so its distance along the ray is q * (scale * inv) + (origin * inv - o * inv)
+        const float sx = ra.w * L.inv.x, sy = rb.x * L.inv.y, sz = rb.y * L.inv.z;
+        const float bx = __builtin_fmaf(ra.x, L.inv.x, -L.oinv.x), by = __builtin_fmaf(ra.y, L.inv.y, -L.oinv.y),
+                    bz = __builtin_fmaf(ra.z, L.inv.z, -L.oinv.z);
+        const unsigned lox = (unsigned)__float_as_int(rb.z), hix = (unsigned)__float_as_int(rb.w);
+        const unsigned loy = (unsigned)__float_as_int(rc.x), hiy = (unsigned)__float_as_int(rc.y);
+        const unsigned loz = (unsigned)__float_as_int(rc.z), hiz = (unsigned)__float_as_int(rc.w);
+        // entry planes: the low ones for a ray going up the axis, the high ones for one going down (L.off*: per-ray flags)
+        const unsigned nxq = L.offx ? hix : lox, fxq = L.offx ? lox : hix;
+        const unsigned nyq = L.offy ? hiy : loy, fyq = L.offy ? loy : hiy;
+        const unsigned nzq = L.offz ? hiz : loz, fzq = L.offz ? loz : hiz;
+#define MPT_UB(w, c) ((float)(((w) >> (8 * (c))) & 0xffu))
+#define MPT_QSLAB(c, tn, h)                                                                                            \
+        tn = fmaxf(fmaxf(__builtin_fmaf(MPT_UB(nxq, c), sx, bx), __builtin_fmaf(MPT_UB(nyq, c), sy, by)),               \
+                   fmaxf(__builtin_fmaf(MPT_UB(nzq, c), sz, bz), 0.0f));                                                 \
+        h = tn <= fminf(fminf(__builtin_fmaf(MPT_UB(fxq, c), sx, bx), __builtin_fmaf(MPT_UB(fyq, c), sy, by)),          \
+                        fminf(__builtin_fmaf(MPT_UB(fzq, c), sz, bz), L.tbest));
+        MPT_QSLAB(0, t0, h0) MPT_QSLAB(1, t1, h1) MPT_QSLAB(2, t2, h2) MPT_QSLAB(3, t3, h3)
+#undef MPT_QSLAB
+#undef MPT_UB
+    } else {
+        MptVec4 nx, fx, ny, fy, nz, fz, idv;
+        sc.node4(L.curr, L.offx, L.offy, L.offz, nx, fx, ny, fy, nz, fz, idv);
+        id0 = __float_as_int(idv.x); id1 = __float_as_int(idv.y); id2 = __float_as_int(idv.z); id3 = __float_as_int(idv.w);
 #define MPT_SLAB(c, tn, h)                                                                                              \
-    float tn = fmaxf(fmaxf(__builtin_fmaf(nx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(ny.c, L.inv.y, -L.oinv.y)),          \
-                     fmaxf(__builtin_fmaf(nz.c, L.inv.z, -L.oinv.z), 0.0f));                                             \
-    bool h = tn <= fminf(fminf(__builtin_fmaf(fx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(fy.c, L.inv.y, -L.oinv.y)),      \
-                         fminf(__builtin_fmaf(fz.c, L.inv.z, -L.oinv.z), L.tbest));
-    MPT_SLAB(x, t0, h0) MPT_SLAB(y, t1, h1) MPT_SLAB(z, t2, h2) MPT_SLAB(w, t3, h3)
+        tn = fmaxf(fmaxf(__builtin_fmaf(nx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(ny.c, L.inv.y, -L.oinv.y)),            \
+                   fmaxf(__builtin_fmaf(nz.c, L.inv.z, -L.oinv.z), 0.0f));                                               \
+        h = tn <= fminf(fminf(__builtin_fmaf(fx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(fy.c, L.inv.y, -L.oinv.y)),      \
+                        fminf(__builtin_fmaf(fz.c, L.inv.z, -L.oinv.z), L.tbest));
+        MPT_SLAB(x, t0, h0) MPT_SLAB(y, t1, h1) MPT_SLAB(z, t2, h2) MPT_SLAB(w, t3, h3)
 #undef MPT_SLAB
+    }
     // entry distances are >= 0, so their bit patterns order like the values; a miss (or the triangle the ray
     // left from, lbvh.py:329) gets the largest key
     const unsigned MISS = 0xffffffffu;
@@ -779,17 +808,22 @@ __global__ MPT_RENDER_BOUNDS void MPT_SUFFIX(render_kernel)(const MptRenderParam
 
 #if !MPT_STRICT
 // ---------------------------------------------------------------- gather kernel over 4-wide nodes
-template <bool COUNT>
+template <bool COUNT, bool QUANT>
 __global__ __launch_bounds__(MPT_BLOCK, 4) void render_kernel_wide(const MptRenderParams p) {
     __shared__ int s_stack[SpillStack::CAP * MPT_BLOCK];
-    WideScene sc; sc.wnode = p.wnode; sc.tgeo = p.tgeo;
     SpillStack stk;
     stk.base = s_stack + threadIdx.x;
     stk.spill = p.stack_spill + ((size_t)blockIdx.x * MPT_BLOCK + threadIdx.x) * SpillStack::SPILL;
     stk.sp = 0;
     Cnt cnt = {};
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
-    trace_stream<COUNT>(p, sc, stk, wq, cnt);
+    if constexpr (QUANT) {
+        QuantScene sc; sc.qnode = p.qnode; sc.tgeo = p.tgeo;
+        trace_stream<COUNT>(p, sc, stk, wq, cnt);
+    } else {
+        WideScene sc; sc.wnode = p.wnode; sc.tgeo = p.tgeo;
+        trace_stream<COUNT>(p, sc, stk, wq, cnt);
+    }
     flush_counters<COUNT>(p, cnt);
 }
 
@@ -958,22 +992,29 @@ MPT_KERNEL_API hipError_t mpt_launch_derive_materials(MptMaterial *mats, int cou
 
 // persistent workgroups over 4-wide nodes; `grid` = number of CUs (scaled here by the blocks each CU can hold);
 // *blocks = workgroups launched (the spill strip must hold blocks x 256 lanes x SpillStack::SPILL entries)
-MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int *blocks) {
-    static std::atomic<int> occ_cache[MPT_MAX_DEVICES][2];
+MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int quant, int *blocks) {
+    static std::atomic<int> occ_cache[MPT_MAX_DEVICES][4];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MPT_MAX_DEVICES) return hipErrorInvalidDevice;
-    int occ = occ_cache[dev][count ? 1 : 0].load(std::memory_order_relaxed);
+    const int v = (count ? 1 : 0) + (quant ? 2 : 0);
+    int occ = occ_cache[dev][v].load(std::memory_order_relaxed);
     if (!occ) {
-        occ = count ? blocks_per_cu(render_kernel_wide<true>) : blocks_per_cu(render_kernel_wide<false>);
-        occ_cache[dev][count ? 1 : 0].store(occ, std::memory_order_relaxed);
+        occ = v == 0 ? blocks_per_cu(render_kernel_wide<false, false>) : v == 1 ? blocks_per_cu(render_kernel_wide<true, false>)
+            : v == 2 ? blocks_per_cu(render_kernel_wide<false, true>) : blocks_per_cu(render_kernel_wide<true, true>);
+        occ_cache[dev][v].store(occ, std::memory_order_relaxed);
     }
     *blocks = grid * occ;
     return hipSuccess;
 }
 
-MPT_KERNEL_API hipError_t mpt_launch_render_wide(const MptRenderParams *p, int blocks, int count, hipStream_t stream) {
-    if (count) hipLaunchKernelGGL((render_kernel_wide<true>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
-    else hipLaunchKernelGGL((render_kernel_wide<false>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
+MPT_KERNEL_API hipError_t mpt_launch_render_wide(const MptRenderParams *p, int blocks, int count, int quant, hipStream_t stream) {
+    if (quant) {
+        if (count) hipLaunchKernelGGL((render_kernel_wide<true, true>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
+        else hipLaunchKernelGGL((render_kernel_wide<false, true>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
+    } else {
+        if (count) hipLaunchKernelGGL((render_kernel_wide<true, false>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
+        else hipLaunchKernelGGL((render_kernel_wide<false, false>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
+    }
     return hipGetLastError();
 }
 #endif

@@ -535,8 +535,9 @@ static int make_wide(mpt_ctx *c) {
     }
     double area_bin = 0.0, area_wide = 0.0;
     for (int b = 0; b < ni; b++) area_bin += node_area[b];
-    std::vector<MptVec4> wnode;
+    std::vector<MptVec4> wnode, qnode;
     wnode.reserve((size_t)ni * 4);
+    qnode.reserve((size_t)ni * 2);
     std::vector<int> bin_of;            // wide node -> the binary node it was grown from
     std::vector<int> depth_of;
     bin_of.push_back(0); depth_of.push_back(1);
@@ -576,6 +577,36 @@ static int make_wide(mpt_ctx *c) {
         }
         rec[6] = { asf(ids[0]), asf(ids[1]), asf(ids[2]), asf(ids[3]) };
         for (int k = 0; k < 8; k++) wnode.push_back(rec[k]);
+        // the quantised record: child planes as bytes over the node's own box, rounded outwards by a quarter of a step
+        // more than needed (the kernel's decode q * (scale * inv) + (origin * inv - o * inv) is off by far less)
+        {
+            float plo[3] = { INFINITY, INFINITY, INFINITY }, phi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (int k = 0; k < cnt; k++)
+                for (int a = 0; a < 3; a++) { plo[a] = std::min(plo[a], ch[k].lo[a]); phi[a] = std::max(phi[a], ch[k].hi[a]); }
+            float scale[3];
+            uint32_t qlo[3] = { 0, 0, 0 }, qhi[3] = { 0, 0, 0 };
+            for (int a = 0; a < 3; a++) {
+                const float e = phi[a] - plo[a];
+                float sc = e > 0.f ? e / 255.f : 0.f;
+                // 255 steps must reach the far side in f32, and a flat node still needs a positive step
+                while (e > 0.f && plo[a] + 255.f * sc < phi[a]) sc = std::nextafter(sc, INFINITY);
+                if (!(sc > 0.f)) sc = std::max(std::fabs(plo[a]) * 1e-6f, 1e-30f);
+                scale[a] = sc;
+                for (int k = 0; k < 4; k++) {
+                    uint32_t l = 255, h = 0;                        // unused child: an inverted box
+                    if (k < cnt) {
+                        const float fl = std::floor((ch[k].lo[a] - plo[a]) / sc - 0.25f), fh = std::ceil((ch[k].hi[a] - plo[a]) / sc + 0.25f);
+                        l = (uint32_t)std::min(255.f, std::max(0.f, fl));
+                        h = (uint32_t)std::min(255.f, std::max(0.f, fh));
+                    }
+                    qlo[a] |= l << (8 * k); qhi[a] |= h << (8 * k);
+                }
+            }
+            qnode.push_back({ plo[0], plo[1], plo[2], scale[0] });
+            qnode.push_back({ scale[1], scale[2], asf((int32_t)qlo[0]), asf((int32_t)qhi[0]) });
+            qnode.push_back({ asf((int32_t)qlo[1]), asf((int32_t)qhi[1]), asf((int32_t)qlo[2]), asf((int32_t)qhi[2]) });
+            qnode.push_back(rec[6]);
+        }
     }
     // a step pushes up to three entries: 3 x depth + sentinel must fit the LDS levels plus the spill strip
     if (3 * depth + 2 > 128) return 0;      // too deep (40 LDS levels + 88 spilled): the gather kernel keeps walking the binary tree
@@ -587,6 +618,12 @@ static int make_wide(mpt_ctx *c) {
         c->wnode_cap = nw;
     }
     HIP_TRY(hipMemcpy(c->wnode, wnode.data(), nw * 8 * sizeof(MptVec4), hipMemcpyHostToDevice));
+    if (nw > c->qnode_cap) {
+        hipFree(c->qnode); c->qnode = nullptr; c->qnode_cap = 0;
+        if (dev_alloc(&c->qnode, nw * 4)) return 1;
+        c->qnode_cap = nw;
+    }
+    HIP_TRY(hipMemcpy(c->qnode, qnode.data(), nw * 4 * sizeof(MptVec4), hipMemcpyHostToDevice));
     c->wide_nodes = (int)nw; c->wide_depth = depth;
     c->wide_ratio = area_bin > 0.0 ? (float)(area_wide / area_bin) : 1.f;
     return 0;

@@ -266,32 +266,44 @@ def test_long_interactive_session(fresh):
 def test_lds_and_gather_kernels_agree_bit_for_bit(fresh):
     '''the LDS-resident kernel and the gather kernel over the binary tree run the same state machine on the
     same tree: one film, whichever serves the scene; the SAH and the plain-LBVH tree, and the gather kernel over
-    the 4-wide collapse of either, visit the same triangles in another order: equal up to equal-depth ties'''
+    the 4-wide collapse of either -- with exact child boxes or with the production records that hold them in 8 bits,
+    rounded outwards -- visit the same triangles in another order: equal up to equal-depth ties'''
     from helpers import assert_parity
     from ptina_amd.things import FilmTable, BVHTree
     from ptina_amd.common import ctx, reset_all
     films = {}
-    for lds, tree, wide in ((1, 1, 0), (0, 1, 0), (1, 0, 0), (0, 0, 0), (0, 1, 1), (0, 0, 1)):
+    for lds, tree, wide, quant in ((1, 1, 0, 1), (0, 1, 0, 1), (1, 0, 0, 1), (0, 0, 0, 1), (0, 1, 1, 1), (0, 0, 1, 1), (0, 1, 1, 0)):
         reset_all()
         eng = _engine(None, scenes.scene_s978(), 96, 80, mode='fast')
         c = ctx()
         c.set_option('lds', lds)
         c.set_option('tree', tree)
         c.set_option('wide', wide)
+        c.set_option('wide_quant', quant)
         BVHTree().build()
+        c.set_option('count', 1)
+        c.call('mpt_reset_counters')
         eng.render(6)
-        films[(lds, tree, wide)] = (FilmTable().get_raw().copy(), FilmTable().get_image().copy(), c.get_option('last_kernel'))
+        films[(lds, tree, wide, quant)] = (FilmTable().get_raw().copy(), FilmTable().get_image().copy(), c.get_option('last_kernel'),
+                                           c.counters())
         if wide:
             assert c.get_option('wide_nodes') > 0 and 1 < c.get_option('wide_depth') <= c.get_option('fast_depth')
     reset_all()
-    assert films[(1, 1, 0)][2] == 1 and films[(0, 1, 0)][2] == 0 and films[(0, 1, 1)][2] == 2
-    assert np.array_equal(films[(1, 1, 0)][0], films[(0, 1, 0)][0])
-    assert np.array_equal(films[(1, 0, 0)][0], films[(0, 0, 0)][0])
-    assert_parity(films[(1, 1, 0)][1], films[(1, 0, 0)][1], *FAST, what='SAH tree vs LBVH')
-    assert_parity(films[(0, 1, 1)][1], films[(1, 1, 0)][1], *FAST, what='4-wide nodes vs binary tree (SAH)')
-    assert_parity(films[(0, 0, 1)][1], films[(1, 0, 0)][1], *FAST, what='4-wide nodes vs binary tree (LBVH)')
-    for k in ((0, 1, 1), (0, 0, 1)):
+    assert films[(1, 1, 0, 1)][2] == 1 and films[(0, 1, 0, 1)][2] == 0 and films[(0, 1, 1, 1)][2] == 2 and films[(0, 1, 1, 0)][2] == 2
+    assert np.array_equal(films[(1, 1, 0, 1)][0], films[(0, 1, 0, 1)][0])
+    assert np.array_equal(films[(1, 0, 0, 1)][0], films[(0, 0, 0, 1)][0])
+    assert_parity(films[(1, 1, 0, 1)][1], films[(1, 0, 0, 1)][1], *FAST, what='SAH tree vs LBVH')
+    assert_parity(films[(0, 1, 1, 1)][1], films[(1, 1, 0, 1)][1], *FAST, what='4-wide nodes vs binary tree (SAH)')
+    assert_parity(films[(0, 0, 1, 1)][1], films[(1, 0, 0, 1)][1], *FAST, what='4-wide nodes vs binary tree (LBVH)')
+    assert_parity(films[(0, 1, 1, 1)][1], films[(0, 1, 1, 0)][1], *FAST, what='8-bit child boxes vs exact ones (4-wide, SAH)')
+    for k in ((0, 1, 1, 1), (0, 0, 1, 1), (0, 1, 1, 0)):
         assert np.all(films[k][0][:, 3] == 6)
+    # boxes rounded outwards: the quantised walk visits a few more nodes (measured: +2 %; the order of the children can
+    # change with the rounded entry distances, so not strictly a superset)
+    exact, quant = films[(0, 1, 1, 0)][3], films[(0, 1, 1, 1)][3]
+    assert exact['rays'] == quant['rays']
+    assert 0.98 * exact['n_node'] <= quant['n_node'] <= 1.10 * exact['n_node']
+    assert 0.98 * exact['n_tri'] <= quant['n_tri'] <= 1.15 * exact['n_tri']
 
 
 def test_launch_pipelining_does_not_change_the_film(fresh):
@@ -1107,7 +1119,15 @@ def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
     # 8192 pixels at 16 spp over a triangle soup: a handful of pixels whose closest hit flips between two
     # nearly coincident triangles carry the RMSE (measured: 0.10 % outliers, rel-RMSE 2.9e-3, max diff 0.14)
     assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 6e-3, what='C5 1M triangles fast, 8 columns x 16 spp')
-    assert ctx().get_option('last_kernel') == 2           # gather kernel over the 4-wide collapse (465 k nodes of 128 B)
+    assert ctx().get_option('last_kernel') == 2           # gather kernel over the 4-wide collapse (465 k nodes, 8-bit child boxes)
+    # the same with the exact child boxes (option wide_quant = 0: 128-B records)
+    ctx().set_option('wide_quant', 0)
+    FilmTable().clear()
+    ctx().call('mpt_sobol_reset', 64)
+    eng.render(spp)
+    raw = FilmTable().get_raw().reshape(nx, ny, 4)
+    assert ctx().get_option('last_kernel') == 2 and np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 6e-3, what='C5 1M triangles fast, exact 4-wide boxes, 8 columns x 16 spp')
     # the same through the binary tree (option wide = 0)
     ctx().set_option('wide', 0)
     FilmTable().clear()
