@@ -235,7 +235,27 @@ template <int N>
 DEV void lane_draws(const MptRenderParams &p, LaneState &L, float *out) {
     const float *P = p.P + (size_t)L.frame * p.sobol_dim;
     const int dim = p.sobol_dim;
-    if (L.rng_i <= 0x7fffffff - N) {
+    if (L.rng_i <= 0x7fffffff - N && L.rng_k + N <= dim) {
+        // the N numbers are consecutive words (no wrap at dim inside them): two 16-byte gathers (any 4-byte
+        // alignment) instead of six -- a gather instruction costs the big scenes the same whatever its width
+        struct __attribute__((packed, aligned(4))) W4 { float a, b, c, d; };
+        struct __attribute__((packed, aligned(4))) W2 { float a, b; };
+        const float *q = P + L.rng_k;
+        static_assert(N == 2 || N == 6, "lane_draws: two (jitter) or six (light + BSDF triples) numbers");
+        if constexpr (N == 6) {
+            const W4 v = *(const W4 *)q;
+            int k2 = L.rng_k + 2;
+            asm("" : "+v"(k2));                                              // (or the compiler turns it into two 4-byte gathers)
+            const W4 w = *(const W4 *)(P + k2);                              // overlaps the first: no read past the six
+            out[0] = v.a; out[1] = v.b; out[2] = v.c; out[3] = v.d; out[4] = w.c; out[5] = w.d;
+        } else {
+            const W2 w = *(const W2 *)q;
+            out[0] = w.a; out[1] = w.b;
+        }
+        const int k = L.rng_k + N;
+        L.rng_k = k == dim ? 0 : k;
+        L.rng_i += N;
+    } else if (L.rng_i <= 0x7fffffff - N) {
         int k = L.rng_k;
 #pragma unroll
         for (int t = 0; t < N; t++) {

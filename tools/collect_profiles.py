@@ -59,7 +59,7 @@ if summary:
         json.dump(summary, fh, indent=1, sort_keys=True)
     print('pmc summary ->', f'{tag}_pmc_summary.json')
 # big scenes (`tools/gpu_round.sh pmcbig1..4` = `run_configs.py C4 C5` under --pmc): the production kernel
-# of the big scenes (4-wide gather, render_kernel_wide<false>) is dispatched as [C4 1-spp, C4 x6 (32 frames of 1024^2), C5 1-spp, C5 x3 (16 frames of 1024^2)]
+# of the big scenes (4-wide gather, render_kernel_wide<false, true>: 8-bit child boxes) is dispatched as [C4 1-spp, C4 x6 (32 frames of 1024^2), C5 1-spp, C5 x3 (16 frames of 1024^2)]
 big = {}
 for d in ('pmcbig1', 'pmcbig2', 'pmcbig3', 'pmcbig4'):
     f = newest(f'{d}/*/*counter_collection.csv')
@@ -67,7 +67,7 @@ for d in ('pmcbig1', 'pmcbig2', 'pmcbig3', 'pmcbig4'):
         continue
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
-        if 'render_kernel_wide<false>' in r['Kernel_Name'] or 'render_kernel_fast<32, false>' in r['Kernel_Name']:
+        if 'render_kernel_wide<false' in r['Kernel_Name'] or 'render_kernel_fast<32, false>' in r['Kernel_Name']:
             per[r['Counter_Name']][int(r['Dispatch_Id'])] += float(r['Counter_Value'])
     for cn, byd in per.items():
         vals = [byd[k] for k in sorted(byd)]
