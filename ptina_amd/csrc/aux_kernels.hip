@@ -159,3 +159,30 @@ MPT_KERNEL_API hipError_t mpt_launch_export(const MptVec4 *film, float *out, int
     hipLaunchKernelGGL(export_kernel, dim3(grid), dim3(256), 0, stream, film, out, nx, ny);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------- production triangle records
+// tfast from tgeo (mpt_types.h): the dual edge vectors of the reference's barycentric solve, geometries.py:134-143,
+// in IEEE arithmetic (this file is compiled with -ffp-contract=off); a degenerate triangle (D = 0) gets
+// infinities / NaNs, which fail every comparison of the test like the reference's own division by zero
+__global__ __launch_bounds__(256) void derive_tfast_kernel(const MptVec4 *__restrict__ tgeo, MptVec4 *__restrict__ tfast, int n) {
+    int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n) return;
+    const MptVec4 g0 = tgeo[(size_t)slot * 4 + 0], g1 = tgeo[(size_t)slot * 4 + 1], g2 = tgeo[(size_t)slot * 4 + 2],
+                  g3 = tgeo[(size_t)slot * 4 + 3];
+    const float D = g0.w, uu = g1.w, uv = g2.w, vv = g3.w;
+    const float u[3] = { g1.x, g1.y, g1.z }, v[3] = { g2.x, g2.y, g2.z };
+    float a[3], c[3];
+    for (int k = 0; k < 3; k++) {
+        a[k] = (uv * v[k] - vv * u[k]) / D;
+        c[k] = (uv * u[k] - uu * v[k]) / D;
+    }
+    tfast[(size_t)slot * 3 + 0] = { g3.x, g3.y, g3.z, g0.x };
+    tfast[(size_t)slot * 3 + 1] = { a[0], a[1], a[2], g0.y };
+    tfast[(size_t)slot * 3 + 2] = { c[0], c[1], c[2], g0.z };
+}
+
+MPT_KERNEL_API hipError_t mpt_launch_derive_tfast(const MptVec4 *tgeo, MptVec4 *tfast, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(derive_tfast_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tgeo, tfast, n);
+    return hipGetLastError();
+}

@@ -177,7 +177,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     for (auto &ev : c->event_pool) hipEventDestroy(ev);
     for (int p = 0; p < 3; p++) hipFree(c->film[p]);
     hipFree(c->resolved); hipFree(c->exported);
-    hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade); hipFree(c->wnode); hipFree(c->qnode); hipFree(c->stack_spill); hipFree(c->fnode_soa);
+    hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade); hipFree(c->wnode); hipFree(c->qnode); hipFree(c->tfast); hipFree(c->stack_spill); hipFree(c->fnode_soa);
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
@@ -590,7 +590,7 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     memcpy(p.world_fac, c->world_fac, sizeof p.world_fac);
     memcpy(p.v2w, c->v2w, sizeof p.v2w);
     p.wnode = c->wnode; p.qnode = c->qnode; p.stack_spill = c->stack_spill;
-    p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade;
+    p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade; p.tfast = c->tfast;
     p.default_mtl = c->caps.max_materials;
     p.mats = c->mats; p.lights = c->lights; p.images = c->images; p.texels = c->texels;
     p.P = c->sP;
@@ -667,11 +667,11 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     if (sobol_advance(c, B, use_spec ? 0 : B, ss, fast ? c->sP2[k] : nullptr)) return 1;   // ahead of time: X only
 
     const int stack = ((c->mode == MPT_MODE_STRICT ? c->tree_depth : c->fast_depth) + 2 <= 32) ? 32 : 64;
-    // LDS-resident kernel: node + triangle records + a 16-bit stack of (depth+1) levels x 1024
+    // LDS-resident kernel: node (64 B) + triangle (48 B) records + a 16-bit stack of (depth+1) levels x 1024
     // lanes must fit the CU's 160 KiB; ids must fit int16
     const int lds_stack = c->fast_depth + 1;            // sentinel + one pending sibling (node or leaf) per level
     // + the material records (96 B each, the default one last) and one byte per triangle naming its record
-    const size_t lds_bytes = ((size_t)(c->nfaces - 1) * 4 + (size_t)c->nfaces * 4 + (size_t)(c->caps.max_materials + 1) * 6) * sizeof(MptVec4) +
+    const size_t lds_bytes = ((size_t)(c->nfaces - 1) * 4 + (size_t)c->nfaces * 3 + (size_t)(c->caps.max_materials + 1) * 6) * sizeof(MptVec4) +
                              (((size_t)c->nfaces + 15) & ~(size_t)15) + (size_t)lds_stack * 1024 * sizeof(short);
     const bool lds_kernel = fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && c->caps.max_materials < 256 &&
                             lds_bytes <= 160 * 1024;

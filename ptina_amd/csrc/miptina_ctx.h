@@ -22,6 +22,7 @@
 MPT_KERNEL_API hipError_t mpt_launch_render_fast(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_render_strict(const MptRenderParams *, int grid, int stack, int count, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_derive_materials(MptMaterial *mats, int count, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_derive_tfast(const MptVec4 *tgeo, MptVec4 *tfast, int n, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int quant, int *blocks);
 MPT_KERNEL_API hipError_t mpt_launch_render_wide(const MptRenderParams *, int blocks, int count, int quant, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
@@ -109,6 +110,7 @@ struct mpt_ctx {
     std::vector<int32_t> h_child, h_leaf, h_mc;
     std::vector<float> h_bmin, h_bmax;
     MptVec4 *snode = nullptr, *fnode = nullptr, *tgeo = nullptr, *tshade = nullptr;
+    MptVec4 *tfast = nullptr; size_t tfast_cap = 0;   // production triangle records, 3 float4 each (derived from tgeo)
     MptVec4 *qnode = nullptr; size_t qnode_cap = 0;   // the same nodes, child boxes quantised to 8 bits, 4 float4 each
     int use_quant = 1;
     MptVec4 *wnode = nullptr; size_t wnode_cap = 0;   // 4-wide nodes of the fast tree (gather kernel), 8 float4 each

@@ -19,6 +19,8 @@
 //                           1e30 that no ray reaches
 //   tgeo   float4[n*4]      per-leaf-slot triangle, ray-independent terms of geometries.py:118-148
 //                           hoisted: {v0.xyz, D} {u.xyz, uu} {v.xyz, uv} {n.xyz, vv}
+//   tfast  float4[n*3]      the production kernels' triangle record: plane normal n = u x v, the dual edge vectors
+//                           a = (uv v - vv u) / D, c = (uv u - uu v) / D, and v0 in the .w lanes (derive_tfast_kernel)
 //   tshade float4[n*4]      per-leaf-slot shading data: {n0.xyz, n1.x} {n1.yz, n2.xy} {n2.z, uv0.xy, uv1.x}
 //                           {uv1.y, uv2.xy, mtlid}
 //   mats   MptMaterial[m+1] the 12 Disney parameters of mtllib.py:44-56 + the terms derived from them, 160 B; the
@@ -80,6 +82,7 @@ struct MptRenderParams {
     const MptVec4 *qnode;                    // the same nodes with the child boxes quantised to 8 bits (64-B records), or null
     const MptVec4 *tgeo;
     const MptVec4 *tshade;
+    const MptVec4 *tfast;                    // production build: 48-byte triangle records {n, v0.x}{a, v0.y}{c, v0.z} derived from tgeo
     const MptMaterial *mats;
     const MptLight *lights;
     const MptImage *images;

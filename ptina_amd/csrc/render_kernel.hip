@@ -58,7 +58,7 @@ DEV BlockTracer make_block_tracer(const MptRenderParams &p, int *lds) {
 typedef Tracer<GlobalScene, Stack> BlockTracer;
 DEV BlockTracer make_block_tracer(const MptRenderParams &p, int *lds) {
     BlockTracer t;
-    t.sc.fnode = p.fnode; t.sc.tgeo = p.tgeo; t.sc.soa_n = p.fnode_soa_n;
+    t.sc.fnode = p.fnode; t.sc.tgeo = p.tfast; t.sc.soa_n = p.fnode_soa_n;
     t.st.base = lds; t.st.sp = 0;
     t.n = p.n;
     return t;
@@ -453,16 +453,10 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     int slot = ~L.curr;
     bool stop = false;
     if (COUNT) cnt.n_tri++;
-    MptVec4 g0, g1, g2, g3;
-    sc.tri(slot, g0, g1, g2, g3);
-#if MPT_LEAF_UPFRONT
-    // all four record loads issued before the first test: left alone the compiler sinks each into the nested branch
-    // that needs it, and a LEAF step becomes three LDS round trips in a row
-    asm volatile("" : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w));
-    asm volatile("" : "+v"(g2.x), "+v"(g2.y), "+v"(g2.z), "+v"(g2.w), "+v"(g3.x), "+v"(g3.y), "+v"(g3.z), "+v"(g3.w));
-#endif
+    MptVec4 g0, g1, g2;
+    sc.tri(slot, g0, g1, g2);
     float dd, su, sv;
-    if (tri_test(g0, g1, g2, g3, L.to, L.td, &dd, &su, &sv)) {
+    if (tri_test_fast(g0, g1, g2, L.to, L.td, &dd, &su, &sv)) {
         if (L.shadow) {
             if (dd <= L.tbest) { L.hidx = slot; stop = true; }              // path.py:51: any occluder within li.dis
         } else if (dd < L.tbest) {                                          // lbvh.py:331
@@ -838,28 +832,28 @@ __global__ __launch_bounds__(MPT_BLOCK, 4) void render_kernel_wide(const MptRend
     Cnt cnt = {};
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
     if constexpr (QUANT) {
-        QuantScene sc; sc.qnode = p.qnode; sc.tgeo = p.tgeo;
+        QuantScene sc; sc.qnode = p.qnode; sc.tgeo = p.tfast;
         trace_stream<COUNT>(p, sc, stk, wq, cnt);
     } else {
-        WideScene sc; sc.wnode = p.wnode; sc.tgeo = p.tgeo;
+        WideScene sc; sc.wnode = p.wnode; sc.tgeo = p.tfast;
         trace_stream<COUNT>(p, sc, stk, wq, cnt);
     }
     flush_counters<COUNT>(p, cnt);
 }
 
 // ---------------------------------------------------------------- LDS-resident persistent kernel
-// dynamic LDS: [ (n-1)*4 node float4 | n*4 triangle float4 | (default_mtl+1)*6 material float4 |
+// dynamic LDS: [ (n-1)*4 node float4 | n*3 triangle float4 (tfast) | (default_mtl+1)*6 material float4 |
 //                n material-record bytes, padded to 16 | lds_stack x 1024 int16 ]     (mpt_lds_scene_bytes)
 template <bool COUNT>
 __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRenderParams p) {
     extern __shared__ __attribute__((aligned(16))) MptVec4 smem[];
-    const int nnode4 = (p.n - 1) * 4, ntri4 = p.n * 4, nmat4 = (p.default_mtl + 1) * MPT_LDS_MAT_VEC4;
+    const int nnode4 = (p.n - 1) * 4, ntri4 = p.n * 3, nmat4 = (p.default_mtl + 1) * MPT_LDS_MAT_VEC4;
     const int nmtl4 = (p.n + 15) >> 4;
     unsigned long long *tl = p.timeline ? p.timeline + 4 * (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
     if (tl && (threadIdx.x & 63) == 0) tl[0] = wall_clock64();
     {   // one copy of the scene per CU: coalesced 16-B loads, ds_write_b128
         for (int k = threadIdx.x; k < nnode4; k += blockDim.x) smem[k] = p.fnode[k];
-        for (int k = threadIdx.x; k < ntri4; k += blockDim.x) smem[nnode4 + k] = p.tgeo[k];
+        for (int k = threadIdx.x; k < ntri4; k += blockDim.x) smem[nnode4 + k] = p.tfast[k];
         for (int k = threadIdx.x; k < nmat4; k += blockDim.x) {
             const int rec = k / MPT_LDS_MAT_VEC4, w = k - rec * MPT_LDS_MAT_VEC4;
             smem[nnode4 + ntri4 + k] = ((const MptVec4 *)(p.mats + rec))[w < 4 ? w : w + 4];

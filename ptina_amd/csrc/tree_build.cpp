@@ -633,6 +633,15 @@ extern "C" int mpt_build_tree(mpt_ctx *c) {
     if (use(c)) return 1;
     c->fnode_soa_valid = false;
     if (c->gpu_build ? build_tree_gpu(c) : build_tree_host(c)) return 1;
+    // the production kernels' 48-byte triangle records, from the reference-order ones
+    const size_t nt = (size_t)std::max(c->nfaces, 1);
+    if (nt > c->tfast_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->tfast); c->tfast = nullptr; c->tfast_cap = 0;
+        if (dev_alloc(&c->tfast, nt * 3)) return 1;
+        c->tfast_cap = nt;
+    }
+    HIP_TRY(mpt_launch_derive_tfast(c->tgeo, c->tfast, c->nfaces, c->stream));
     return make_wide(c);
 }
 
