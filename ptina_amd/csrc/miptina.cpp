@@ -667,11 +667,11 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     if (sobol_advance(c, B, use_spec ? 0 : B, ss, fast ? c->sP2[k] : nullptr)) return 1;   // ahead of time: X only
 
     const int stack = ((c->mode == MPT_MODE_STRICT ? c->tree_depth : c->fast_depth) + 2 <= 32) ? 32 : 64;
-    // LDS-resident kernel: node (64 B) + triangle (48 B) records + a 16-bit stack of (depth+1) levels x 1024
+    // LDS-resident kernel: node (64 B, MPT_LDS_NODE_STRIDE apart) + triangle (48 B) records + a 16-bit stack of (depth+1) levels x 1024
     // lanes must fit the CU's 160 KiB; ids must fit int16
     const int lds_stack = c->fast_depth + 1;            // sentinel + one pending sibling (node or leaf) per level
     // + the material records (96 B each, the default one last) and one byte per triangle naming its record
-    const size_t lds_bytes = ((size_t)(c->nfaces - 1) * 4 + (size_t)c->nfaces * 3 + (size_t)(c->caps.max_materials + 1) * 6) * sizeof(MptVec4) +
+    const size_t lds_bytes = ((((size_t)(c->nfaces - 1) * MPT_LDS_NODE_STRIDE + 15) >> 4) + (size_t)c->nfaces * 3 + (size_t)(c->caps.max_materials + 1) * 6) * sizeof(MptVec4) +
                              (((size_t)c->nfaces + 15) & ~(size_t)15) + (size_t)lds_stack * 1024 * sizeof(short);
     const bool lds_kernel = fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && c->caps.max_materials < 256 &&
                             lds_bytes <= 160 * 1024;

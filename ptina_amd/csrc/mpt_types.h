@@ -62,6 +62,13 @@ struct MptLight {              // light/__init__.py:14-18
 
 struct MptImage { int32_t nx, ny, base, pad; };   // image.py:14-16
 
+// LDS-resident kernel: bytes from one node record to the next in LDS.  72, not 64: a ds_read_b64 is served in two
+// groups of 32 lanes over 64 banks of 4 bytes, and with 64-byte records every lane's read of a given plane lands
+// on one of FOUR bank pairs (16 i mod 64); with 72-byte records on one of 32 (18 i mod 64) -- reads stay 8-byte aligned
+#ifndef MPT_LDS_NODE_STRIDE
+#define MPT_LDS_NODE_STRIDE 72
+#endif
+
 struct MptRenderParams {
     int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders
     int32_t nframes, chunk, nchunks, n;     // batch frames; frames per work item; items per tile; #triangles

@@ -842,17 +842,22 @@ __global__ __launch_bounds__(MPT_BLOCK, 4) void render_kernel_wide(const MptRend
 }
 
 // ---------------------------------------------------------------- LDS-resident persistent kernel
-// dynamic LDS: [ (n-1)*4 node float4 | n*3 triangle float4 (tfast) | (default_mtl+1)*6 material float4 |
+// dynamic LDS: [ (n-1) node records of MPT_LDS_NODE_STRIDE bytes, padded to 16 | n*3 triangle float4 (tfast) | (default_mtl+1)*6 material float4 |
 //                n material-record bytes, padded to 16 | lds_stack x 1024 int16 ]     (mpt_lds_scene_bytes)
 template <bool COUNT>
 __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRenderParams p) {
     extern __shared__ __attribute__((aligned(16))) MptVec4 smem[];
-    const int nnode4 = (p.n - 1) * 4, ntri4 = p.n * 3, nmat4 = (p.default_mtl + 1) * MPT_LDS_MAT_VEC4;
+    // node records MPT_LDS_NODE_STRIDE bytes apart (bank spreading), the region rounded up to whole float4
+    const int nnode4 = ((p.n - 1) * MPT_LDS_NODE_STRIDE + 15) >> 4, ntri4 = p.n * 3, nmat4 = (p.default_mtl + 1) * MPT_LDS_MAT_VEC4;
     const int nmtl4 = (p.n + 15) >> 4;
     unsigned long long *tl = p.timeline ? p.timeline + 4 * (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
     if (tl && (threadIdx.x & 63) == 0) tl[0] = wall_clock64();
     {   // one copy of the scene per CU: coalesced 16-B loads, ds_write_b128
-        for (int k = threadIdx.x; k < nnode4; k += blockDim.x) smem[k] = p.fnode[k];
+        for (int k = threadIdx.x; k < (p.n - 1) * 4; k += blockDim.x) {          // 8-byte stores: the records are 8-byte aligned
+            const MptVec4 v = p.fnode[k];
+            float *d = (float *)((char *)smem + (k >> 2) * MPT_LDS_NODE_STRIDE + (k & 3) * 16);
+            *(float2 *)d = make_float2(v.x, v.y); *(float2 *)(d + 2) = make_float2(v.z, v.w);
+        }
         for (int k = threadIdx.x; k < ntri4; k += blockDim.x) smem[nnode4 + k] = p.tfast[k];
         for (int k = threadIdx.x; k < nmat4; k += blockDim.x) {
             const int rec = k / MPT_LDS_MAT_VEC4, w = k - rec * MPT_LDS_MAT_VEC4;
