@@ -306,6 +306,43 @@ def test_lds_and_gather_kernels_agree_bit_for_bit(fresh):
     assert 0.98 * exact['n_tri'] <= quant['n_tri'] <= 1.15 * exact['n_tri']
 
 
+def test_quantised_boxes_far_from_the_origin(fresh, oracle_mod):
+    '''the 8-bit child boxes of the 4-wide nodes are offsets from each node's own box, decoded in the kernel as
+    q * (scale * inv) + (origin * inv - o * inv): a scene moved 300-500 units away from the origin (coordinates 100 x
+    the size of its triangles' boxes) costs that decode precision first.  The rounding margin must hold: both the
+    quantised and the exact 4-wide walk against the oracle on the moved scene, and against each other'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd.tools.matrix import translate
+    T = np.array([300.0, -200.0, 500.0])
+    vertices, mtlids, materials, images = scenes.scene_s978()
+    moved = np.array(vertices, dtype=np.float32, copy=True)
+    moved[:, 0:3] += T.astype(np.float32)
+    scene = (moved, mtlids, materials, images)
+    camera = scenes.BENCH_CAMERA @ translate(-T)
+    lights = [(translate(np.array([1.0, 2.0, 3.0]) + T), np.array([32.0, 32.0, 32.0]), 0.5, 'POINT')]
+    nx, ny, spp = 96, 80, 8
+    ref = setup_oracle(oracle_mod, scene, nx, ny, camera=camera, lights=lights)
+    ref.render(spp)
+    want = ref.get_image()
+    got = {}
+    for quant in (1, 0):
+        reset_all()
+        eng = _engine(None, scene, nx, ny, mode='fast', camera=camera, lights=lights)
+        c = ctx()
+        c.set_option('lds', 0)
+        c.set_option('wide_quant', quant)
+        eng.render(spp)
+        raw = FilmTable().get_raw().reshape(nx, ny, 4)
+        assert c.get_option('last_kernel') == 2 and np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
+        got[quant] = FilmTable().get_image().copy()
+        # f32 positions 500 units out carry 3e-5 of absolute error: pixels along silhouettes flip (measured below 0.3 %)
+        assert_parity(got[quant], want, FAST[0], 0.01, 1e-2, what=f'moved scene, 4-wide quant={quant} vs oracle')
+    reset_all()
+    assert_parity(got[1], got[0], *FAST, what='moved scene, 8-bit boxes vs exact ones')
+
+
 def test_launch_pipelining_does_not_change_the_film(fresh):
     '''G launches on 1/G of the CUs each, D batches in flight: same film bit for bit, any G and D,
     including batches of different sizes back to back (the ring of slots is resized in between)'''
