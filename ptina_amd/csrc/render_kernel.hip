@@ -563,6 +563,10 @@ DEV void pool_prepare(const MptRenderParams &p, PrimaryPool &pp, bool inside, in
 DEV float lane_from(float v, int byte_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_lane, __float_as_int(v))); }
 DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(byte_lane, v); }
 
+#ifndef MPT_PREF_NODE
+#define MPT_PREF_NODE 1     // a NODE step when nodes * MPT_PREF_NODE >= leaves * MPT_PREF_LEAF, else a LEAF step
+#define MPT_PREF_LEAF 1
+#endif
 #ifndef MPT_LEAVE_A
 #define MPT_LEAVE_A 2    // leave traversal mode when traversing * A < waiting * B
 #define MPT_LEAVE_B 1
@@ -661,7 +665,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             // traversing ones 2 : 1 (best of the ratios tried on MI355X)
             if (trav * MPT_LEAVE_A < (64 - ndead - trav) * MPT_LEAVE_B) break;
             MPT_STAMP_BEGIN
-            if (cn >= cl) {
+            if (cn * MPT_PREF_NODE >= cl * MPT_PREF_LEAF) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
                 if (L.st == ST_NODE) {
                     if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
