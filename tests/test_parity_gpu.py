@@ -536,6 +536,38 @@ def test_edge_cases_empty_and_single_triangle(fresh, oracle_mod):
     reset_all()
 
 
+def test_tiny_scenes_through_every_production_kernel(fresh, oracle_mod):
+    '''two and three triangles (one and two internal nodes: a 4-wide record with two or three of its four slots
+    used) and the 34-triangle box, through the LDS-resident kernel, the binary gather kernel and the 4-wide one
+    with 8-bit and with exact child boxes: all against the oracle'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    quad = np.zeros((9, 8), np.float32)
+    quad[:, :3] = [[-1.5, 0.2, 0], [1.5, 0.2, 0], [1.5, 2.8, 0], [-1.5, 0.2, 0], [1.5, 2.8, 0], [-1.5, 2.8, 0],
+                   [-0.5, 1.0, 0.8], [0.7, 1.2, 0.9], [0.1, 2.2, 0.6]]
+    quad[:, 5] = 1
+    scenes_ = {'two triangles': (quad[:6].copy(), np.array([-1, -1], np.int32), [], []),
+               'three triangles': (quad.copy(), np.array([-1, -1, -1], np.int32), [], []),
+               's34': scenes.scene_s34()}
+    for name, scene in scenes_.items():
+        ref = setup_oracle(oracle_mod, scene, 48, 40)
+        ref.render(8)
+        want = ref.get_image()
+        for lds, wide, quant, kernel in ((1, 1, 1, 1), (0, 0, 1, 0), (0, 1, 1, 2), (0, 1, 0, 2)):
+            reset_all()
+            eng = _engine(None, scene, 48, 40, mode='fast')
+            c = ctx()
+            c.set_option('lds', lds)
+            c.set_option('wide', wide)
+            c.set_option('wide_quant', quant)
+            eng.render(8)
+            raw = FilmTable().get_raw().reshape(48, 40, 4)
+            assert c.get_option('last_kernel') == kernel and np.all(raw[..., 3] == 8), (name, lds, wide, quant)
+            assert_parity(FilmTable().get_image(), want, *FAST, what=f'{name}: lds={lds} wide={wide} quant={quant}')
+    reset_all()
+
+
 @pytest.mark.parametrize('k', [0.002, 50.0])
 def test_scene_scale_dependence_is_the_references(fresh, oracle_mod, k):
     '''eps = 1e-6 and inf = 1e6 are absolute (common.py:32-33) and Face.intersect tests |n.d| against eps
