@@ -174,6 +174,37 @@ int mpt_probe_kernel(mpt_ctx *ctx, int threads, int lds_bytes, double *usec);
 /* HIP-event time of the render kernels launched since the last call (ms) and their count */
 int mpt_kernel_time(mpt_ctx *ctx, double *ms, int *launches);
 
+/* Test door: ONE device function of the hot path evaluated on n rows of inputs by the build the context's "mode"
+ * selects (the strict build's reference-order IEEE code or the production build's fast forms) -- the same inlined
+ * functions the render kernels run.  Rows are 4-byte words (f32; i32 for the two hash kinds); the column counts
+ * per kind are fixed (checked).  Holds the HIP code directly to vectors computed by the reference's own function
+ * bodies (tests/golden/reference_l1.npz); each kind names the reference function it evaluates. */
+enum {
+    MPT_UNIT_SCHLICK = 0,         /* materials/microfacet.py:9-10   in: cos                                  out: 1 */
+    MPT_UNIT_DIELECTRIC = 1,      /* materials/microfacet.py:14-27  in: etai, etao, cosi                     out: 1 */
+    MPT_UNIT_GTR1 = 2,            /* materials/microfacet.py:31-34  in: cosh, alpha                          out: 1 */
+    MPT_UNIT_GTR2 = 3,            /* materials/microfacet.py:38-41  in: cosh, alpha                          out: 1 */
+    MPT_UNIT_SMITHGGX = 4,        /* materials/microfacet.py:45-48  in: cos, alpha                           out: 1 */
+    MPT_UNIT_SAMPLE_GTR1 = 5,     /* materials/microfacet.py:69-71  in: u, v, alpha                          out: 3 */
+    MPT_UNIT_SAMPLE_GTR2 = 6,     /* materials/microfacet.py:75-77  in: u, v, alpha                          out: 3 */
+    MPT_UNIT_TANSPACE = 7,        /* common.py:213-217              in: normal3, v3                          out: tanspace(normal) @ v */
+    MPT_UNIT_SPHERICAL = 8,       /* common.py:221-225              in: h, p                                 out: 3 */
+    MPT_UNIT_DIR2TEX = 9,         /* common.py:234-239              in: dir3                                 out: 2 */
+    MPT_UNIT_REFLECT = 10,        /* common.py:247-249              in: I3, N3                               out: 3 */
+    MPT_UNIT_REFRACT = 11,        /* common.py:252-260              in: I3, N3, eta                          out: has_r, T3 */
+    MPT_UNIT_BOX = 12,            /* geometries.py:24-46            in: lo3, hi3, o3, d3                     out: hit, near, far (fast build: far = -1) */
+    MPT_UNIT_FACE = 13,           /* geometries.py:96-148           in: v0 v1 v2, o3, d3, vn0 vn1 vn2, vt0 vt1 vt2 (30)  out: hit, depth, s, t, normal3, texcoord2 */
+    MPT_UNIT_SPHERE = 14,         /* geometries.py:159-177          in: pos3, rad2, o3, d3                   out: t */
+    MPT_UNIT_AREA = 15,           /* geometries.py:58-74            in: pos3, dirx3, diry3, o3, d3           out: hit, depth, u, v */
+    MPT_UNIT_DISNEY_BRDF = 16,    /* materials/disney.py:13-106     in: 14 parameters, normal3, sign, indir3, outdir3 (24)  out: rgb */
+    MPT_UNIT_DISNEY_BOUNCE = 17,  /* materials/disney.py:13-50,115-233  in: 14 parameters, normal3, sign, indir3, samp3 (24) out: outdir3, pdf, color3 */
+    MPT_UNIT_POWER_HEURISTIC = 18,/* engine/path.py:11-15           in: a, b                                 out: 1 */
+    MPT_UNIT_WANGHASH = 19,       /* sampling/__init__.py:9-16      in: i32                                  out: i32 */
+    MPT_UNIT_WANGHASH2 = 20,      /* sampling/__init__.py:20-23     in: i32, i32                             out: i32 */
+    MPT_UNIT_KINDS = 21
+};
+int mpt_unit_eval(mpt_ctx *ctx, int kind, const void *in, int in_cols, void *out, int out_cols, int n);
+
 /* multi-GPU film gather over RCCL (one process per GPU).  uid = ncclUniqueId bytes (128). */
 int mpt_comm_unique_id(char uid[128]);
 int mpt_comm_init(mpt_ctx *ctx, const char uid[128], int nranks, int rank);

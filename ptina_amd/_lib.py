@@ -18,6 +18,16 @@ MODE_FAST, MODE_STRICT = 0, 1
 LIGHT_TYPES = {'POINT': 1, 'AREA': 2}          # LightPool.TYPES, light/__init__.py:11
 
 
+# kinds of mpt_unit_eval (include/miptina.h, enum MPT_UNIT_*): name -> (kind, input columns, output columns)
+UNIT_KINDS = {
+    'schlick': (0, 1, 1), 'dielectric': (1, 3, 1), 'gtr1': (2, 2, 1), 'gtr2': (3, 2, 1), 'smithggx': (4, 2, 1),
+    'sample_gtr1': (5, 3, 3), 'sample_gtr2': (6, 3, 3), 'tanspace': (7, 6, 3), 'spherical': (8, 2, 3),
+    'dir2tex': (9, 3, 2), 'reflect': (10, 6, 3), 'refract': (11, 7, 4), 'box': (12, 12, 3), 'face': (13, 30, 9),
+    'sphere': (14, 10, 1), 'area': (15, 15, 4), 'disney_brdf': (16, 24, 3), 'disney_bounce': (17, 24, 7),
+    'power_heuristic': (18, 2, 1), 'wanghash': (19, 1, 1), 'wanghash2': (20, 2, 1),
+}
+
+
 class Caps(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
                 ('max_faces', 'max_texels', 'max_materials', 'max_textures', 'max_lights',
@@ -77,6 +87,7 @@ SIGNATURES = {
     'mpt_reset_counters': (_i, [_vp]),
     'mpt_probe_kernel': (_i, [_vp, _i, _i, C.POINTER(C.c_double)]),
     'mpt_kernel_time': (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
+    'mpt_unit_eval': (_i, [_vp, _i, _vp, _i, _vp, _i, _i]),
     'mpt_comm_unique_id': (_i, [C.c_char_p]),
     'mpt_comm_init': (_i, [_vp, C.c_char_p, _i, _i]),
     'mpt_comm_gather_film': (_i, [_vp, _i, _i]),
@@ -203,6 +214,16 @@ class Context:
         v = C.c_int(0)
         self.call('mpt_get_option', key.encode(), C.byref(v))
         return v.value
+
+    def unit_eval(self, name, rows):
+        '''test door (mpt_unit_eval): one device function of the hot path on rows of inputs, by the build the
+        context's mode selects; rows f32 (i32 for the hash kinds), returns [n, out_cols] of the same type'''
+        kind, nin, nout = UNIT_KINDS[name]
+        dt = np.int32 if name.startswith('wanghash') else np.float32
+        a = np.ascontiguousarray(np.asarray(rows, dt).reshape(-1, nin))
+        out = np.zeros((a.shape[0], nout), dt)
+        self.call('mpt_unit_eval', kind, a.ctypes.data_as(C.c_void_p), nin, out.ctypes.data_as(C.c_void_p), nout, a.shape[0])
+        return out
 
     def counters(self):
         cnt = Counters()

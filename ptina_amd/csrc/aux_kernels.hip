@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include "mpt_types.h"
+#include "tri_records.h"
 
 // SobolSampler.update, sampling/sobol.py:99-105, for `count` consecutive frames in one launch:
 // thread j owns dimension j, keeps X[j] in a register, and emits P[f][j] for every frame.
@@ -167,18 +168,10 @@ MPT_KERNEL_API hipError_t mpt_launch_export(const MptVec4 *film, float *out, int
 __global__ __launch_bounds__(256) void derive_tfast_kernel(const MptVec4 *__restrict__ tgeo, MptVec4 *__restrict__ tfast, int n) {
     int slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= n) return;
-    const MptVec4 g0 = tgeo[(size_t)slot * 4 + 0], g1 = tgeo[(size_t)slot * 4 + 1], g2 = tgeo[(size_t)slot * 4 + 2],
-                  g3 = tgeo[(size_t)slot * 4 + 3];
-    const float D = g0.w, uu = g1.w, uv = g2.w, vv = g3.w;
-    const float u[3] = { g1.x, g1.y, g1.z }, v[3] = { g2.x, g2.y, g2.z };
-    float a[3], c[3];
-    for (int k = 0; k < 3; k++) {
-        a[k] = (uv * v[k] - vv * u[k]) / D;
-        c[k] = (uv * u[k] - uu * v[k]) / D;
-    }
-    tfast[(size_t)slot * 3 + 0] = { g3.x, g3.y, g3.z, g0.x };
-    tfast[(size_t)slot * 3 + 1] = { a[0], a[1], a[2], g0.y };
-    tfast[(size_t)slot * 3 + 2] = { c[0], c[1], c[2], g0.z };
+    const MptVec4 g[4] = { tgeo[(size_t)slot * 4 + 0], tgeo[(size_t)slot * 4 + 1], tgeo[(size_t)slot * 4 + 2], tgeo[(size_t)slot * 4 + 3] };
+    MptVec4 f[3];
+    tri_make_tfast(g, f);
+    tfast[(size_t)slot * 3 + 0] = f[0]; tfast[(size_t)slot * 3 + 1] = f[1]; tfast[(size_t)slot * 3 + 2] = f[2];
 }
 
 MPT_KERNEL_API hipError_t mpt_launch_derive_tfast(const MptVec4 *tgeo, MptVec4 *tfast, int n, hipStream_t stream) {

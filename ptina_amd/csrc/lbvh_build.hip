@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include "mpt_types.h"
+#include "tri_records.h"
 
 #define LB_BLOCK 256
 
@@ -234,24 +235,11 @@ __global__ __launch_bounds__(LB_BLOCK) void pack_tris_kernel(const float *__rest
     if (slot >= n) return;
     int f = leaf[slot];
     const float *p0 = vpos(verts, f, 0), *p1 = vpos(verts, f, 1), *p2 = vpos(verts, f, 2);
-    float u[3], v[3], nn[3];
+    MptVec4 g[4], sh[4];
+    tri_make_tgeo(p0, p1, p2, g);
+    tri_make_tshade(p0, p1, p2, asf(mtlids[f]), sh);
 #pragma unroll
-    for (int a = 0; a < 3; a++) { u[a] = p1[a] - p0[a]; v[a] = p2[a] - p0[a]; }
-    nn[0] = u[1] * v[2] - u[2] * v[1];
-    nn[1] = u[2] * v[0] - u[0] * v[2];
-    nn[2] = u[0] * v[1] - u[1] * v[0];
-    float uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
-    float uv = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
-    float vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-    float D = uv * uv - uu * vv;
-    tgeo[(size_t)slot * 4 + 0] = { p0[0], p0[1], p0[2], D };
-    tgeo[(size_t)slot * 4 + 1] = { u[0], u[1], u[2], uu };
-    tgeo[(size_t)slot * 4 + 2] = { v[0], v[1], v[2], uv };
-    tgeo[(size_t)slot * 4 + 3] = { nn[0], nn[1], nn[2], vv };
-    tshade[(size_t)slot * 4 + 0] = { p0[3], p0[4], p0[5], p1[3] };
-    tshade[(size_t)slot * 4 + 1] = { p1[4], p1[5], p2[3], p2[4] };
-    tshade[(size_t)slot * 4 + 2] = { p2[5], p0[6], p0[7], p1[6] };
-    tshade[(size_t)slot * 4 + 3] = { p1[7], p2[6], p2[7], asf(mtlids[f]) };
+    for (int k = 0; k < 4; k++) { tgeo[(size_t)slot * 4 + k] = g[k]; tshade[(size_t)slot * 4 + k] = sh[k]; }
 }
 
 // ------------------------------------------------------------------ driver

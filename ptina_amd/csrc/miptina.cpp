@@ -177,7 +177,8 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     for (auto &ev : c->event_pool) hipEventDestroy(ev);
     for (int p = 0; p < 3; p++) hipFree(c->film[p]);
     hipFree(c->resolved); hipFree(c->exported);
-    hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade); hipFree(c->wnode); hipFree(c->qnode); hipFree(c->tfast); hipFree(c->stack_spill); hipFree(c->fnode_soa);
+    hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade); hipFree(c->wnode); hipFree(c->qnode); hipFree(c->tfast); hipFree(c->fnode_soa);
+    for (int k = 0; k < MPT_MAX_PIPE; k++) hipFree(c->stack_spill2[k]);
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
@@ -589,7 +590,7 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     p.ntiles = p.tiles_x * p.tiles_y;
     memcpy(p.world_fac, c->world_fac, sizeof p.world_fac);
     memcpy(p.v2w, c->v2w, sizeof p.v2w);
-    p.wnode = c->wnode; p.qnode = c->qnode; p.stack_spill = c->stack_spill;
+    p.wnode = c->wnode; p.qnode = c->qnode; p.stack_spill = nullptr;
     p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade; p.tfast = c->tfast;
     p.default_mtl = c->caps.max_materials;
     p.mats = c->mats; p.lights = c->lights; p.images = c->images; p.texels = c->texels;
@@ -754,14 +755,17 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     int wide_blocks = 0;
     if (wide_kernel) {
         HIP_TRY(mpt_wide_blocks(launch_cus, c->count, c->use_quant, &wide_blocks));
-        const size_t need_spill = (size_t)wide_blocks * MPT_BLOCK * 88;   // SpillStack::SPILL entries per lane
-        if (need_spill > c->stack_spill_cap) {
-            HIP_TRY(hipDeviceSynchronize());
-            hipFree(c->stack_spill); c->stack_spill = nullptr; c->stack_spill_cap = 0;
-            if (dev_alloc(&c->stack_spill, need_spill)) return 1;
-            c->stack_spill_cap = need_spill;
-        }
-        p.stack_spill = c->stack_spill;
+        const size_t need_spill = (size_t)wide_blocks * MPT_BLOCK * 128;   // >= SpillStack::SPILL entries per lane (128 - LDS levels)
+        // every slot of the ring at once (an allocation synchronises the device), and one strip PER SLOT: the launches of
+        // different slots overlap, and a strip is indexed by block and lane only
+        for (int q = 0; q < c->cur_depth; q++)
+            if (need_spill > c->stack_spill2_cap[q]) {
+                HIP_TRY(hipDeviceSynchronize());
+                hipFree(c->stack_spill2[q]); c->stack_spill2[q] = nullptr; c->stack_spill2_cap[q] = 0;
+                if (dev_alloc(&c->stack_spill2[q], need_spill)) return 1;
+                c->stack_spill2_cap[q] = need_spill;
+            }
+        p.stack_spill = c->stack_spill2[k];
     }
     if (fast && !lds_kernel && !wide_kernel && c->node_soa && c->nfaces >= 2) {
         // layout A/B: the same records as four arrays (one 16-B gather per array instead of one 64-B record)
@@ -968,6 +972,33 @@ extern "C" int mpt_probe_kernel(mpt_ctx *c, int threads, int lds_bytes, double *
     HIP_TRY(hipStreamSynchronize(c->probe_stream));
     auto t1 = std::chrono::steady_clock::now();
     if (usec) *usec = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    return 0;
+}
+
+// test door: one device function of the hot path on rows of inputs (include/miptina.h, unit_eval.hip)
+extern "C" int mpt_unit_eval(mpt_ctx *c, int kind, const void *in, int in_cols, void *out, int out_cols, int n) {
+    if (use_ro(c)) return 1;
+    static const int cols[MPT_UNIT_KINDS][2] = {
+        { 1, 1 }, { 3, 1 }, { 2, 1 }, { 2, 1 }, { 2, 1 }, { 3, 3 }, { 3, 3 }, { 6, 3 }, { 2, 3 }, { 3, 2 }, { 6, 3 }, { 7, 4 },
+        { 12, 3 }, { 30, 9 }, { 10, 1 }, { 15, 4 }, { 24, 3 }, { 24, 7 }, { 2, 1 }, { 1, 1 }, { 2, 1 } };
+    if (kind < 0 || kind >= MPT_UNIT_KINDS) return fail("unit kind %d outside [0, %d)", kind, (int)MPT_UNIT_KINDS);
+    if (in_cols != cols[kind][0] || out_cols != cols[kind][1])
+        return fail("unit kind %d takes %d input and %d output columns, got %d and %d", kind, cols[kind][0], cols[kind][1],
+                    in_cols, out_cols);
+    if (n < 0 || (n > 0 && (!in || !out))) return fail("bad unit_eval arguments");
+    if (n == 0) return 0;
+    float *d_in = nullptr, *d_out = nullptr;
+    if (dev_alloc(&d_in, (size_t)n * in_cols)) return 1;
+    if (dev_alloc(&d_out, (size_t)n * out_cols)) { hipFree(d_in); return 1; }
+    hipError_t e = hipMemcpyAsync(d_in, in, (size_t)n * in_cols * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, (size_t)n * out_cols * 4, c->stream);
+    if (e == hipSuccess)
+        e = c->mode == MPT_MODE_STRICT ? mpt_launch_unit_eval_strict(kind, d_in, in_cols, d_out, out_cols, n, c->stream)
+                                       : mpt_launch_unit_eval_fast(kind, d_in, in_cols, d_out, out_cols, n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * out_cols * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_in); hipFree(d_out);
+    if (e != hipSuccess) return fail("mpt_unit_eval: %s", hipGetErrorString(e));
     return 0;
 }
 

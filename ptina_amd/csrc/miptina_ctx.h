@@ -35,6 +35,8 @@ MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *parti
 MPT_KERNEL_API hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_transpose_nodes(const MptVec4 *in, MptVec4 *out, int ni, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_probe(double *out, int threads, size_t lds_bytes, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_unit_eval_fast(int kind, const float *in, int in_cols, float *out, int out_cols, int n, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_unit_eval_strict(int kind, const float *in, int in_cols, float *out, int out_cols, int n, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
 
 // on-GPU LBVH build (lbvh_build.hip)
@@ -118,7 +120,9 @@ struct mpt_ctx {
     float wide_ratio = 1.f;                           // expected fetches per ray, wide / binary (surface-area sums)
     int use_wide = 1;                                 // option "wide": 1 walk the 4-wide nodes when the scene does not fit LDS
                                                       // (default), 0 the binary tree
-    int *stack_spill = nullptr; size_t stack_spill_cap = 0;
+    // overflow strips of the wide kernel's per-lane stacks: one per ring slot, because launches of different slots
+    // are resident together and index their strips by block and lane only
+    int *stack_spill2[MPT_MAX_PIPE] = {}; size_t stack_spill2_cap[MPT_MAX_PIPE] = {};
     int node_soa = 0;                                 // option "node_soa" (layout A/B): binary gather kernel reads an SoA transpose
     MptVec4 *fnode_soa = nullptr; size_t fnode_soa_cap = 0; bool fnode_soa_valid = false;
     size_t node_cap = 0, tri_cap = 0;

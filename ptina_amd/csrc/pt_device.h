@@ -208,7 +208,7 @@ DEV bool tri_test_fast(MptVec4 g0, MptVec4 g1, MptVec4 g2, V3 ro, V3 rd, float *
 #endif
 
 // Box.intersect, geometries.py:24-46
-DEV bool box_strict(V3 lo, V3 hi, V3 ro, V3 rd) {
+DEV bool box_strict(V3 lo, V3 hi, V3 ro, V3 rd, float *near_ = nullptr, float *far_ = nullptr) {
     float nearv = 0.0f, farv = MPT_INF;
     bool hit = true;
     const float lo_[3] = { lo.x, lo.y, lo.z }, hi_[3] = { hi.x, hi.y, hi.z };
@@ -226,6 +226,8 @@ DEV bool box_strict(V3 lo, V3 hi, V3 ro, V3 rd) {
             if (nearv > farv) hit = false;
         }
     }
+    if (near_) *near_ = nearv;
+    if (far_) *far_ = farv;
     return hit;
 }
 
@@ -334,7 +336,10 @@ struct QuantScene {
 struct SpillStack {
     static constexpr int SENTINEL = (int)0x80000000;
     static constexpr int PLANE_OFF = 16;               // bytes between the lo and hi float4 of an axis in a wide record
-    static constexpr int CAP = 40, SPILL = 88;    // 40 levels x 256 lanes x 4 B = 40 KiB of LDS: four workgroups per CU
+#ifndef MPT_X_SPILL_CAP
+#define MPT_X_SPILL_CAP 40     // (a test build sets it to a handful of levels so that every ray uses the global strip)
+#endif
+    static constexpr int CAP = MPT_X_SPILL_CAP, SPILL = 128 - CAP;    // 40 levels x 256 lanes x 4 B = 40 KiB of LDS: four workgroups per CU
     int *base;                 // &lds[threadIdx.x]
     int *spill;                // this lane's SPILL entries
     int sp;
@@ -564,7 +569,7 @@ DEV float sphere_intersect(V3 pos, float rad2, V3 ro, V3 rd) {               // 
     return ret;
 }
 
-DEV bool area_intersect(V3 pos, V3 dirx, V3 diry, V3 ro, V3 rd, float *depth) {   // geometries.py:58-74
+DEV bool area_intersect(V3 pos, V3 dirx, V3 diry, V3 ro, V3 rd, float *depth, float *u_ = nullptr, float *v_ = nullptr) {   // geometries.py:58-74
     bool hit = false;
     V3 nrm = normalized(cross(dirx, diry));
     float NoD = dot(nrm, rd);
@@ -574,6 +579,8 @@ DEV bool area_intersect(V3 pos, V3 dirx, V3 diry, V3 ro, V3 rd, float *depth) { 
         float u = m_div(dot(hitdisp, dirx), norm_sqr(dirx));
         float v = m_div(dot(hitdisp, diry), norm_sqr(diry));
         *depth = t;
+        if (u_) *u_ = u;
+        if (v_) *v_ = v;
         if (-1.0f < u && u < 1.0f && -1.0f < v && v < 1.0f) hit = true;
     }
     return hit;
@@ -1139,13 +1146,18 @@ DEV LightSample lights_sample(const MptRenderParams &p, V3 hitpos, V3 samp) {   
     return ret;
 }
 
+DEV void dir2tex(V3 dir, float *s, float *t) {                               // common.py:234-239
+    V3 dn = normalized(dir);
+    *s = atan2f(dn.z, dn.x) / MPT_PI * 0.5f + 0.5f;
+    *t = atan2f(dn.y, sqrtf(dn.x * dn.x + dn.z * dn.z)) / MPT_PI + 0.5f;
+}
+
 DEV V3 world_at(const MptRenderParams &p, V3 dir) {                          // light/world.py:22-29
     V3 fac = v3(p.world_fac[0], p.world_fac[1], p.world_fac[2]);
     if (p.world_tex != -1) {
         V3 d2 = v3(dir.x, dir.z, -dir.y);                                    // dir.y, dir.z = dir.z, -dir.y
-        V3 dn = normalized(d2);                                              // dir2tex, common.py:234-239
-        float s = atan2f(dn.z, dn.x) / MPT_PI * 0.5f + 0.5f;
-        float t = atan2f(dn.y, sqrtf(dn.x * dn.x + dn.z * dn.z)) / MPT_PI + 0.5f;
+        float s, t;
+        dir2tex(d2, &s, &t);
         MptVec4 tx = image_sample(p, p.world_tex, s, t);
         fac = fac * v3(tx.x, tx.y, tx.z);
     }
@@ -1170,15 +1182,20 @@ DEV void camera_generate(const MptRenderParams &p, float x, float y, V3 *ro, V3 
 }
 
 // ---------------------------------------------------------------- shading geometry (model.py:88-101, geometries.py:96-108)
+// Face.normal / Face.texcoord, geometries.py:96-108, from a tshade record and the hit's barycentrics
+DEV void face_shading(MptVec4 s0, MptVec4 s1, MptVec4 s2, MptVec4 s3, float u, float v, V3 *nrm, float *tu, float *tv) {
+    float wx = 1.0f - u - v, wy = u, wz = v;
+    V3 vn0 = v3(s0.x, s0.y, s0.z), vn1 = v3(s0.w, s1.x, s1.y), vn2 = v3(s1.z, s1.w, s2.x);
+    *nrm = normalized(vn0 * wx + vn1 * wy + vn2 * wz);
+    *tu = wx * s2.y + wy * s2.w + wz * s3.y;
+    *tv = wx * s2.z + wy * s3.x + wz * s3.z;
+}
+
 DEV void get_geometries(const MptRenderParams &p, const Hit &hit, V3 ro, V3 rd, V3 *hitpos, V3 *normal, Disney &mat) {
     const MptVec4 *s = p.tshade + (size_t)hit.index * 4;
     MptVec4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
-    float u = hit.u, v = hit.v;
-    float wx = 1.0f - u - v, wy = u, wz = v;
-    V3 vn0 = v3(s0.x, s0.y, s0.z), vn1 = v3(s0.w, s1.x, s1.y), vn2 = v3(s1.z, s1.w, s2.x);
-    V3 nrm = normalized(vn0 * wx + vn1 * wy + vn2 * wz);
-    float tu = wx * s2.y + wy * s2.w + wz * s3.y;
-    float tv = wx * s2.z + wy * s3.x + wz * s3.z;
+    V3 nrm; float tu, tv;
+    face_shading(s0, s1, s2, s3, hit.u, hit.v, &nrm, &tu, &tv);
     *hitpos = ro + rd * hit.depth;
     float sign = -dot(rd, nrm);
     if (sign < 0.0f) nrm = -nrm;
@@ -1200,12 +1217,8 @@ template <class SCENE>
 DEV void get_geometries_rec(const MptRenderParams &p, const SCENE &sc, const ShadeRec &r, const Hit &hit, V3 ro, V3 rd,
                             V3 *hitpos, V3 *normal, Disney &mat) {
     const MptVec4 s0 = r.s0, s1 = r.s1, s2 = r.s2, s3 = r.s3;
-    float u = hit.u, v = hit.v;
-    float wx = 1.0f - u - v, wy = u, wz = v;
-    V3 vn0 = v3(s0.x, s0.y, s0.z), vn1 = v3(s0.w, s1.x, s1.y), vn2 = v3(s1.z, s1.w, s2.x);
-    V3 nrm = normalized(vn0 * wx + vn1 * wy + vn2 * wz);
-    float tu = wx * s2.y + wy * s2.w + wz * s3.y;
-    float tv = wx * s2.z + wy * s3.x + wz * s3.z;
+    V3 nrm; float tu, tv;
+    face_shading(s0, s1, s2, s3, hit.u, hit.v, &nrm, &tu, &tv);
     *hitpos = ro + rd * hit.depth;
     float sign = -dot(rd, nrm);
     if (sign < 0.0f) nrm = -nrm;

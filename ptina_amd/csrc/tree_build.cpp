@@ -2,6 +2,7 @@
 // SAH re-partition for the fast build, and the glue around the device build (lbvh_build.hip).
 
 #include "miptina_ctx.h"
+#include "tri_records.h"
 #include <atomic>
 #include <thread>
 
@@ -338,24 +339,9 @@ static int build_tree_host(mpt_ctx *c) {
     for (int slot = 0; slot < n; slot++) {
         int f = c->h_leaf[slot];
         const float *p0 = pos(f, 0), *p1 = pos(f, 1), *p2 = pos(f, 2);
-        // hoisted terms of Face.intersect, geometries.py:120-122,134-136,140 (same f32 operations)
-        float u[3], v[3], nn[3];
-        for (int a = 0; a < 3; a++) { u[a] = p1[a] - p0[a]; v[a] = p2[a] - p0[a]; }
-        nn[0] = u[1] * v[2] - u[2] * v[1];
-        nn[1] = u[2] * v[0] - u[0] * v[2];
-        nn[2] = u[0] * v[1] - u[1] * v[0];
-        float uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
-        float uv = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
-        float vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-        float D = uv * uv - uu * vv;
-        tgeo[(size_t)slot * 4 + 0] = { p0[0], p0[1], p0[2], D };
-        tgeo[(size_t)slot * 4 + 1] = { u[0], u[1], u[2], uu };
-        tgeo[(size_t)slot * 4 + 2] = { v[0], v[1], v[2], uv };
-        tgeo[(size_t)slot * 4 + 3] = { nn[0], nn[1], nn[2], vv };
-        tshade[(size_t)slot * 4 + 0] = { p0[3], p0[4], p0[5], p1[3] };
-        tshade[(size_t)slot * 4 + 1] = { p1[4], p1[5], p2[3], p2[4] };
-        tshade[(size_t)slot * 4 + 2] = { p2[5], p0[6], p0[7], p1[6] };
-        tshade[(size_t)slot * 4 + 3] = { p1[7], p2[6], p2[7], asf(c->mtlids[f]) };
+        // hoisted terms of Face.intersect, geometries.py:120-122,134-136,140 (same f32 operations: tri_records.h)
+        tri_make_tgeo(p0, p1, p2, &tgeo[(size_t)slot * 4]);
+        tri_make_tshade(p0, p1, p2, asf(c->mtlids[f]), &tshade[(size_t)slot * 4]);
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if ((size_t)std::max(ni, 1) > c->node_cap) {

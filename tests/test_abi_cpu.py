@@ -151,3 +151,16 @@ def test_ptina_alias_package_maps_onto_ptina_amd():
     for name in ('init_things', 'FilmTable', 'ModelPool', 'MaterialPool', 'ImagePool', 'BVHTree', 'Camera',
                  'LightPool', 'WorldLight', 'PathEngine', 'ti', 'np'):
         assert name in ns, name
+
+
+def test_unit_kind_table_mirrors_the_header_enum():
+    '''mpt_unit_eval's kinds: the ctypes-side table and the header's enum agree, and every kind cites a reference function'''
+    from ptina_amd import _lib
+    src = open(os.path.join(ROOT, 'include', 'miptina.h')).read()
+    enum = dict((k.lower(), int(v)) for k, v in re.findall(r'MPT_UNIT_([A-Z0-9_]+) = (\d+)', src))
+    n = enum.pop('kinds')
+    assert n == len(enum) == len(_lib.UNIT_KINDS)
+    assert {k: v[0] for k, v in _lib.UNIT_KINDS.items()} == enum
+    for line in src.splitlines():
+        if re.search(r'MPT_UNIT_[A-Z0-9_]+ = \d+,', line):
+            assert re.search(r'\.py:\d+', line), f'no reference citation: {line.strip()}'

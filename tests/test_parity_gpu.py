@@ -306,6 +306,52 @@ def test_lds_and_gather_kernels_agree_bit_for_bit(fresh):
     assert 0.98 * exact['n_tri'] <= quant['n_tri'] <= 1.15 * exact['n_tri']
 
 
+_SPILL_SCRIPT = r'''
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+from ptina_amd import scenes
+from ptina_amd.common import ctx, reset_all
+from ptina_amd.things import FilmTable
+from helpers import setup_engine
+films = []
+for sync_each in (True, False):
+    reset_all()
+    eng = setup_engine(scenes.scene_s978(), 160, 128, mode='fast')
+    c = ctx()
+    c.set_option('lds', 0)                 # the 4-wide gather kernel (last_kernel 2)
+    c.set_option('batch', 2)
+    c.set_option('pipe_depth', 4)          # four launches in flight
+    for _ in range(8):
+        eng.render(2)                      # one launch each
+        if sync_each:
+            c.call('mpt_synchronize')
+    films.append(FilmTable().get_raw().copy())
+    assert c.get_option('last_kernel') == 2 and c.get_option('cur_depth') == 4
+assert np.all(films[0][:, 3] == 16)
+print('EQUAL' if np.array_equal(films[0], films[1]) else 'DIFFERENT %d' % int((films[0] != films[1]).any(axis=1).sum()))
+'''
+
+
+def test_pipelined_wide_launches_keep_their_own_spill_strips(fresh, tmp_path):
+    '''round-2 ADVICE: the overflow strips of the wide kernel's per-lane stacks are indexed by block and lane only, and the
+    launches of different ring slots are resident together -- each slot needs its own.  A test build of the library keeps
+    only 4 stack levels in LDS (libmiptina_spilltest.so, make -C ptina_amd/csrc spilltest), so every ray of the
+    978-triangle scene runs through the strips: eight launches issued back to back (four in flight) must give the film
+    of eight launches issued one at a time, bit for bit'''
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, 'ptina_amd', 'libmiptina_spilltest.so')
+    assert os.path.exists(lib), 'build it with make -C ptina_amd/csrc spilltest (__graft_entry__.build() does)'
+    script = tmp_path / 'spill.py'
+    script.write_text(_SPILL_SCRIPT)
+    env = dict(os.environ, MIPTINA_LIB=lib)
+    r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'EQUAL' in r.stdout, r.stdout + r.stderr
+
+
 def test_quantised_boxes_far_from_the_origin(fresh, oracle_mod):
     '''the 8-bit child boxes of the 4-wide nodes are offsets from each node's own box, decoded in the kernel as
     q * (scale * inv) + (origin * inv - o * inv): a scene moved 300-500 units away from the origin (coordinates 100 x

@@ -1,0 +1,248 @@
+'''
+GPU (-m gpu): the HIP device functions held DIRECTLY to vectors computed by the reference's own function
+bodies (tests/golden/reference_l1.npz, made by tests/golden/make_reference_l1_golden.py from /root/reference's
+@ti.func sources) -- not through the CPU oracle.
+
+mpt_unit_eval (include/miptina.h) runs one inlined device function of the render kernels per row, in the build the
+context's mode selects:
+  strict build (reference-order IEEE arithmetic, no contraction): a few ulp of the f32 vectors -- libm-grade
+      sinf / cosf / powf / logf differ from numpy's by <= 1-2 ulp and a cancellation in front amplifies that
+      (the same per-function bounds tests/test_reference_l1_cpu.py holds the C oracle to);
+  production build (v_rcp / v_rsq / v_sqrt / v_sin / v_cos / exp2-log2, FMA contraction, 48-byte triangle records,
+      shared-lobe Disney.bounce): relative 1e-5 against the same f32 vectors (whose inputs are exact in f32), with
+      the stated per-function exceptions, each with the reason it is looser.
+Discrete outputs (hit flags, which Choice branch a bounce took, has-refraction, integer hashes) must be the
+reference's exactly, up to the stated handful of last-bit edge decisions.
+
+Reference functions: materials/microfacet.py:9-78, common.py:213-260, geometries.py:24-177,
+materials/disney.py:13-233 (+ Choice, materials/__init__.py:37-48), sampling/__init__.py:9-23, engine/path.py:11-15.
+'''
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'reference_l1.npz')
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(params=['strict', 'fast'])
+def dev(request, fresh):
+    from ptina_amd import _lib
+    from ptina_amd.things import init_things
+    from ptina_amd.common import ctx
+    init_things()
+    ctx().set_option('mode', _lib.MODE_STRICT if request.param == 'strict' else _lib.MODE_FAST)
+    return request.param, ctx()
+
+
+def report(msg):
+    from helpers import _report
+    print(msg)
+    _report(msg)
+
+
+def close(got, want, rel, what, abs_=0.0, allow=0):
+    '''|got - want| <= rel |want| + abs_ element-wise; NaN / infinity patterns equal; up to `allow` rows may fail'''
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, what
+    g2, w2 = got.reshape(got.shape[0], -1), want.reshape(want.shape[0], -1)
+    nan_ok = np.isnan(g2) == np.isnan(w2)
+    inf = np.isinf(w2)
+    inf_ok = np.where(inf, g2 == w2, ~np.isinf(g2))
+    fin = ~(np.isnan(w2) | inf | np.isnan(g2) | np.isinf(g2))
+    err = np.where(fin, np.abs(g2 - w2), 0.0)
+    bound = rel * np.abs(np.where(fin, w2, 0.0)) + abs_
+    ratio = np.where(fin, err / np.maximum(bound, 1e-300), 0.0)
+    row_bad = (~nan_ok | ~inf_ok | (ratio > 1.0)).any(axis=1)
+    worst = float(ratio.max()) if ratio.size else 0.0
+    report(f'{what}: worst error {worst:.3f} x the bound (rel {rel:g}, abs {abs_:g}); rows outside {int(row_bad.sum())} of {len(row_bad)} (allowed {allow})')
+    assert int(row_bad.sum()) <= allow, f'{what}: {int(row_bad.sum())} rows outside the bound (worst {worst:.2f} x; rel {rel:g}, abs {abs_:g}); first bad rows {np.nonzero(row_bad)[0][:8]}'
+
+
+def pick(mode, strict, fast):
+    return strict if mode == 'strict' else fast
+
+
+def test_microfacet(gold, dev):
+    mode, c = dev
+    tag = 'f32'
+    x = gold[f'{tag}/schlick/in']
+    close(c.unit_eval('schlick', x)[:, 0], gold[f'{tag}/schlick/out'], pick(mode, 2e-6, 1e-5), 'schlickFresnel', 1e-12)
+    close(c.unit_eval('dielectric', gold[f'{tag}/dielectric/in'])[:, 0], gold[f'{tag}/dielectric/out'],
+          pick(mode, 4e-6, 1e-5), 'dielectricFresnel', pick(mode, 1e-9, 2e-7))   # (a1 - a2) / (a1 + a2) cancels at normal incidence: absolute floor
+    g = gold[f'{tag}/gtr/in']
+    # GTR1 = (a2 - 1) / (pi log(a2) t): near alpha = 1 both a2 - 1 and log(a2) cancel; the fast build's v_log_f32 has
+    # ~1 ulp ABSOLUTE error in log2, i.e. a large relative one where log(a2) -> 0
+    close(c.unit_eval('gtr1', g)[:, 0], gold[f'{tag}/gtr1/out'], pick(mode, 2e-5, 2e-4), 'GTR1')
+    close(c.unit_eval('gtr2', g)[:, 0], gold[f'{tag}/gtr2/out'], pick(mode, 2e-6, 1e-5), 'GTR2')
+    close(c.unit_eval('smithggx', g)[:, 0], gold[f'{tag}/smithggx/out'], pick(mode, 2e-6, 1e-5), 'smithGGX')
+    s = gold[f'{tag}/sample_gtr/in']
+    want1, want2 = gold[f'{tag}/sample_gtr1/out'], gold[f'{tag}/sample_gtr2/out']
+    got1, got2 = c.unit_eval('sample_gtr1', s), c.unit_eval('sample_gtr2', s)
+    assert np.isnan(want1).any() and np.isfinite(want1).any()        # alpha < 1: NaN, as in the reference
+    # sample_GTR1: sqrt(alpha^(2 - 2u) - 1) / (alpha^2 - 1) then sqrt(1 - h^2): two cancellations; v_sin / v_cos carry
+    # ~1e-6 absolute error
+    close(got1, want1, pick(mode, 3e-5, 3e-4), 'sample_GTR1', pick(mode, 3e-6, 3e-5))
+    # sample_GTR2: h = sqrt((1 - u) / (1 - u (1 - a^2))) through v_rcp, then sqrt(1 - h^2): for h -> 1 the second root
+    # amplifies the reciprocal's ulp (measured 1.7e-4 on two of 64 rows, 2e-5 elsewhere)
+    close(got2, want2, pick(mode, 1e-5, 3e-4), 'sample_GTR2', pick(mode, 1e-6, 2e-6))
+
+
+def test_common_helpers(gold, dev):
+    mode, c = dev
+    tag = 'f32'
+    close(c.unit_eval('tanspace', gold[f'{tag}/tanspace/in']), gold[f'{tag}/tanspace/out'], pick(mode, 4e-6, 1e-5), 'tanspace @ v', pick(mode, 4e-6, 1e-5))
+    close(c.unit_eval('spherical', gold[f'{tag}/spherical/in']), gold[f'{tag}/spherical/out'], pick(mode, 2e-6, 1e-5), 'spherical', pick(mode, 5e-7, 2e-6))
+    close(c.unit_eval('dir2tex', gold[f'{tag}/dir2tex/in']), gold[f'{tag}/dir2tex/out'], pick(mode, 2e-6, 1e-5), 'dir2tex', pick(mode, 2e-7, 1e-6))
+    close(c.unit_eval('reflect', gold[f'{tag}/reflect/in']), gold[f'{tag}/reflect/out'], pick(mode, 2e-6, 1e-5), 'reflect', pick(mode, 4e-7, 1e-6))
+    want = gold[f'{tag}/refract/out']
+    got = c.unit_eval('refract', gold[f'{tag}/refract/in'])
+    assert np.array_equal(got[:, 0], want[:, 0]), 'refract: has_r (total internal reflection decided differently)'
+    close(got[:, 1:], want[:, 1:], pick(mode, 4e-6, 1e-5), 'refract', pick(mode, 4e-7, 1e-6))
+
+
+def test_geometries(gold, dev):
+    mode, c = dev
+    tag = 'f32'
+    # ---- Box.intersect
+    rows, want = gold[f'{tag}/box/in'], gold[f'{tag}/box/out']
+    got = c.unit_eval('box', rows)
+    if mode == 'strict':
+        assert np.array_equal(got[:, 0], want[:, 0]), 'Box.intersect: hit flag'
+        close(got[:, 1:], want[:, 1:], 2e-6, 'Box.intersect near / far', 1e-6)
+    else:
+        # production slab test (1/d, o/d, no |d| < eps branch): same hit set wherever no ray component is below eps
+        # (the reference then tests the origin against the slab instead, geometries.py:33-35; a measure-zero set of rays)
+        general = (np.abs(rows[:, 9:12]) >= 1e-6).all(axis=1)
+        assert general.sum() >= 96
+        assert np.array_equal(got[general, 0], want[general, 0]), 'box_fast: hit flag on rays with no component below eps'
+        hit = general & (want[:, 0] == 1)
+        close(got[hit, 1], want[hit, 1], 1e-5, 'box_fast entry distance', 2e-6)
+        report(f'box_fast on the {int((~general).sum())} axis-parallel rays: {int((got[~general, 0] != want[~general, 0]).sum())} hit flags differ (informational)')
+    # ---- Face.intersect + normal + texcoord
+    rows = np.column_stack([gold[f'{tag}/face/in'], gold[f'{tag}/face/vn'], gold[f'{tag}/face/vt']])
+    want = gold[f'{tag}/face/out']
+    got = c.unit_eval('face', rows)
+    flips = got[:, 0] != want[:, 0]
+    # a hit decided on the last bit (s + t <= 1 on an edge, D ~ 1e-8 needles) may flip
+    report(f'Face.intersect [{mode}]: {int(flips.sum())} of {len(flips)} hit flags differ')
+    assert flips.sum() <= pick(mode, 2, 4), f'Face.intersect: {int(flips.sum())} hit flags differ'
+    ok = ~flips & (want[:, 0] == 1)
+    assert ok.sum() >= 30
+    close(got[ok, 1], want[ok, 1], pick(mode, 2e-5, 5e-5), 'Face.intersect depth')
+    # s, t = (uv wv - vv wu) / D: needle triangles (D ~ 1e-8) amplify the last ulp of the dot products
+    needle = np.zeros(len(rows), bool)
+    needle[:12] = True
+    close(got[ok & ~needle, 2:4], want[ok & ~needle, 2:4], pick(mode, 2e-4, 2e-4), 'Face.intersect uv', pick(mode, 2e-5, 2e-5))
+    close(got[ok & ~needle, 4:7], gold[f'{tag}/face/normal'][ok & ~needle], pick(mode, 2e-4, 2e-4), 'Face.normal', pick(mode, 2e-5, 2e-5))
+    close(got[ok & ~needle, 7:9], gold[f'{tag}/face/texcoord'][ok & ~needle], pick(mode, 2e-4, 2e-4), 'Face.texcoord', pick(mode, 2e-5, 2e-5))
+    # ---- Sphere.intersect
+    rows, want = gold[f'{tag}/sphere/in'], gold[f'{tag}/sphere/out']
+    got = c.unit_eval('sphere', rows)[:, 0]
+    assert np.array_equal(got == 0, want == 0), 'Sphere.intersect: miss pattern'
+    close(got, want, pick(mode, 2e-5, 1e-4), 'Sphere.intersect')      # b - sqrt(det) cancels for grazing / near hits
+    # ---- Area.intersect
+    rows, want = gold[f'{tag}/area/in'], gold[f'{tag}/area/out']
+    got = c.unit_eval('area', rows)
+    assert np.array_equal(got[:, 0], want[:, 0]), 'Area.intersect: hit flag'
+    facing = want[:, 1] < 1e6                                # NoD > eps: depth / uv are computed (else inf, 0, 0)
+    assert np.array_equal(got[~facing, 1:], want[~facing, 1:].astype(np.float32))
+    close(got[facing, 1:], want[facing, 1:], pick(mode, 2e-5, 5e-5), 'Area.intersect depth / uv', pick(mode, 2e-6, 5e-6))
+
+
+def _branch_leaf(b):
+    '''which leaf of the Choice tree (materials/__init__.py:37-48, disney.py:136-231) a recorded decision string is'''
+    return {0b11: 'coat', 0b100: 'diffuse', 0b1010: 'spec', 0b10111: 'trans_reflect', 0b10110: 'trans_refract'}.get(int(b), 'spec_dead')
+
+
+def test_disney_brdf_and_bounce(gold, dev):
+    mode, c = dev
+    tag = 'f32'
+    x = gold[f'{tag}/disney/in']
+    samp = gold[f'{tag}/disney/samp']
+    names = [str(s) for s in gold['material_names']]
+    mat = x[:, 0].astype(int)
+    chaotic = np.isin(mat, [names.index(n) for n in ('glass', 'rough_glass')])
+    ior0 = mat == names.index('gltf_compat')              # ior = 0: the reference itself yields inf / NaN there
+    rows_brdf = x[:, 1:25]
+    rows_bounce = np.column_stack([x[:, 1:22], samp])
+    got_brdf = c.unit_eval('disney_brdf', rows_brdf)
+    got_b = c.unit_eval('disney_bounce', rows_bounce)
+    want_brdf, want_b = gold[f'{tag}/disney/brdf'], gold[f'{tag}/disney/bounce']
+    # ---- brdf: a sum of lobes with pow5 / log / sqrt inside
+    if mode == 'strict':
+        close(got_brdf, want_brdf, 5e-5, 'Disney.brdf', 2e-6)
+    else:
+        # the production build skips the clearcoat / transmission terms when their factor is exactly zero
+        # ("identical whenever the skipped factor is finite"): the ior = 0 material's skipped Fresnel term is NaN in
+        # the reference, so that material is compared where the reference is finite only
+        fin = np.isfinite(want_brdf).all(axis=1)
+        report(f'Disney.brdf [fast]: {int((~fin).sum())} rows where the reference itself is not finite (ior = 0 material: {int((~fin & ior0).sum())})')
+        assert (~fin & ~ior0).sum() == 0
+        close(got_brdf[fin & ~chaotic], want_brdf[fin & ~chaotic], 3e-5, 'Disney.brdf', 2e-6)
+        # transmission materials at roughness 0.08: GTR2's t = 1 + (a2 - 1) cos^2 cancels to ~a2 = 4e-5 in f32
+        close(got_brdf[fin & chaotic], want_brdf[fin & chaotic], 5e-3, 'Disney.brdf (transmission materials)', 2e-5)
+    # ---- bounce: the lobe is a discrete decision on the re-used sample (Choice): dead / alive pattern first
+    dead_g, dead_w = (got_b[:, :3] == 0).all(axis=1), (want_b[:, :3] == 0).all(axis=1)
+    nan_w = np.isnan(want_b).any(axis=1)
+    mism = (dead_g != dead_w) & ~nan_w
+    report(f'Disney.bounce [{mode}]: {int(mism.sum())} of {len(mism)} samples die in one implementation only; NaN rows in the reference {int(nan_w.sum())}')
+    assert mism.sum() <= pick(mode, 1, 2)
+    live = ~mism & ~nan_w & ~dead_w
+    # the outgoing direction tells which lobe was sampled: a different Choice branch gives an O(1) different direction
+    dirs_err = np.abs(got_b[live, :3] - want_b[live, :3]).max(axis=1)
+    leaf = np.array([_branch_leaf(b) for b in gold[f'{tag}/disney/branch']])
+    report(f'Disney.bounce [{mode}]: live rows per Choice leaf ' + ', '.join(f'{k} {int((leaf[live] == k).sum())}' for k in sorted(set(leaf))))
+    for k in ('diffuse', 'spec', 'trans_reflect', 'trans_refract'):
+        assert (leaf[live] == k).sum() >= 3, f'no live vectors for the {k} leaf'
+    # the clearcoat leaf: clearcoatAlpha = lerp(gloss, 0.1, 0.001) < 1 always, so the reference's sample_GTR1 is
+    # sqrt(negative) = NaN, dot_or_zero(NaN) = 0 and the `cosoh > 0` guard kills the path (disney.py:136-158): every
+    # coat vector is dead in the reference, and must be dead here (v_max_f32(0, NaN) = 0 like Taichi's max)
+    coat = leaf == 'coat'
+    assert coat.sum() >= 20 and dead_w[coat].all() and dead_g[coat].all() and (got_b[coat] == 0).all()
+    plain = live & ~chaotic
+    assert (np.abs(got_b[plain, :3] - want_b[plain, :3]).max(axis=1) <= pick(mode, 2e-4, 1e-3)).all(), \
+        f'Disney.bounce: an outgoing direction is off by {dirs_err.max():.2e}: a different lobe was sampled'
+    err = np.abs(got_b - want_b) / (np.abs(want_b) + 1e-3)
+    per_row = np.where(np.isnan(err), 0.0, err).max(axis=1)
+    bound = pick(mode, 2e-4, 1e-3)
+    report(f'Disney.bounce [{mode}]: worst relative error, plain materials {per_row[plain].max():.2e} (bound {bound:g}), '
+           f'transmission materials {per_row[live & chaotic].max():.2e} (bound 5e-2)')
+    assert (per_row[plain] <= bound).all(), f'Disney.bounce: worst relative error {per_row[plain].max():.2e} (bound {bound:g})'
+    # transmission materials at roughness 0.08: three digits are gone in f32; same branch, looser values
+    assert (per_row[live & chaotic] <= 5e-2).all(), f'Disney.bounce (transmission): worst {per_row[live & chaotic].max():.2e}'
+    # every transmission / refraction vector took the reference's branch: direction within 2e-2 of the reference's
+    tr = live & np.isin(leaf, ['trans_reflect', 'trans_refract'])
+    assert tr.sum() >= 6 and (np.abs(got_b[tr, :3] - want_b[tr, :3]).max(axis=1) <= 2e-2).all()
+
+
+def test_power_heuristic_and_hashes(gold, dev):
+    mode, c = dev
+    tag = 'f32'
+    close(c.unit_eval('power_heuristic', gold[f'{tag}/power/in'])[:, 0], gold[f'{tag}/power/out'], pick(mode, 1e-6, 1e-5), 'power_heuristic', 1e-12)
+    xs = gold['int/wanghash/in'].astype(np.int64)
+    got = c.unit_eval('wanghash', xs.astype(np.int32))[:, 0]
+    assert np.array_equal(got.astype(np.int64), gold['int/wanghash/out']), 'wanghash'
+    ij = gold['int/wanghash2/in']
+    got = c.unit_eval('wanghash2', ij.astype(np.int32))[:, 0]
+    assert np.array_equal(got.astype(np.int64), gold['int/wanghash2/out']), 'wanghash2'
+    assert (gold['int/wanghash2/out'] < 0).any()          # the floor-mod of sobol.py:123 matters
+
+
+def test_unit_eval_refuses_wrong_shapes(fresh):
+    import ctypes as C
+    from ptina_amd.things import init_things
+    from ptina_amd.common import ctx
+    init_things()
+    a = np.zeros((4, 3), np.float32)
+    with pytest.raises(RuntimeError, match='input and'):
+        ctx().call('mpt_unit_eval', 0, a.ctypes.data_as(C.c_void_p), 3, a.ctypes.data_as(C.c_void_p), 1, 4)
+    with pytest.raises(RuntimeError, match='unit kind'):
+        ctx().call('mpt_unit_eval', 99, a.ctypes.data_as(C.c_void_p), 3, a.ctypes.data_as(C.c_void_p), 1, 4)
