@@ -3,9 +3,10 @@
 bench.py -- Msamples/s of the path-trace hot path on the 978-triangle cornell scene,
 512x512, 32 spp (BASELINE.json configs[1]), on N MI355X of one node.
 
-One "step" = the timed region of the reference's exams/benchmark.py:29-36: 32 x PathEngine.render()
-(each = Sobol update + one sample per pixel) followed by FilmTable.get_image() -- the resolve AND
-the read-back of the 4 MiB image into a host array.  The scene, BVH, Sobol tables and film are
+One "step" = the timed region of the reference's exams/benchmark.py:29-36: PathEngine.render(32) -- the
+reference's 32 x render(), each = Sobol update + one sample per pixel, enqueued by ONE call and fused into one
+launch (result-identical to 32 calls: tests/test_parity_gpu.py::test_batching_does_not_change_the_film) --
+followed by FilmTable.get_image(): the resolve AND the read-back of the 4 MiB image into a host array.  The scene, BVH, Sobol tables and film are
 resident in HBM before the timed region starts.  `value` is that D2H-inclusive rate (the metric
 SURVEY.md 8d defines); `value_resolve_only` (stops at the resolved image in HBM, consecutive steps
 overlapped) is reported beside it.
@@ -14,10 +15,14 @@ N > 1, one rank per GPU: launched by torch.distributed.run (RANK / LOCAL_RANK / 
 environment) or -- when WORLD_SIZE is not set -- by this script itself, which then only spawns N
 fresh copies of itself (ptina_amd.dist.launch_ranks) before anything has touched the GPU and relays
 rank 0's line.  The film columns are dealt out in stripes of 16, rank r renders stripes r, r+N, ...
-of the replicated scene and the stripes are gathered to rank 0 with grouped ncclSend/ncclRecv (RCCL
-over xGMI) before the resolve: strong scaling of the same 512x512x32 job.  No PyTorch in the
-process; the RCCL unique id travels through a file, barriers and the max-over-ranks are RCCL
-all-reduces.
+of the replicated scene and the stripes are gathered to rank 0 -- each rank's share packed into ONE
+message, one ncclSend per rank / N - 1 ncclRecv on the root (RCCL over xGMI), scattered into the film in
+front of the resolve: strong scaling of the same 512x512x32 job (`value`, `config`: unchanged by N).
+After the headline steps an N > 1 run also times BASELINE configs[2]'s film -- s978 2048x2048, 32 spp per
+step, striped and gathered the same way -- and adds `c3` to the line: the configuration on which
+near-linear scaling is reachable (16 x the work per launch; the headline film is 3.6 ms of work for ONE GPU).
+No PyTorch in the process; the RCCL unique id travels through a file, barriers and the max-over-ranks are
+RCCL all-reduces.
 
 Roofline (N = 1): the dominant kernel is bound by VALU issue at partial lane occupancy, not by HBM
 and not by MFMA -- its scene lives in LDS.  The `roofline` object therefore prices VALU lane-operations
@@ -50,6 +55,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_SIMD = 256 * 4             # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 SIMD_LANES = 32              # a wave64 VALU instruction issues over 2 cycles on a SIMD-32
 PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')
+C3_N = 2048                  # BASELINE.json configs[2]: 2048 x 2048 film (32 spp per step here, 256 stated: 8 steps)
+# the launch model of DESIGN.md section 6, measured on ONE MI355X (tools/gpu_diag.py shares_sync): a launch of 1/N of
+# a film costs a / N + b -- b = the end-of-launch drain, independent of N
+MODEL = {'headline': {'a_ms': 3.0, 'b_ms': 0.5}, 'c3': {'a_ms': 47.2, 'b_ms': 0.5},
+         'from': 'one-GPU share measurements, DESIGN.md section 6 (round 2)'}
 
 PMC_PASSES = [
     ['SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES',
@@ -75,6 +85,9 @@ def collect_pmc(argv_tail, budget_s=150):
     out = {}
     work = tempfile.mkdtemp(prefix='miptina_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
+    # the profiler's preloaded tool initialises HIP before libmiptina can ask for more hardware queues: ask here, so
+    # that the counters come from the queue configuration the timed run uses (option "hw_queues")
+    env.setdefault('GPU_MAX_HW_QUEUES', '12')
     try:
         for i, counters in enumerate(PMC_PASSES):
             d = os.path.join(work, f'pass{i}')
@@ -253,38 +266,88 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='do not run the rocprofv3 --pmc passes (counters from profiles/)')
     ap.add_argument('--force-comm', action='store_true', help='create the RCCL communicator even for one rank')
+    ap.add_argument('--c3-steps', type=int, default=3, help='N > 1: timed steps of the 2048x2048x32 leg (0 = skip it)')
+    ap.add_argument('--stub', action='store_true',
+                    help='tests only: a stand-in renderer that touches no GPU (checks the launcher and the line format)')
     ap.add_argument('--role', default='main', choices=['main', 'pmc-child'],
                     help='pmc-child: the same render steps with nothing else around them (run under rocprofv3)')
     return ap.parse_args(argv)
 
 
+class _Stub:
+    '''TESTS ONLY (--stub): stands in for the engine / context / film / communicator with objects that touch no GPU
+    and no RCCL, so that the rank launcher and the shape of the result line can be checked on a CPU box
+    (tests/test_dist_cpu.py).  A "render" sleeps a / N + b of the launch model; nothing is computed.'''
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.nx, self.lib = rank, world, NX, self
+        self.opts = {'nranks': world, 'last_div': 1, 'last_kernel': 1, 'clock_khz': 2400000, 'hw_queues': 0}
+
+    # context
+    def mpt_device_count(self): return self.world
+    def call(self, name, *a): pass
+    def set_option(self, k, v): pass
+    def get_option(self, k): return self.opts.get(k, 0)
+    def kernel_time(self): return 1.0, 1
+
+    def counters(self):
+        return dict(samples=NX * NY * SPP, rays=1, n_box=1, n_tri=1, n_shade=1, n_draws=1, bounces=1, n_node=1,
+                    it_node=1, it_leaf=1, it_shade=1, it_new=1)
+
+    # engine
+    def render(self, n=1):
+        m = MODEL['c3' if self.nx == C3_N else 'headline']
+        time.sleep((m['a_ms'] / self.world + m['b_ms']) * 1e-5 * n / SPP)      # 1 % of the modelled time
+
+    # film
+    def get_image(self, id=0):
+        import numpy as np
+        return np.ones((self.nx, self.nx, 4), np.float32)
+
+    def clear(self, id=0): pass
+    def set_size(self, nx, ny): self.nx = nx
+
+    # communicator
+    def set_stripes(self, nx): pass
+    def gather(self, id=0, root=0): pass
+    def barrier(self): pass
+    def allreduce_max(self, v): return v
+    def close(self): pass
+
+
 def run_rank(args, rank, world, pmc, pmc_source):
     import numpy as np  # noqa: F401
-    from ptina_amd import scenes
-    from ptina_amd.common import ctx
-    from ptina_amd.things import FilmTable
-    from ptina_amd.dist import RcclFilm
-    from helpers import setup_engine
+    if args.stub:
+        eng = c = film = _Stub(rank, world)
+        comm = c if (world > 1 or args.force_comm) else None
+        scene = None
+    else:
+        from ptina_amd import scenes, _lib
+        from ptina_amd.common import ctx
+        from ptina_amd.things import FilmTable
+        from ptina_amd.dist import RcclFilm
+        from helpers import setup_engine
 
-    scene = scenes.get_scene(args.scene)
-    eng = setup_engine(scene, NX, NY, mode=args.mode)
-    c = ctx()
-    if c.lib.mpt_device_count() < world:
-        raise SystemExit(f'--gpus {world} but only {c.lib.mpt_device_count()} GPU(s) visible')
+        scene = scenes.get_scene(args.scene)
+        # N > 1 also renders BASELINE configs[2]'s 2048 x 2048 film: capacity at init_things, as in the reference
+        eng = setup_engine(scene, NX, NY, mode=args.mode, max_filmsize=(C3_N * C3_N if world > 1 else 2**21))
+        c = ctx()
+        if c.lib.mpt_device_count() < world and not _lib.devices_isolated():
+            raise SystemExit(f'--gpus {world} but only {c.lib.mpt_device_count()} GPU(s) visible')
+        comm = RcclFilm(rank, world) if (world > 1 or args.force_comm) else None
+        film = FilmTable()
     if args.chunk >= 0:
         c.set_option('chunk', args.chunk)
     c.set_option('batch', SPP)
-    comm = RcclFilm(rank, world) if (world > 1 or args.force_comm) else None
     if comm:
         comm.set_stripes(NX)                  # every world-th stripe of 16 columns: even load
     n_gpus = c.get_option('nranks') if comm else 1
     if n_gpus != world:
         raise SystemExit(f'communicator has {n_gpus} ranks, expected {world}')
-    film = FilmTable()
 
     def step(d2h):
         '''exams/benchmark.py:29-36: 32 x render() then get_image()'''
-        eng.render(SPP)                       # 32 x (Sobol update + 1 spp), one fused launch
+        eng.render(SPP)                       # render(32) = 32 x (Sobol update + 1 spp), one fused launch
         if comm:
             c.call('mpt_flush')
             comm.gather(0, 0)
@@ -348,6 +411,33 @@ def run_rank(args, rank, world, pmc, pmc_source):
     if comm:
         dt_resolve = comm.allreduce_max(dt_resolve)
 
+    # ---- N > 1: BASELINE configs[2]'s film (2048 x 2048, 32 spp per step), striped and gathered the same way
+    c3 = None
+    if comm and world > 1 and args.c3_steps > 0:
+        film.set_size(C3_N, C3_N)             # (back to one slab: the stripes are dealt again for this width)
+        comm.set_stripes(C3_N)
+        film.clear()
+        step(True)                            # untimed: sample slabs, gather buffers and the host array are allocated here
+        barrier()
+        c.kernel_time()
+        t3 = time.perf_counter()
+        for _ in range(args.c3_steps):
+            img3 = step(True)
+        barrier()
+        dt3 = comm.allreduce_max(time.perf_counter() - t3)
+        kms3, nl3 = c.kernel_time()
+        if rank == 0:
+            assert img3 is not None and img3.shape == (C3_N, C3_N, 4) and float(img3[..., 3].min()) == 1.0
+            m = MODEL['c3']
+            c3 = {'msamples_s': round(C3_N * C3_N * SPP * args.c3_steps / dt3 / 1e6, 3),
+                  'ms_per_step': round(dt3 / args.c3_steps * 1e3, 4), 'n_gpus': n_gpus, 'steps': args.c3_steps,
+                  'workload': f'{args.scene} {C3_N}x{C3_N}, {SPP} spp per step (BASELINE configs[2] states 256 spp = 8 such steps), '
+                              'stripes of 16 columns per rank, one-message gather, resolve + D2H of the 64 MiB image',
+                  'render_kernel_ms_rank0': round(kms3 / max(nl3, 1), 4),
+                  'model_ms_per_step': round(m['a_ms'] / n_gpus + m['b_ms'], 3),
+                  'model': f"a / N + b with a = {m['a_ms']} ms, b = {m['b_ms']} ms per launch ({MODEL['from']}); "
+                           'the gather and the 64 MiB read-back are not in the model'}
+
     if rank == 0:
         assert img is not None and img.shape == (NX, NY, 4) and float(img[..., 3].min()) == 1.0
         total = NX * NY * SPP * args.steps
@@ -366,10 +456,10 @@ def run_rank(args, rank, world, pmc, pmc_source):
                                         clock_hz, concurrent)
         samples_per_launch = cnt['samples'] / W
         out = {
-            'metric': 'Msamples/sec (pixels x spp / s), 512x512x32spp cornell-monkey (978 tri)',
+            'metric': ('STUB, NOT A MEASUREMENT: ' if args.stub else '') + 'Msamples/sec (pixels x spp / s), 512x512x32spp cornell-monkey (978 tri)',
             'value': round(total / dt / 1e6, 3), 'unit': 'Msamples/s', 'n_gpus': n_gpus, 'steps': args.steps,
             'warmup': W, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
-            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'STUB (no GPU, tests only)' if args.stub else 'synthetic',
             'config': {'workload': f'{args.scene}: 978-tri synthetic cornell + bumpy sphere, {NX}x{NY}, {SPP} spp, '
                                    'unidirectional MIS path tracer, depth<=5; step = 32 x render() + get_image() '
                                    '(resolve + D2H), exams/benchmark.py:29-36', 'film': [NX, NY], 'spp': SPP,
@@ -394,8 +484,18 @@ def run_rank(args, rank, world, pmc, pmc_source):
             'counters_per_sample': {k: round(v / max(cnt['samples'], 1), 3) for k, v in cnt.items() if k != 'samples'},
             'mrays_per_s': round(cnt['rays'] / W * concurrent / avg_kernel_s / 1e6, 1),
             'samples_per_launch': int(samples_per_launch),
+            # hardware queues the HIP runtime multiplexes this process's streams onto: the library asks for 12 before
+            # the runtime starts; under rocprofv3 --pmc the GPU is initialised first and the request has no effect
+            'hw_queues': c.get_option('hw_queues') or None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if n_gpus > 1:
+            m = MODEL['headline']
+            out['model_ms_per_step'] = round(m['a_ms'] / n_gpus + m['b_ms'], 3)
+            out['model'] = f"a / N + b with a = {m['a_ms']} ms, b = {m['b_ms']} ms per launch ({MODEL['from']}), before the gather"
+        if c3 is not None:
+            out['c3'] = c3
+        if world == 1 and not args.no_cpu_baseline and not args.stub:
+            from ptina_amd import scenes
             out['cpu_baseline'] = cpu_baseline(scene, scenes.BENCH_CAMERA)
         print(json.dumps(out), flush=True)
     if comm:
@@ -418,7 +518,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     pmc, pmc_source = None, 'not collected'
-    if args.role == 'main' and world == 1 and args.mode == 'fast' and not args.no_pmc \
+    if args.role == 'main' and world == 1 and args.mode == 'fast' and not args.no_pmc and not args.stub \
             and os.environ.get('MIPTINA_BENCH_PMC', '1') != '0':
         # before anything in this process touches the GPU
         tail = ['--steps', '3', '--warmup', '1', '--scene', args.scene, '--mode', args.mode, '--no-cpu-baseline']

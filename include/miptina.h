@@ -89,7 +89,9 @@ void mpt_destroy(mpt_ctx *ctx);
  * read-only: "tree_depth", "fast_depth", "wide_nodes", "wide_depth", "wide_ratio_permille", "pending", "last_kernel" (0 = gather over
  * the binary tree, 1 = LDS-resident, 2 = gather over 4-wide nodes), "num_cus",
  * "cur_div", "cur_depth" (the ring the last launch belonged to: G launches of 1/G of the CUs, that many batches in
- * flight), "last_div" (what the last launch really took: 1 when it found the ring idle, else cur_div) */
+ * flight), "last_div" (what the last launch really took: 1 when it found the ring idle, else cur_div), "hw_queues"
+ * (GPU_MAX_HW_QUEUES as the HIP runtime was asked for it -- the library requests 12 at load time unless the variable is
+ * set; NEGATIVE when that request came after a preloaded profiler tool may already have initialised HIP) */
 int mpt_set_option(mpt_ctx *ctx, const char *key, int value);
 int mpt_get_option(mpt_ctx *ctx, const char *key, int *value);
 
@@ -208,7 +210,19 @@ int mpt_unit_eval(mpt_ctx *ctx, int kind, const void *in, int in_cols, void *out
 /* multi-GPU film gather over RCCL (one process per GPU).  uid = ncclUniqueId bytes (128). */
 int mpt_comm_unique_id(char uid[128]);
 int mpt_comm_init(mpt_ctx *ctx, const char uid[128], int nranks, int rank);
+/* The split of the film between R ranks as a pure function (no context, no GPU): the float4 ranges (film index
+ * x*ny + y) rank r owns, in ascending x = the order they are packed into its one message of the gather.
+ * stripe_w == 0: one slab [r*nx/R, (r+1)*nx/R); stripe_w > 0: stripes r, r+R, ... of stripe_w columns.  Writes the
+ * first `cap` pieces (offsets / counts in float4 elements; either may be NULL) and returns the number of pieces,
+ * -1 for arguments that name no split. */
+int mpt_comm_plan(int nx, int ny, int stripe_w, int r, int R, int64_t *offsets, int64_t *counts, int cap);
+/* One message per peer: a share of several stripes is packed side by side, sent as one range and scattered into
+ * the root's film by one kernel in front of the resolve; a one-range share travels film to film. */
 int mpt_comm_gather_film(mpt_ctx *ctx, int pass, int root);
+/* Test door, one GPU, no communicator: the pack and scatter halves of the gather for rank `as_rank` of `nranks`
+ * sending to `root`, with a device copy standing in for the message.  film_in: the sender's film [nx*ny][4];
+ * film_out: the root's film, updated in place.  Uses the context's film size and stripe width. */
+int mpt_comm_selftest(mpt_ctx *ctx, int as_rank, int nranks, int root, const float *film_in, float *film_out);
 int mpt_comm_barrier(mpt_ctx *ctx);
 int mpt_comm_allreduce_max(mpt_ctx *ctx, double *value);
 int mpt_comm_destroy(mpt_ctx *ctx);

@@ -90,7 +90,9 @@ SIGNATURES = {
     'mpt_unit_eval': (_i, [_vp, _i, _vp, _i, _vp, _i, _i]),
     'mpt_comm_unique_id': (_i, [C.c_char_p]),
     'mpt_comm_init': (_i, [_vp, C.c_char_p, _i, _i]),
+    'mpt_comm_plan': (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i]),
     'mpt_comm_gather_film': (_i, [_vp, _i, _i]),
+    'mpt_comm_selftest': (_i, [_vp, _i, _i, _i, _fp, _fp]),
     'mpt_comm_barrier': (_i, [_vp]),
     'mpt_comm_allreduce_max': (_i, [_vp, C.POINTER(C.c_double)]),
     'mpt_comm_destroy': (_i, [_vp]),
@@ -172,6 +174,24 @@ def iptr(a):
     return a.ctypes.data_as(_ip)
 
 
+def devices_isolated():
+    '''True when the launcher shows each rank its own GPU(s) only (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES set per task, SLURM --gpus-per-task): LOCAL_RANK then does not index the visible devices'''
+    return any(os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
+
+
+def rank_device(ndev):
+    '''the device of this rank: MIPTINA_DEVICE if given; LOCAL_RANK when the node's GPUs are all visible (a rank
+    whose LOCAL_RANK has no device then fails in mpt_create -- "device out of range" -- instead of piling onto
+    somebody else's GPU); device 0 when the launcher isolated ONE GPU per rank'''
+    if os.environ.get('MIPTINA_DEVICE'):
+        return int(os.environ['MIPTINA_DEVICE'])
+    lr = int(os.environ.get('LOCAL_RANK', '0'))
+    if ndev == 1 and lr > 0 and devices_isolated():
+        return 0
+    return lr
+
+
 class Context:
     '''one device context = the reference's set of singletons (things.py:20-28)'''
 
@@ -183,9 +203,7 @@ class Context:
             setattr(c, k, int(v))
         self.caps = c
         if device is None:
-            # one rank per GPU: a rank whose LOCAL_RANK has no device fails in mpt_create ("device out of
-            # range") instead of piling onto somebody else's GPU
-            device = int(os.environ.get('MIPTINA_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+            device = rank_device(lib.mpt_device_count())
         self.device = device
         self.lib = lib
         h = lib.mpt_create(C.byref(c), device)

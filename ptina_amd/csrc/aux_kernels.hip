@@ -3,6 +3,7 @@
 // float4 records (dwordx4 per lane, consecutive lanes on consecutive addresses).
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "mpt_types.h"
 #include "tri_records.h"
 
@@ -158,6 +159,25 @@ MPT_KERNEL_API hipError_t mpt_launch_export(const MptVec4 *film, float *out, int
     if (n == 0) return hipSuccess;
     int grid = (int)((n + 255) / 256);
     hipLaunchKernelGGL(export_kernel, dim3(grid), dim3(256), 0, stream, film, out, nx, ny);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- film gather: pack / unpack by the comm plan
+// A rank's share of a striped film is several column ranges (mpt_comm_plan); it travels as ONE contiguous
+// message: copy_pieces packs the ranges side by side before the send, and on the root scatters every peer's
+// received message back into the film -- the plan's piece table drives both (blockIdx.y = piece).
+__global__ __launch_bounds__(256) void copy_pieces_kernel(const MptVec4 *__restrict__ src, MptVec4 *__restrict__ dst,
+                                                          const MptPiece *__restrict__ tab) {
+    const MptPiece pc = tab[blockIdx.y];
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < pc.count; t += (long long)gridDim.x * 256)
+        dst[pc.dst + t] = src[pc.src + t];
+}
+
+MPT_KERNEL_API hipError_t mpt_launch_copy_pieces(const MptVec4 *src, MptVec4 *dst, const MptPiece *tab, int npieces,
+                                             long long max_count, hipStream_t stream) {
+    if (npieces <= 0 || max_count <= 0) return hipSuccess;
+    const int gx = (int)std::min<long long>((max_count + 255) / 256, 1024);
+    hipLaunchKernelGGL(copy_pieces_kernel, dim3(gx, npieces), dim3(256), 0, stream, src, dst, tab);
     return hipGetLastError();
 }
 

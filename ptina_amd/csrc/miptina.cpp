@@ -17,7 +17,24 @@
 // request has no effect and streams fold onto 4 hardware queues: launches of a multi-GPU share then overlap
 // less (G = 4 is slower than G = 1 there), results do not change.  Export GPU_MAX_HW_QUEUES
 // yourself in such a process.
-__attribute__((constructor)) static void mpt_want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+// Where the request comes too late it is SAID (stderr, once) and option "hw_queues" reads negative; bench.py hands
+// the variable to its rocprofv3 passes itself, so that counters and timings come from the same queue configuration.
+static int g_hwq = 0;            // GPU_MAX_HW_QUEUES after the constructor (0: unparsable)
+static bool g_hwq_late = false;  // set here while a preloaded profiler tool may already have initialised HIP
+__attribute__((constructor)) static void mpt_want_hw_queues() {
+    if (!getenv("GPU_MAX_HW_QUEUES")) {
+        setenv("GPU_MAX_HW_QUEUES", "12", 0);
+        const char *pre = getenv("LD_PRELOAD");
+        if ((pre && strstr(pre, "rocprof")) || getenv("ROCP_TOOL_LIBRARIES")) {
+            g_hwq_late = true;
+            fprintf(stderr, "libmiptina: GPU_MAX_HW_QUEUES=12 requested after a preloaded profiler tool may have initialised HIP: "
+                            "streams may fold onto the default 4 hardware queues (results unchanged; export the variable "
+                            "before starting the profiler)\n");
+        }
+    }
+    const char *v = getenv("GPU_MAX_HW_QUEUES");
+    g_hwq = v ? atoi(v) : 0;
+}
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -181,6 +198,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     for (int k = 0; k < MPT_MAX_PIPE; k++) hipFree(c->stack_spill2[k]);
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
+    hipFree(c->gather_buf); hipFree(c->d_pieces);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
     if (c->h_watchdog) hipHostFree(c->h_watchdog);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -332,6 +350,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "rank") *value = c->rank;
     else if (k == "device") *value = c->device;
     else if (k == "clock_khz") *value = c->clock_khz;
+    else if (k == "hw_queues") *value = g_hwq_late ? -g_hwq : g_hwq;
     else return fail("unknown option '%s'", k.c_str());
     return 0;
 }

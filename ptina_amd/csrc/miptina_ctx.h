@@ -37,6 +37,8 @@ MPT_KERNEL_API hipError_t mpt_launch_transpose_nodes(const MptVec4 *in, MptVec4 
 MPT_KERNEL_API hipError_t mpt_launch_probe(double *out, int threads, size_t lds_bytes, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_unit_eval_fast(int kind, const float *in, int in_cols, float *out, int out_cols, int n, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_unit_eval_strict(int kind, const float *in, int in_cols, float *out, int out_cols, int n, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_copy_pieces(const MptVec4 *src, MptVec4 *dst, const MptPiece *tab, int npieces,
+                                             long long max_count, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_export(const MptVec4 *film, float *out, int nx, int ny, hipStream_t);
 
 // on-GPU LBVH build (lbvh_build.hip)
@@ -188,6 +190,11 @@ struct mpt_ctx {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     double *d_scratch = nullptr;
+    // film gather of a striped split (comm.cpp): the share packed into one message per peer
+    MptVec4 *gather_buf = nullptr; size_t gather_cap = 0;   // sender: its packed share; root: every peer's, back to back
+    MptPiece *d_pieces = nullptr; size_t pieces_cap = 0;     // the plan's piece table on the device
+    int plan_key[6] = { -1, -1, -1, -1, -1, -1 };            // (nx, ny, stripe_w, R, rank, root) the table was made for
+    int plan_npieces = 0; long long plan_max_count = 0;
 };
 
 // entry checks of the API calls (miptina.cpp)

@@ -60,6 +60,9 @@ struct MptLight {              // light/__init__.py:14-18
     MptVec4 ax0, ax1, ax2;     // rows of the 3x3 axes matrix
 };
 
+// one contiguous float4 range of the film gather's pack / unpack (comm.cpp): count elements from src to dst
+struct MptPiece { long long src, dst, count; };
+
 struct MptImage { int32_t nx, ny, base, pad; };   // image.py:14-16
 
 // LDS-resident kernel: bytes from one node record to the next in LDS.  72, not 64: a ds_read_b64 is served in two

@@ -9,11 +9,11 @@ Film index is x*ny + y (reference filmtable.py:38): the columns [x0, x1) of a sl
 contiguous float4 range, and because pixel hashes use global (i, j) and every rank advances the
 same Sobol index, the tiled image is bit-identical to the single-GPU image.
 
-Two transports:
-  * 'rccl'  : mpt_comm_* in libmiptina.so -- grouped ncclSend/ncclRecv straight between film
-              buffers over xGMI (the product path);
-  * 'torch' : any initialised torch.distributed group on host arrays (gloo on CPU; used by the
-              world_size-2 CPU tests, where the per-rank renderer is the oracle).
+Transport: mpt_comm_* in libmiptina.so -- one ncclSend per rank / R - 1 ncclRecv on the root, over
+xGMI: a share of several stripes is packed side by side on the device, travels as one message and is
+scattered into the root's film by one kernel.  Which float4 ranges of the film a rank owns, and in which
+order they are packed, is the pure function mpt_comm_plan (comm_plan() below; no GPU needed), which the
+world_size-2 CPU tests drive over gloo with the oracle as the per-rank renderer (tests/dist_helpers.py).
 '''
 
 import os
@@ -34,6 +34,22 @@ def stripe_columns(nx, world, rank, width=STRIPE):
     '''columns of `rank` when the film is dealt out in stripes (mpt_set_stripes(width, rank, world))'''
     x = np.arange(nx)
     return x[(x // width) % world == rank]
+
+
+def comm_plan(nx, ny, stripe_w, rank, world):
+    '''libmiptina's own split (mpt_comm_plan, a pure function: no context, no GPU): the (offset, count) float4
+    ranges of the film -- index x*ny + y -- that `rank` of `world` owns, in the order they are packed into its one
+    message of the gather.  stripe_w = 0: one slab; > 0: stripes of that many columns dealt round-robin'''
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load_library()
+    n = lib.mpt_comm_plan(int(nx), int(ny), int(stripe_w), int(rank), int(world), None, None, 0)
+    if n < 0:
+        raise ValueError(f'no such split: nx={nx} ny={ny} stripe_w={stripe_w} rank={rank} world={world}')
+    off = (C.c_int64 * max(n, 1))()
+    cnt = (C.c_int64 * max(n, 1))()
+    lib.mpt_comm_plan(int(nx), int(ny), int(stripe_w), int(rank), int(world), off, cnt, n)
+    return [(int(off[i]), int(cnt[i])) for i in range(n)]
 
 
 def env_rank():
@@ -215,27 +231,3 @@ class RcclFilm:
 
     def close(self):
         self.ctx.call('mpt_comm_destroy')
-
-
-def gather_film_torch(film_raw, nx, ny, rank, world, root=0, stripe=None):
-    '''host-array gather through torch.distributed: film_raw is this rank's [nx*ny, 4] raw
-    film of which only its share (slab, or stripes of `stripe` columns) is meaningful; returns the
-    assembled film on root'''
-    import torch
-    import torch.distributed as dist
-    if stripe:
-        cols = [stripe_columns(nx, world, r, stripe) for r in range(world)]
-    else:
-        cols = [np.arange(*slab_bounds(nx, world, r)) for r in range(world)]
-    most = max(len(c) for c in cols)               # gloo's gather wants equal shapes: pad
-    mine = torch.zeros((most, ny, 4), dtype=torch.float32)
-    mine[:len(cols[rank])] = torch.from_numpy(np.ascontiguousarray(film_raw.reshape(nx, ny, 4)[cols[rank]]))
-    if rank == root:
-        bufs = [torch.empty((most, ny, 4), dtype=torch.float32) for _ in cols]
-        dist.gather(mine, bufs, dst=root)
-        out = np.zeros((nx, ny, 4), np.float32)
-        for c, b in zip(cols, bufs):
-            out[c] = b.numpy()[:len(c)]
-        return out.reshape(nx * ny, 4)
-    dist.gather(mine, None, dst=root)
-    return None

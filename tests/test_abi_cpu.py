@@ -164,3 +164,20 @@ def test_unit_kind_table_mirrors_the_header_enum():
     for line in src.splitlines():
         if re.search(r'MPT_UNIT_[A-Z0-9_]+ = \d+,', line):
             assert re.search(r'\.py:\d+', line), f'no reference citation: {line.strip()}'
+
+
+def test_rank_device_selection(monkeypatch):
+    '''one rank per GPU: LOCAL_RANK indexes the node's devices, except under launchers that isolate one GPU per
+    rank (then every rank sees a single device 0); MIPTINA_DEVICE overrides (round-2 ADVICE)'''
+    from ptina_amd import _lib
+    for k in ('MIPTINA_DEVICE', 'LOCAL_RANK', 'HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(k, raising=False)
+    assert _lib.rank_device(8) == 0
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    assert _lib.rank_device(8) == 3
+    assert _lib.rank_device(1) == 3              # a one-GPU box: mpt_create refuses ("device out of range")
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '3')
+    assert _lib.rank_device(1) == 0              # isolated: the rank's own GPU is its device 0
+    assert _lib.rank_device(8) == 3
+    monkeypatch.setenv('MIPTINA_DEVICE', '5')
+    assert _lib.rank_device(1) == 5

@@ -34,6 +34,70 @@ def test_stripe_columns_partition():
                 assert max(map(len, cols)) - min(map(len, cols)) <= 16
 
 
+def test_comm_plan_is_the_split_the_renderer_uses():
+    '''mpt_comm_plan (pure C function of libmiptina: no context, no GPU) against the Python statement of the split
+    (dist.slab_bounds / dist.stripe_columns, which the stripe / slab render tests hold the kernels to), for
+    R in {1, 2, 3, 8}, ragged widths and both split kinds; the ranges partition the film; packed order is ascending x'''
+    from ptina_amd.dist import comm_plan, slab_bounds, stripe_columns
+    for ny in (1, 5, 37):
+        for nx in (1, 7, 16, 50, 70, 512, 2048, 100):
+            for world in (1, 2, 3, 8):
+                for stripe in (0, 16, 32):
+                    owned = np.zeros(nx * ny, np.int32)
+                    for r in range(world):
+                        plan = comm_plan(nx, ny, stripe, r, world)
+                        cols = np.arange(*slab_bounds(nx, world, r)) if stripe == 0 else stripe_columns(nx, world, r, stripe)
+                        want = np.zeros(nx * ny, bool)
+                        want.reshape(nx, ny)[cols] = True
+                        got = np.zeros(nx * ny, bool)
+                        last = -1
+                        for o, n in plan:
+                            assert n > 0 and o > last and o % ny == 0 and n % ny == 0
+                            got[o:o + n] = True
+                            last = o + n - 1
+                        assert np.array_equal(got, want), (nx, ny, world, stripe, r)
+                        assert len(plan) <= (1 if stripe == 0 else (nx + stripe * world - 1) // (stripe * world))
+                        owned += got
+                    assert np.all(owned == 1)
+    # BASELINE config 3 on 8 GPUs: 16 stripes of 16 columns per rank = 16 pieces, one message
+    plan = comm_plan(2048, 2048, 16, 3, 8)
+    assert len(plan) == 16 and all(n == 16 * 2048 for _, n in plan) and plan[0][0] == 3 * 16 * 2048
+    with pytest.raises(ValueError):
+        comm_plan(512, 512, 16, 8, 8)
+    with pytest.raises(ValueError):
+        comm_plan(512, 512, -1, 0, 8)
+
+
+def test_packed_gather_reassembles_any_film_in_process():
+    '''the whole gather replayed in numpy for R in {2, 3, 8} (pack by the sender's plan, one message, scatter by the
+    same plan on the root): whatever the root held in the peers' columns is overwritten, its own columns are kept'''
+    from ptina_amd.dist import comm_plan
+    from dist_helpers import pack_share, scatter_share
+    rng = np.random.default_rng(3)
+    for nx, ny, stripe in ((70, 9, 16), (512, 4, 16), (50, 7, 0), (33, 3, 32)):
+        truth = rng.normal(size=(nx * ny, 4)).astype(np.float32)
+        for world in (2, 3, 8):
+            for root in (0, world - 1):
+                plans = [comm_plan(nx, ny, stripe, r, world) for r in range(world)]
+                films = []
+                for r in range(world):            # every rank holds only its share (the rest: garbage)
+                    f = np.full((nx * ny, 4), np.float32(-7.0 - r))
+                    for o, n in plans[r]:
+                        f[o:o + n] = truth[o:o + n]
+                    films.append(f)
+                out = films[root].copy()
+                nmsg = 0
+                for r in range(world):
+                    if r == root or not plans[r]:
+                        continue
+                    msg = pack_share(films[r], plans[r])
+                    assert msg.shape[0] == sum(n for _, n in plans[r])
+                    scatter_share(out, plans[r], msg)
+                    nmsg += 1
+                assert nmsg <= world - 1
+                assert np.array_equal(out, truth), (nx, ny, stripe, world, root)
+
+
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -41,7 +105,8 @@ def _worker(rank, world, port, out):
     import torch.distributed as dist
     import oracle
     from ptina_amd import scenes
-    from ptina_amd.dist import slab_bounds, gather_film_torch
+    from ptina_amd.dist import slab_bounds
+    from dist_helpers import gather_film_torch
     from helpers import setup_oracle
     dist.init_process_group('gloo', rank=rank, world_size=world)
     nx, ny, spp = 30, 20, 2
@@ -186,3 +251,31 @@ def test_bench_self_launch_is_decided_before_any_gpu_call(monkeypatch, tmp_path)
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert 'WORLD_SIZE=4' in str(e.value.code)
+
+
+def test_bench_n_gpu_line_carries_the_config3_leg(tmp_path):
+    '''`bench.py --gpus 2` through its own launcher with the stand-in renderer (--stub: no GPU, no RCCL): rank 0's
+    line keeps the headline metric / config and adds `c3` (BASELINE configs[2]'s 2048 x 2048 film) with the
+    launch-model prediction beside the measured step'''
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MIPTINA_RDZV_DIR'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--stub', '--c3-steps', '2'], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['scaling'] == 'strong'
+    assert '512x512x32spp' in line['metric'] and line['config']['film'] == [512, 512] and line['config']['spp'] == 32
+    assert line['metric'].startswith('STUB') and 'STUB' in line['data']          # never mistaken for a measurement
+    c3 = line['c3']
+    assert c3['n_gpus'] == 2 and c3['steps'] == 2 and '2048x2048' in c3['workload']
+    assert c3['msamples_s'] > 0 and c3['ms_per_step'] > 0
+    assert abs(c3['model_ms_per_step'] - (47.2 / 2 + 0.5)) < 1e-6 and 'a / N + b' in c3['model']
+    assert abs(line['model_ms_per_step'] - (3.0 / 2 + 0.5)) < 1e-6
+    # one GPU: no c3 leg, no model keys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--stub'],
+                       env=env, capture_output=True, text=True, timeout=120)
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and line['n_gpus'] == 1 and 'c3' not in line and 'model_ms_per_step' not in line

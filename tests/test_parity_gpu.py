@@ -1299,6 +1299,7 @@ def test_config3_eight_stripe_shares_reassemble_bit_identically(fresh):
     from ptina_amd.things import FilmTable
     from ptina_amd.common import ctx, reset_all
     from ptina_amd.dist import stripe_columns
+    from ptina_amd import _lib
     n, spp, R = 2048, 32, 8
     scene = scenes.scene_s978()
     eng = _engine(None, scene, n, n, mode='fast', max_filmsize=n * n)
@@ -1314,9 +1315,55 @@ def test_config3_eight_stripe_shares_reassemble_bit_identically(fresh):
         part = FilmTable().get_raw().reshape(n, n, 4)
         cols = stripe_columns(n, R, r)
         assert np.all(part[np.setdiff1d(np.arange(n), cols)] == 0)
-        tiled[cols] = part[cols]
+        if r == 0:
+            tiled[cols] = part[cols]                      # the root's own share is already in its film
+        else:
+            # the gather's device half for this peer: its 16 stripes packed into ONE message by copy_pieces,
+            # the message copied, and scattered into the root's film (mpt_comm_selftest; RCCL itself needs 2 GPUs)
+            flat = np.ascontiguousarray(tiled.reshape(-1, 4))
+            ctx().call('mpt_comm_selftest', r, R, 0, _lib.fptr(np.ascontiguousarray(part.reshape(-1, 4))), _lib.fptr(flat))
+            tiled = flat.reshape(n, n, 4)
     reset_all()
     assert np.array_equal(tiled, full)
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_gather_pack_and_scatter_kernels_follow_the_plan(fresh, world):
+    '''the device half of mpt_comm_gather_film on one GPU (mpt_comm_selftest: pack by the sender's plan, one
+    message, scatter on the root) for R in {2, 3, 8}, a ragged film, striped and slab splits and a root that is not
+    rank 0: every peer's columns arrive, nothing else of the root's film is touched'''
+    from ptina_amd import _lib
+    from ptina_amd.common import ctx
+    from ptina_amd.dist import comm_plan
+    from ptina_amd.things import init_things, FilmTable
+    init_things()
+    rng = np.random.default_rng(world)
+    nx, ny = 102, 37
+    FilmTable().set_size(nx, ny)
+    truth = rng.normal(size=(nx * ny, 4)).astype(np.float32)
+    for stripe in (16, 0, 32):
+        if stripe:
+            ctx().call('mpt_set_stripes', stripe, 0, world)
+        else:
+            ctx().call('mpt_set_slab', 0, nx)            # back to slab mode (stripe_w = 0)
+        for root in (0, world - 1):
+            plans = [comm_plan(nx, ny, stripe, r, world) for r in range(world)]
+            out = np.full((nx * ny, 4), np.float32(-3.0))
+            for o, n in plans[root]:
+                out[o:o + n] = truth[o:o + n]
+            for r in range(world):
+                if r == root:
+                    continue
+                share = np.full((nx * ny, 4), np.float32(-9.0 - r))          # garbage outside the share
+                for o, n in plans[r]:
+                    share[o:o + n] = truth[o:o + n]
+                before = out.copy()
+                ctx().call('mpt_comm_selftest', r, world, root, _lib.fptr(share), _lib.fptr(out))
+                touched = np.zeros(nx * ny, bool)
+                for o, n in plans[r]:
+                    touched[o:o + n] = True
+                assert np.array_equal(out[~touched], before[~touched]), (stripe, root, r)
+            assert np.array_equal(out, truth), (stripe, root)
 
 
 def test_bench_refuses_more_gpus_than_the_box_has(fresh):

@@ -48,22 +48,33 @@ def report(msg):
     _report(msg)
 
 
-def close(got, want, rel, what, abs_=0.0, allow=0):
-    '''|got - want| <= rel |want| + abs_ element-wise; NaN / infinity patterns equal; up to `allow` rows may fail'''
+def close(got, want, rel, what, abs_=0.0, allow=0, slack=None):
+    '''|got - want| <= rel |want| + abs_ (+ slack) element-wise; NaN / infinity patterns equal; up to `allow` rows may
+    fail.  slack: an array like `want` added to the bound -- used with spread() below for ill-conditioned inputs'''
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape, what
     g2, w2 = got.reshape(got.shape[0], -1), want.reshape(want.shape[0], -1)
+    sl = 0.0 if slack is None else np.nan_to_num(np.asarray(slack, np.float64).reshape(w2.shape), nan=0.0, posinf=0.0, neginf=0.0)
     nan_ok = np.isnan(g2) == np.isnan(w2)
     inf = np.isinf(w2)
     inf_ok = np.where(inf, g2 == w2, ~np.isinf(g2))
     fin = ~(np.isnan(w2) | inf | np.isnan(g2) | np.isinf(g2))
     err = np.where(fin, np.abs(g2 - w2), 0.0)
-    bound = rel * np.abs(np.where(fin, w2, 0.0)) + abs_
+    bound = rel * np.abs(np.where(fin, w2, 0.0)) + abs_ + sl
     ratio = np.where(fin, err / np.maximum(bound, 1e-300), 0.0)
     row_bad = (~nan_ok | ~inf_ok | (ratio > 1.0)).any(axis=1)
     worst = float(ratio.max()) if ratio.size else 0.0
     report(f'{what}: worst error {worst:.3f} x the bound (rel {rel:g}, abs {abs_:g}); rows outside {int(row_bad.sum())} of {len(row_bad)} (allowed {allow})')
     assert int(row_bad.sum()) <= allow, f'{what}: {int(row_bad.sum())} rows outside the bound (worst {worst:.2f} x; rel {rel:g}, abs {abs_:g}); first bad rows {np.nonzero(row_bad)[0][:8]}'
+
+
+def spread(gold, key, k=4.0):
+    '''k x |f32 run - f64 run| of the reference's own function on (to 1e-7) the same inputs: how ill-conditioned each
+    output is.  The production build's different rounding (FMA, v_rcp) may move such an output as far as the
+    reference's own precision does -- e.g. GTR2's t = 1 + (a^2 - 1) cos^2 at alpha = 0.001 (the mirror material: the
+    reference's two runs differ by 57 %), or sqrt(1 - h^2) for h -> 1'''
+    a, b = gold[f'f32/{key}'].astype(np.float64), gold[f'f64/{key}'].astype(np.float64)
+    return k * np.abs(a - b)
 
 
 def pick(mode, strict, fast):
@@ -90,9 +101,11 @@ def test_microfacet(gold, dev):
     # sample_GTR1: sqrt(alpha^(2 - 2u) - 1) / (alpha^2 - 1) then sqrt(1 - h^2): two cancellations; v_sin / v_cos carry
     # ~1e-6 absolute error
     close(got1, want1, pick(mode, 3e-5, 3e-4), 'sample_GTR1', pick(mode, 3e-6, 3e-5))
-    # sample_GTR2: h = sqrt((1 - u) / (1 - u (1 - a^2))) through v_rcp, then sqrt(1 - h^2): for h -> 1 the second root
-    # amplifies the reciprocal's ulp (measured 1.7e-4 on two of 64 rows, 2e-5 elsewhere)
-    close(got2, want2, pick(mode, 1e-5, 3e-4), 'sample_GTR2', pick(mode, 1e-6, 2e-6))
+    # sample_GTR2: h = sqrt((1 - u) / (1 - u (1 - a^2))), then sqrt(1 - h^2): for alpha -> 0, h -> 1 and the second root
+    # loses every digit the first kept (rows 3 and 18, alpha = 0.003 / 0.04: the reference's f32 and f64 runs differ
+    # by 5e-3 there): the production build gets the reference's own spread on top of 2e-5
+    close(got2, want2, pick(mode, 1e-5, 2e-5), 'sample_GTR2', pick(mode, 1e-6, 2e-6),
+          slack=None if mode == 'strict' else spread(gold, 'sample_gtr2/out'))
 
 
 def test_common_helpers(gold, dev):
@@ -210,7 +223,10 @@ def test_disney_brdf_and_bounce(gold, dev):
     plain = live & ~chaotic
     assert (np.abs(got_b[plain, :3] - want_b[plain, :3]).max(axis=1) <= pick(mode, 2e-4, 1e-3)).all(), \
         f'Disney.bounce: an outgoing direction is off by {dirs_err.max():.2e}: a different lobe was sampled'
-    err = np.abs(got_b - want_b) / (np.abs(want_b) + 1e-3)
+    # production build: plus the reference's own f32-vs-f64 spread per output (the mirror material's alpha = 0.001 makes
+    # GTR2 cancel completely: its pdf differs by up to 57 % between the reference's two runs)
+    sl = 0.0 if mode == 'strict' else np.nan_to_num(spread(gold, 'disney/bounce'))
+    err = np.maximum(np.abs(got_b - want_b) - sl, 0.0) / (np.abs(want_b) + 1e-3)
     per_row = np.where(np.isnan(err), 0.0, err).max(axis=1)
     bound = pick(mode, 2e-4, 1e-3)
     report(f'Disney.bounce [{mode}]: worst relative error, plain materials {per_row[plain].max():.2e} (bound {bound:g}), '

@@ -4,6 +4,7 @@
 # usage: tools/gpu_round.sh step1 step2 ...   (steps: see the case list; ABLIBS='a b' ... ablibs benches ptina_amd/libmiptina_a.so, _b.so)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-12}   # also for the rocprofv3 steps, whose tool initialises HIP before libmiptina loads
 run() {  # name seconds command...
   local name=$1 secs=$2; shift 2
   echo "=== $name ===" | tee -a gpurun_out/round.log
