@@ -72,7 +72,7 @@ PMC_PASSES = [
 def render_kernel_name(mode, last_kernel):
     if mode != 'fast':
         return 'render_kernel_strict'
-    return ('render_kernel_fast', 'render_kernel_lds', 'render_kernel_wide')[last_kernel]
+    return ('render_kernel_fast', 'render_kernel_lds', 'render_kernel_wide', 'render_kernel_pool')[last_kernel]
 
 
 def collect_pmc(argv_tail, budget_s=150):

@@ -56,6 +56,15 @@ typedef struct {
     uint64_t it_leaf;        /* wave-level LEAF steps issued             */
     uint64_t it_shade;       /* wave-level SHADE stages issued           */
     uint64_t it_new;         /* wave-level NEW stages issued             */
+    /* the pooled LDS kernel (option "pool"): how its two kinds of waves spent the launch */
+    uint64_t pl_local;       /* bounces a tracer wave did itself because the shade pool was full (lanes)        */
+    uint64_t pl_batches;     /* SHADE batches of the shader waves                                               */
+    uint64_t pl_batch_lanes; /* requests in those batches (pl_batch_lanes / (64 pl_batches) = SHADE lane use)   */
+    uint64_t pl_prim;        /* batches of primary rays made by the shader waves                                */
+    uint64_t pl_tidle;       /* polls of a tracer wave that held no path and found no ray                       */
+    uint64_t pl_sidle;       /* polls of a shader wave that found nothing to do                                 */
+    uint64_t pl_trips;       /* trips of a tracer wave from its traversal loop to the pools                     */
+    uint64_t pl_taken;       /* rays taken out of the ray pool by tracer lanes                                  */
 } mpt_counters;
 
 #define MPT_LIGHT_POINT 1    /* LightPool.TYPES, ptina/light/__init__.py:11 */

@@ -37,7 +37,8 @@ class Caps(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ('samples', 'rays', 'n_box', 'n_tri', 'n_shade', 'n_draws', 'bounces', 'n_node',
-                 'it_node', 'it_leaf', 'it_shade', 'it_new')]
+                 'it_node', 'it_leaf', 'it_shade', 'it_new',
+                 'pl_local', 'pl_batches', 'pl_batch_lanes', 'pl_prim', 'pl_tidle', 'pl_sidle', 'pl_trips', 'pl_taken')]
 
     def asdict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

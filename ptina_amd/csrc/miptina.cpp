@@ -128,7 +128,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (dev_alloc(&c->mats, (size_t)c->caps.max_materials + 1)) return bail("materials");   // + the default material's record
     if (dev_alloc(&c->images, c->caps.max_textures)) return bail("images");
     if (dev_alloc(&c->lights, MPT_MAX_LIGHTS)) return bail("lights");
-    if (dev_alloc(&c->d_counters, 12)) return bail("counters");
+    if (dev_alloc(&c->d_counters, 20)) return bail("counters");
     if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
     if (dev_alloc(&c->d_work, 16)) return bail("work counters");   // 8 queue heads
     for (int k = 0; k < MPT_MAX_PIPE; k++) {
@@ -155,7 +155,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
         *c->h_watchdog = 0;
         c->d_watchdog = (unsigned int *)dp;
     }
-    hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), c->stream);
+    hipMemsetAsync(c->d_counters, 0, 20 * sizeof(unsigned long long), c->stream);
     hipMemsetAsync(c->d_work, 0, 16 * sizeof(unsigned int), c->stream);
     {   // unset materials: factor 0 (field-zero, mtllib.py:12-13), texture -1 (deviation Q6)
         std::vector<MptMaterial> z((size_t)c->caps.max_materials + 1);
@@ -282,6 +282,11 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->count = value ? 1 : 0;
     } else if (k == "lds") {
         c->use_lds = value ? 1 : 0;
+    } else if (k == "pool") {
+        c->use_pool = value ? 1 : 0;
+    } else if (k == "pool_shaders") {
+        if (value < 1 || value > 8) return fail("pool_shaders must be in 1..8");
+        c->pool_shaders = value;
     } else if (k == "timeline") {
         c->timeline = value ? 1 : 0;
     } else if (k == "pipe_depth") {
@@ -333,6 +338,8 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "pending") *value = c->pending;
     else if (k == "lds") *value = c->use_lds;
     else if (k == "lds_block") *value = c->lds_block;
+    else if (k == "pool") *value = c->use_pool;
+    else if (k == "pool_shaders") *value = c->pool_shaders;
     else if (k == "pipe_depth") *value = c->pipe_depth;
     else if (k == "grid_div") *value = c->grid_div;
     else if (k == "cur_depth") *value = c->cur_depth;
@@ -434,9 +441,12 @@ extern "C" int mpt_load_model(mpt_ctx *c, const float *verts, const int32_t *mtl
     c->verts.assign(verts, verts + (size_t)n * 24);
     if (mtlids) c->mtlids.assign(mtlids, mtlids + n);
     else c->mtlids.assign(n, -1);                                             // model.py:80-81
-    for (int i = 0; i < n; i++)
+    c->max_mtlid = -1;
+    for (int i = 0; i < n; i++) {
         if (c->mtlids[i] < -1 || c->mtlids[i] >= c->caps.max_materials)
             return fail("material id %d of face %d outside [-1, %d)", c->mtlids[i], i, c->caps.max_materials);
+        c->max_mtlid = std::max(c->max_mtlid, (int)c->mtlids[i]);
+    }
     c->tree_valid = false;
     return 0;
 }
@@ -695,6 +705,21 @@ extern "C" int mpt_flush(mpt_ctx *c) {
                              (((size_t)c->nfaces + 15) & ~(size_t)15) + (size_t)lds_stack * 1024 * sizeof(short);
     const bool lds_kernel = fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && c->caps.max_materials < 256 &&
                             lds_bytes <= 160 * 1024;
+    // the same scene with the waves of the workgroup specialised and two path pools in LDS (render_pool.h): only the material
+    // records the model uses, stacks for the tracer waves only, node records 72 bytes apart where that fits and 64 where not
+    size_t pool_bytes = 0;
+    int pool_stride = 0;
+    const int pool_nmats = c->max_mtlid + 1;
+    if (lds_kernel && c->use_pool && c->sdim <= 32768 && c->lds_block == 0) {
+        for (int stride : { MPT_LDS_NODE_STRIDE, 64 }) {
+            const size_t b = ((((size_t)(c->nfaces - 1) * stride + 15) >> 4) + (size_t)c->nfaces * 3 + (size_t)(pool_nmats + 1) * 6) * sizeof(MptVec4) +
+                             (((size_t)c->nfaces + 15) & ~(size_t)15) + mpt_pool_lds_overhead() +
+                             (size_t)lds_stack * (size_t)(16 - c->pool_shaders) * 64 * sizeof(short);
+            if (b <= 160 * 1024) { pool_bytes = b; pool_stride = stride; break; }
+        }
+    }
+    const bool pool_kernel = pool_bytes != 0;
+    p.lds_node_stride = pool_stride; p.lds_nmats = pool_nmats; p.pool_shaders = c->pool_shaders;
     int chunk = B, nchunks = 1;
     const int tw = 1 << c->tile_w_shift, th = 1 << c->tile_h_shift;
     int tile_cols = 0;
@@ -817,10 +842,11 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(hipEventRecord(e0, rs));
     if (!fast) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, rs));
+    else if (pool_kernel) HIP_TRY(mpt_launch_render_pool(&p, launch_cus, 1024, pool_bytes, c->count, rs));
     else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, launch_cus, c->lds_block ? c->lds_block : 1024, lds_bytes, c->count, rs));
     else if (wide_kernel) HIP_TRY(mpt_launch_render_wide(&p, wide_blocks, c->count, c->use_quant, rs));
     else HIP_TRY(mpt_launch_render_fast(&p, launch_cus, stack, c->count, rs));
-    c->last_kernel = lds_kernel ? 1 : wide_kernel ? 2 : 0;
+    c->last_kernel = pool_kernel ? 3 : lds_kernel ? 1 : wide_kernel ? 2 : 0;
     HIP_TRY(hipEventRecord(e1, rs));
     c->events.push_back({ e0, e1 });
     if (c->events.size() > 4096) {
@@ -957,12 +983,14 @@ extern "C" int mpt_get_film_raw(mpt_ctx *c, int pass, float *out) {
 extern "C" int mpt_get_counters(mpt_ctx *c, mpt_counters *out) {
     if (use_ro(c)) return 1;
     if (mpt_flush(c)) return 1;
-    unsigned long long h[12];
+    unsigned long long h[20];
     HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     out->samples = h[0]; out->rays = h[1]; out->n_box = h[2]; out->n_tri = h[3];
     out->n_shade = h[4]; out->n_draws = h[5]; out->bounces = h[6]; out->n_node = h[7];
     out->it_node = h[8]; out->it_leaf = h[9]; out->it_shade = h[10]; out->it_new = h[11];
+    out->pl_local = h[12]; out->pl_batches = h[13]; out->pl_batch_lanes = h[14]; out->pl_prim = h[15];
+    out->pl_tidle = h[16]; out->pl_sidle = h[17]; out->pl_trips = h[18]; out->pl_taken = h[19];
     return 0;
 }
 
@@ -1023,7 +1051,7 @@ extern "C" int mpt_unit_eval(mpt_ctx *c, int kind, const void *in, int in_cols, 
 
 extern "C" int mpt_reset_counters(mpt_ctx *c) {
     if (use(c)) return 1;
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 20 * sizeof(unsigned long long), c->stream));
     return 0;
 }
 

@@ -26,6 +26,8 @@ MPT_KERNEL_API hipError_t mpt_launch_derive_tfast(const MptVec4 *tgeo, MptVec4 *
 MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int quant, int *blocks);
 MPT_KERNEL_API hipError_t mpt_launch_render_wide(const MptRenderParams *, int blocks, int count, int quant, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_render_pool(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
+MPT_KERNEL_API size_t mpt_pool_lds_overhead(void);
 MPT_KERNEL_API hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
@@ -76,6 +78,8 @@ struct mpt_ctx {
 
     // options
     int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1, lds_block = 0;
+    int use_pool = 0, pool_shaders = 3;  // LDS kernel with specialised waves and path pools (render_pool.h)
+    int max_mtlid = -1;                  // largest material id of the model (-1: only the default material)
     int num_cus = 256;
     int clock_khz = 0;                   // hipDeviceProp_t.clockRate: peak shader clock (roofline peaks in bench.py)
     int tile_w_shift = 3, tile_h_shift = 3;   // work-item tile 2^w x 2^h pixels

@@ -134,7 +134,11 @@ DEV float rng_random(Rng &r) {
 DEV V3 random3(Rng &r) { float a = rng_random(r), b = rng_random(r), c = rng_random(r); return v3(a, b, c); }
 
 // ---------------------------------------------------------------- counters
-struct Cnt { unsigned rays, n_box, n_tri, n_shade, n_draws, bounces, n_node, samples, it_node, it_leaf, it_shade, it_new; };
+struct Cnt { unsigned rays, n_box, n_tri, n_shade, n_draws, bounces, n_node, samples, it_node, it_leaf, it_shade, it_new;
+             // pooled kernel (render_pool.h): bounces a tracer did itself because the shade pool was full; shader batches and the
+             // requests in them; primary-ray batches; tracer / shader polls with nothing to do; trips of a tracer to the pools;
+             // rays taken by tracers
+             unsigned pl_local, pl_batches, pl_batch_lanes, pl_prim, pl_tidle, pl_sidle, pl_trips, pl_taken; };
 
 // ---------------------------------------------------------------- geometry
 struct Hit { int hit; float depth; int index; float u, v; };
@@ -377,6 +381,9 @@ struct LdsScene {
     // still on its way from L2, instead of gathering it from L2 after that record has arrived (it holds the id).
     LdsVec4Ptr mats;
     LdsU8Ptr mtl;
+    int nstride;               // bytes from one node record to the next (MPT_LDS_NODE_STRIDE; 64 where 72 does not fit)
+    int mat_last, mat_default; // LDS record mat_last is the default material = record mat_default of the global table
+                               // (the pooled kernel keeps only the records the model uses; else both are default_mtl)
     // The slab planes of both children picked by the ray's direction signs instead of by min / max: a node
     // record holds {lo, lo, hi, hi} (child 0, child 1) per axis, so the entry planes of an axis are the 8 bytes at
     // offset 0 for a ray going up that axis and at offset 8 for one going down, and the exit planes are the
@@ -384,7 +391,7 @@ struct LdsScene {
     // and 12 v_min / v_max fewer per step.
     DEV void node_planes(int i, int ox, int oy, int oz, mpt_f2 &nx, mpt_f2 &fx, mpt_f2 &ny, mpt_f2 &fy,
                          mpt_f2 &nz, mpt_f2 &fz, mpt_f2 &ids) const {
-        LdsBytePtr nd = (LdsBytePtr)fnode + i * MPT_LDS_NODE_STRIDE;
+        LdsBytePtr nd = (LdsBytePtr)fnode + i * nstride;
         LdsBytePtr ax = nd + ox, ay = nd + oy, az = nd + oz;
         nx = *(LdsVec2Ptr)ax;        fx = *(LdsVec2Ptr)(nd + (ox ^ 8));
         ny = *(LdsVec2Ptr)(ay + 16); fy = *(LdsVec2Ptr)(nd + 16 + (oy ^ 8));
@@ -410,6 +417,17 @@ struct Stack16 {
     int sp;
     DEV void push(int v) { base[sp * MPT_LDS_BLOCK] = (short)v; sp++; }
     DEV int pop() { sp--; return (int)base[sp * MPT_LDS_BLOCK]; }
+};
+
+// the same LIFO for the tracer waves of the pooled kernel: [level][tracer lane], the lane count a launch parameter
+struct Stack16V {
+    static constexpr int SENTINEL = -32768;
+    static constexpr int PLANE_OFF = 8;
+    LdsShortPtr base;          // &lds16[tracer lane]
+    int stride;                // tracer lanes of the workgroup (wave-uniform)
+    int sp;
+    DEV void push(int v) { base[sp * stride] = (short)v; sp++; }
+    DEV int pop() { sp--; return (int)base[sp * stride]; }
 };
 
 #if MPT_STRICT
@@ -1227,7 +1245,7 @@ DEV void get_geometries_rec(const MptRenderParams &p, const SCENE &sc, const Sha
         const int rec = sc.mtl[hit.index];
         LdsVec4Ptr q = sc.mats + rec * MPT_LDS_MAT_VEC4;
         MptVec4 q0 = lds_ld(q), q1 = lds_ld(q + 1), q2 = lds_ld(q + 2), q3 = lds_ld(q + 3), d0 = lds_ld(q + 4), d1 = lds_ld(q + 5);
-        material_from(p, p.mats + rec, q0, q1, q2, q3, d0, d1, tu, tv, mat);
+        material_from(p, p.mats + (rec == sc.mat_last ? sc.mat_default : rec), q0, q1, q2, q3, d0, d1, tu, tv, mat);
     } else {
         material_get(p, __float_as_int(s3.w), tu, tv, mat);
     }

@@ -68,10 +68,11 @@ DEV BlockTracer make_block_tracer(const MptRenderParams &p, int *lds) {
 template <bool COUNT>
 DEV void flush_counters(const MptRenderParams &p, const Cnt &c) {
     if (!COUNT) return;
-    unsigned v[12] = { c.samples, c.rays, c.n_box, c.n_tri, c.n_shade, c.n_draws, c.bounces, c.n_node,
-                       c.it_node, c.it_leaf, c.it_shade, c.it_new };
+    unsigned v[20] = { c.samples, c.rays, c.n_box, c.n_tri, c.n_shade, c.n_draws, c.bounces, c.n_node,
+                       c.it_node, c.it_leaf, c.it_shade, c.it_new,
+                       c.pl_local, c.pl_batches, c.pl_batch_lanes, c.pl_prim, c.pl_tidle, c.pl_sidle, c.pl_trips, c.pl_taken };
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
+    for (int k = 0; k < 20; k++) {
         unsigned x = v[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
@@ -479,9 +480,12 @@ DEV void stage_shadow_done(const MptRenderParams &p, LaneState &L, STACK &stk, C
 }
 
 // path.py:31-62 for one bounce.  On entry L.to / L.prd are the path ray r.o / r.d and
-// (L.hidx >= 0, L.tbest, L.hidx, L.hu, L.hv) the closest hit.
-template <bool COUNT, class SCENE, class STACK>
-DEV void stage_shade(const MptRenderParams &p, const SCENE &sc, LaneState &L, STACK &stk, Cnt &cnt) {
+// (L.hidx >= 0, L.tbest, L.hidx, L.hu, L.hv) the closest hit.  shade_core is the bounce itself; what follows it --
+// a shadow ray from hitpos towards the sampled light, or the next bounce from hitpos -- is the caller's: the wave that
+// shaded starts it in the same lane (stage_shade), or hands it to another wave through the workgroup's ray pool.
+enum { SH_END = 0, SH_BOUNCE = 1, SH_SHADOW = 2 };   // path over (miss: world light added) | next bounce from hitpos | shadow ray first
+template <bool COUNT, class SCENE>
+DEV int shade_core(const MptRenderParams &p, const SCENE &sc, LaneState &L, Cnt &cnt, V3 &hitpos, V3 &sdir, float &sdis) {
     V3 ro = L.to, rd = L.prd;
     const bool was_hit = L.hidx >= 0;
     float hdepth = was_hit ? L.tbest : MPT_INF;
@@ -499,15 +503,15 @@ DEV void stage_shade(const MptRenderParams &p, const SCENE &sc, LaneState &L, ST
         float mis = power_heuristic(L.last_brdf_pdf, lit.pdf);
         L.result = L.result + L.throughput * (lit.color * mis);
     }
+    hitpos = ro; sdir = v3s(0.0f); sdis = 0.0f;
     if (!was_hit) {
         L.result = L.result + L.throughput * world_at(p, rd);
         L.depth = 5;                                                         // break, path.py:39
-        lane_next_bounce<COUNT>(p, L, stk, ro, cnt);
-        return;
+        return SH_END;
     }
     L.navoid = ~L.hidx;
     Hit hit; hit.hit = 1; hit.depth = hdepth; hit.index = L.hidx; hit.u = L.hu; hit.v = L.hv;
-    V3 hitpos, normal; Disney mat;
+    V3 normal; Disney mat;
     get_geometries_rec(p, sc, rec, hit, ro, rd, &hitpos, &normal, mat);
     if (COUNT) { cnt.n_shade++; cnt.n_draws += 6; }
     float sign = -dot(rd, normal);                                           // path.py:44-46 (never negative)
@@ -529,11 +533,20 @@ DEV void stage_shade(const MptRenderParams &p, const SCENE &sc, LaneState &L, ST
     L.prd = brdf.outdir;
     L.last_brdf_pdf = brdf.pdf;
     if (want_shadow && p.n >= 2) {
-        lane_start_ray<COUNT>(L, stk, hitpos, li.dir, li.dis, true, cnt);
-    } else {
-        if (want_shadow) { L.result = L.result + L.direct; if (COUNT) cnt.rays++; }   // no geometry to occlude
-        lane_next_bounce<COUNT>(p, L, stk, hitpos, cnt);
+        sdir = li.dir; sdis = li.dis;
+        return SH_SHADOW;
     }
+    if (want_shadow) { L.result = L.result + L.direct; if (COUNT) cnt.rays++; }   // no geometry to occlude
+    return SH_BOUNCE;
+}
+
+template <bool COUNT, class SCENE, class STACK>
+DEV void stage_shade(const MptRenderParams &p, const SCENE &sc, LaneState &L, STACK &stk, Cnt &cnt) {
+    V3 hitpos, sdir;
+    float sdis;
+    const int next = shade_core<COUNT>(p, sc, L, cnt, hitpos, sdir, sdis);
+    if (next == SH_SHADOW) lane_start_ray<COUNT>(L, stk, hitpos, sdir, sdis, true, cnt);
+    else lane_next_bounce<COUNT>(p, L, stk, hitpos, cnt);                    // SH_END: depth is 5, the sample is stored
 }
 
 // do_render up to the camera ray, path.py:82-90, in two halves.  A wave prepares the primary rays of the next 64
@@ -826,8 +839,11 @@ __global__ MPT_RENDER_BOUNDS void MPT_SUFFIX(render_kernel)(const MptRenderParam
 
 #if !MPT_STRICT
 // ---------------------------------------------------------------- gather kernel over 4-wide nodes
+#ifndef MPT_WIDE_WAVES
+#define MPT_WIDE_WAVES 4      // waves per SIMD the 4-wide gather kernel is compiled for (its register budget: 512 / this)
+#endif
 template <bool COUNT, bool QUANT>
-__global__ __launch_bounds__(MPT_BLOCK, 4) void render_kernel_wide(const MptRenderParams p) {
+__global__ __launch_bounds__(MPT_BLOCK, MPT_WIDE_WAVES) void render_kernel_wide(const MptRenderParams p) {
     __shared__ int s_stack[SpillStack::CAP * MPT_BLOCK];
     SpillStack stk;
     stk.base = s_stack + threadIdx.x;
@@ -881,6 +897,8 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
     sc.tgeo = (LdsVec4Ptr)(void *)(smem + nnode4);
     sc.mats = (LdsVec4Ptr)(void *)(smem + nnode4 + ntri4);
     sc.mtl = (LdsU8Ptr)(void *)(smem + nnode4 + ntri4 + nmat4);
+    sc.nstride = MPT_LDS_NODE_STRIDE;
+    sc.mat_last = p.default_mtl; sc.mat_default = p.default_mtl;
     Stack16 stk;
     stk.base = (LdsShortPtr)(void *)(smem + nnode4 + ntri4 + nmat4 + nmtl4) + threadIdx.x;
     stk.sp = 0;
@@ -986,6 +1004,10 @@ MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *p, int gr
                                             hipStream_t stream) {
     return count ? launch_lds<true>(p, grid, block, lds_bytes, stream) : launch_lds<false>(p, grid, block, lds_bytes, stream);
 }
+#endif
+
+#if !MPT_STRICT
+#include "render_pool.h"
 #endif
 
 #if !MPT_STRICT
