@@ -89,7 +89,8 @@ void mpt_destroy(mpt_ctx *ctx);
  * takes effect at the next mpt_build_tree), "tile_w_shift"/"tile_h_shift" (work-item tile 2^w x 2^h pixels),
  * "wide" (scenes that do not fit LDS: 1 = walk the fast tree collapsed into 4-wide nodes, default; 0 = the
  * binary tree), "wide_quant" (1 = the 4-wide nodes as 64-byte records with 8-bit child boxes rounded outwards: four
- * gathers per step, default; 0 = 128-byte records with the exact boxes: seven), "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
+ * gathers per step, default; 0 = 128-byte records with the exact boxes: seven), "wide_build" (1 = that collapse runs on the
+ * device, default; 0 = host pass over downloaded records: same bytes), "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
  * walks the LBVH itself; default 2^22), "grid_div" (each launch takes 1/G of the CUs so that G launches are resident
  * in different phases; 0 = choose by samples per lane, and the whole chip for a launch that finds nothing else in flight: default), "pipe_depth" (batches in flight,
  * 2..6; 0 = auto), "lds_block" (lanes per persistent workgroup of the LDS kernel, diagnostics),
@@ -126,6 +127,10 @@ int mpt_build_tree(mpt_ctx *ctx);
 /* test/inspection: reference-layout tree arrays (tree/lbvh.py:48-56); any pointer may be NULL */
 int mpt_get_tree(mpt_ctx *ctx, int32_t *child /*[n-1][2]*/, int32_t *leaf /*[n]*/,
                  float *bmin /*[n-1][3]*/, float *bmax /*[n-1][3]*/, int32_t *mc /*[n]*/, int32_t *depth);
+
+/* test/inspection: the 4-wide records the gather kernels walk (no reference counterpart): wnode [nw][8][4] f32 with the exact
+ * child boxes, qnode [nw][4][4] with 8-bit boxes; any pointer may be NULL; *nw = wide nodes built (0: none) */
+int mpt_get_wide(mpt_ctx *ctx, float *wnode, float *qnode, int cap_nodes, int *nw);
 
 /* Camera.set_perspective, ptina/camera.py:19-22: the two f32 matrices the reference stores
  * (V2W = inv(pers) computed by the caller in f64 exactly as the reference does) */

@@ -64,6 +64,7 @@ SIGNATURES = {
     'mpt_load_image': (_i, [_vp, _fp, _i, _i, C.POINTER(_i)]),
     'mpt_build_tree': (_i, [_vp]),
     'mpt_get_tree': (_i, [_vp, _ip, _ip, _fp, _fp, _ip, _ip]),
+    'mpt_get_wide': (_i, [_vp, _fp, _fp, _i, C.POINTER(_i)]),
     'mpt_set_camera': (_i, [_vp, _fp, _fp]),
     'mpt_clear_lights': (_i, [_vp]),
     'mpt_add_light': (_i, [_vp, _i, _fp, _fp, _fp, C.c_float, C.POINTER(_i)]),

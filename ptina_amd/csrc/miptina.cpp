@@ -199,6 +199,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     hipFree(c->gather_buf); hipFree(c->d_pieces);
+    hipFree(c->wb_bin_of); hipFree(c->wb_ncount); hipFree(c->wb_offset); hipFree(c->wb_scan); hipFree(c->wb_area);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
     if (c->h_watchdog) hipHostFree(c->h_watchdog);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -306,6 +307,8 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->node_soa = value ? 1 : 0;
     } else if (k == "wide") {
         c->use_wide = value ? 1 : 0;
+    } else if (k == "wide_build") {
+        if ((value ? 1 : 0) != c->wide_build) { c->wide_build = value ? 1 : 0; c->tree_valid = false; }
     } else if (k == "wide_quant") {
         c->use_quant = value ? 1 : 0;
     } else if (k == "tree") {
@@ -350,6 +353,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "reserve_cus") *value = c->reserve_cus;
     else if (k == "wide") *value = c->use_wide;
     else if (k == "wide_quant") *value = c->use_quant;
+    else if (k == "wide_build") *value = c->wide_build;
     else if (k == "wide_nodes") *value = c->wide_nodes;
     else if (k == "wide_ratio_permille") *value = (int)(c->wide_ratio * 1000.f + 0.5f);
     else if (k == "wide_depth") *value = c->wide_depth;

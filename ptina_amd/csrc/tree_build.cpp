@@ -479,7 +479,7 @@ static int build_tree_gpu(mpt_ctx *c) {
 // surface area is replaced by its own two children until four are held (or only leaves are left).  A ray then
 // makes about half as many dependent record fetches, which is what the scenes that do not fit LDS wait for.
 // Host pass over the downloaded records (1 M triangles: 64 MB down, ~0.1 s, 64 MB up), off the render path.
-static int make_wide(mpt_ctx *c) {
+static int make_wide_host(mpt_ctx *c) {
     c->wide_nodes = 0; c->wide_depth = 0;
     const int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
     if (ni < 1) return 0;
@@ -546,7 +546,9 @@ static int make_wide(mpt_ctx *c) {
         MptVec4 rec[8];
         float *f = &rec[0].x;
         for (int k = 0; k < 32; k++) f[k] = 0.f;
-        int32_t ids[4] = { 0, 0, 0, 0 };
+        // an unused slot names leaf slot n: one extra triangle record of NaNs that no ray can hit (round 2 stored 0, the
+        // root, there: a ray along (1,1,1) could be sent back to it)
+        int32_t ids[4] = { ~n, ~n, ~n, ~n };
         for (int k = 0; k < 4; k++) {
             float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { 1e30f, 1e30f, 1e30f };   // unused child: out of every ray's reach
             if (k < cnt) {
@@ -615,12 +617,64 @@ static int make_wide(mpt_ctx *c) {
     return 0;
 }
 
+// The same collapse on the device (wide_build.hip): nothing is downloaded, one integer per level comes back.  Produces the
+// host pass's bytes (tests/test_parity_gpu.py::test_device_wide_collapse_equals_the_host_pass).
+static int make_wide_device(mpt_ctx *c) {
+    c->wide_nodes = 0; c->wide_depth = 0;
+    const int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
+    if (ni < 1) return 0;
+    if ((size_t)ni * 8 * sizeof(MptVec4) >= ((size_t)1 << 31)) return 0;   // the kernel addresses the records with 32-bit byte offsets
+    if ((size_t)ni > c->wnode_cap) {
+        hipFree(c->wnode); c->wnode = nullptr; c->wnode_cap = 0;
+        if (dev_alloc(&c->wnode, (size_t)ni * 8)) return 1;
+        c->wnode_cap = ni;
+    }
+    if ((size_t)ni > c->qnode_cap) {
+        hipFree(c->qnode); c->qnode = nullptr; c->qnode_cap = 0;
+        if (dev_alloc(&c->qnode, (size_t)ni * 4)) return 1;
+        c->qnode_cap = ni;
+    }
+    if ((size_t)ni > c->wb_cap) {
+        hipFree(c->wb_bin_of); hipFree(c->wb_ncount); hipFree(c->wb_offset); hipFree(c->wb_scan); hipFree(c->wb_area);
+        c->wb_bin_of = c->wb_ncount = c->wb_offset = nullptr; c->wb_scan = nullptr; c->wb_area = nullptr; c->wb_cap = 0;
+        HIP_TRY(mpt_wide_scan_bytes(ni, &c->wb_scan_bytes));
+        if (dev_alloc(&c->wb_bin_of, (size_t)ni + 4) || dev_alloc(&c->wb_ncount, (size_t)ni) || dev_alloc(&c->wb_offset, (size_t)ni) ||
+            dev_alloc((char **)&c->wb_scan, std::max<size_t>(c->wb_scan_bytes, 16)) || dev_alloc(&c->wb_area, 2)) return 1;
+        c->wb_cap = ni;
+    }
+    int nw = 0, depth = 0;
+    double area[2] = { 0.0, 0.0 };
+    HIP_TRY(mpt_wide_build(c->fnode, n, c->wnode, c->qnode, c->wb_bin_of, c->wb_ncount, c->wb_offset, c->wb_scan, c->wb_scan_bytes,
+                           c->wb_area, &nw, &depth, area, c->stream));
+    // a step pushes up to three entries: 3 x depth + sentinel must fit the LDS levels plus the spill strip
+    if (3 * depth + 2 > 128) return 0;      // too deep: the gather kernel keeps walking the binary tree
+    c->wide_nodes = nw; c->wide_depth = depth;
+    c->wide_ratio = area[1] > 0.0 ? (float)(area[0] / area[1]) : 1.f;
+    return 0;
+}
+
+static int make_wide(mpt_ctx *c) { return c->wide_build ? make_wide_device(c) : make_wide_host(c); }
+
+// test / inspection: the 4-wide records the gather kernels walk -- wnode [nw][8] float4 (exact boxes), qnode [nw][4] float4
+// (8-bit boxes); any pointer may be NULL; *nw = number of wide nodes (0: not built)
+extern "C" int mpt_get_wide(mpt_ctx *c, float *wnode, float *qnode, int cap_nodes, int *nw) {
+    if (use_ro(c)) return 1;
+    if (!c->tree_valid) return fail("BVH not built: call build_tree() after load_model()");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int k = std::min(cap_nodes, c->wide_nodes);
+    if (wnode && k > 0) HIP_TRY(hipMemcpy(wnode, c->wnode, (size_t)k * 8 * sizeof(MptVec4), hipMemcpyDeviceToHost));
+    if (qnode && k > 0) HIP_TRY(hipMemcpy(qnode, c->qnode, (size_t)k * 4 * sizeof(MptVec4), hipMemcpyDeviceToHost));
+    if (nw) *nw = c->wide_nodes;
+    return 0;
+}
+
 extern "C" int mpt_build_tree(mpt_ctx *c) {
     if (use(c)) return 1;
     c->fnode_soa_valid = false;
     if (c->gpu_build ? build_tree_gpu(c) : build_tree_host(c)) return 1;
     // the production kernels' 48-byte triangle records, from the reference-order ones
-    const size_t nt = (size_t)std::max(c->nfaces, 1);
+    // (+ 1: record n is all NaNs -- the leaf an unused slot of a 4-wide node names; no ray can hit it)
+    const size_t nt = (size_t)std::max(c->nfaces, 1) + 1;
     if (nt > c->tfast_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         hipFree(c->tfast); c->tfast = nullptr; c->tfast_cap = 0;
@@ -628,6 +682,7 @@ extern "C" int mpt_build_tree(mpt_ctx *c) {
         c->tfast_cap = nt;
     }
     HIP_TRY(mpt_launch_derive_tfast(c->tgeo, c->tfast, c->nfaces, c->stream));
+    HIP_TRY(hipMemsetAsync(c->tfast + (size_t)c->nfaces * 3, 0xff, 3 * sizeof(MptVec4), c->stream));   // 0xffffffff: a NaN
     return make_wide(c);
 }
 

@@ -1,0 +1,194 @@
+// wide_build.hip -- the 4-wide collapse of the fast build's binary tree, on the device.
+//
+// The gather kernels walk the binary tree of c->fnode (a node record holds its two children's boxes) collapsed into
+// 4-wide nodes: starting from a node's two children, the internal child with the largest surface area is replaced by
+// its own two children until four are held (or only leaves are left).  Round 2 did this on the host over downloaded
+// records (64 MB down, 0.1 s, 96 MB up at 1 M triangles); here it stays on the device:
+//   one pass per LEVEL of the wide tree (breadth first, so wide node numbers are the host pass's):
+//     expand   one lane per wide node of the level: grows its four children from the binary records, writes the
+//              128-byte record with exact boxes (wnode) and the 64-byte record with 8-bit child boxes rounded
+//              outwards (qnode), and counts its internal children
+//     scan     exclusive prefix sum of those counts (rocPRIM): where the children's numbers start
+//     link     gives the internal children their numbers (level end + prefix + rank) in both records and records
+//              which binary node each of them grows from
+// The arithmetic of the quantisation is the host pass's, operation for operation, without contraction (this file
+// is compiled with -ffp-contract=off): both passes produce the same bytes (tests/test_parity_gpu.py).
+// An unused child slot holds the id of leaf slot n -- one extra triangle record of NaNs that no ray can hit -- and a
+// box no ray enters; round 2 stored id 0 there, the root, which a ray along (1,1,1) could be sent back to.
+
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include <cmath>
+#include "mpt_types.h"
+
+#define WB_BLOCK 256
+
+struct WbChild { int id; float lo[3], hi[3]; };
+
+__device__ __forceinline__ int wb_asi(float f) { return __float_as_int(f); }
+__device__ __forceinline__ float wb_asf(int v) { return __int_as_float(v); }
+
+__device__ __forceinline__ void wb_children_of(const MptVec4 *__restrict__ fnode, int b, WbChild out[2]) {
+    const MptVec4 r0 = fnode[(size_t)b * 4 + 0], r1 = fnode[(size_t)b * 4 + 1], r2 = fnode[(size_t)b * 4 + 2], r3 = fnode[(size_t)b * 4 + 3];
+    out[0].id = wb_asi(r3.x); out[1].id = wb_asi(r3.y);
+    out[0].lo[0] = r0.x; out[1].lo[0] = r0.y; out[0].hi[0] = r0.z; out[1].hi[0] = r0.w;
+    out[0].lo[1] = r1.x; out[1].lo[1] = r1.y; out[0].hi[1] = r1.z; out[1].hi[1] = r1.w;
+    out[0].lo[2] = r2.x; out[1].lo[2] = r2.y; out[0].hi[2] = r2.z; out[1].hi[2] = r2.w;
+}
+
+__device__ __forceinline__ float wb_area(const WbChild &c) {
+    const float dx = fmaxf(c.hi[0] - c.lo[0], 0.f), dy = fmaxf(c.hi[1] - c.lo[1], 0.f), dz = fmaxf(c.hi[2] - c.lo[2], 0.f);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// expand: wide nodes [lo, lo + count) of one level.  ncount[t] = internal children of wide node lo + t (0 beyond the level)
+__global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__restrict__ fnode, const int *__restrict__ bin_of, int lo,
+                                                            int count, int empty_id, MptVec4 *__restrict__ wnode, MptVec4 *__restrict__ qnode,
+                                                            int *__restrict__ ncount, double *__restrict__ area_sum) {
+    const int t = blockIdx.x * WB_BLOCK + threadIdx.x;
+    if (t >= count) return;
+    const int w = lo + t;
+    WbChild ch[4];
+    int cnt = 2;
+    wb_children_of(fnode, bin_of[w], ch);
+    {   // surface area of the node this record is grown from (= the union of its two children): the collapse's share of
+        // the expected fetches per ray (informational: option "wide_ratio_permille")
+        WbChild own = ch[0];
+        for (int a = 0; a < 3; a++) { own.lo[a] = fminf(ch[0].lo[a], ch[1].lo[a]); own.hi[a] = fmaxf(ch[0].hi[a], ch[1].hi[a]); }
+        atomicAdd(area_sum, (double)wb_area(own));
+    }
+    while (cnt < 4) {
+        int best = -1; float ba = -1.f;
+        for (int k = 0; k < cnt; k++)
+            if (ch[k].id >= 0) { const float a = wb_area(ch[k]); if (a > ba) { ba = a; best = k; } }
+        if (best < 0) break;
+        WbChild two[2];
+        wb_children_of(fnode, ch[best].id, two);
+        ch[best] = two[0];
+        ch[cnt++] = two[1];
+    }
+    // ---- the exact record: {lo.x[4]} {hi.x[4]} {lo.y[4]} {hi.y[4]} {lo.z[4]} {hi.z[4]} {id[4]} {-}
+    float rec[32];
+    for (int k = 0; k < 32; k++) rec[k] = 0.f;
+    int ids[4], nint = 0;
+    for (int k = 0; k < 4; k++) {
+        float l[3] = { 1e30f, 1e30f, 1e30f }, h[3] = { 1e30f, 1e30f, 1e30f };   // unused child: out of every ray's reach
+        ids[k] = empty_id;
+        if (k < cnt) {
+            for (int a = 0; a < 3; a++) { l[a] = ch[k].lo[a]; h[a] = ch[k].hi[a]; }
+            ids[k] = ch[k].id;                        // internal children: the BINARY node for now, numbered by wb_link
+            if (ch[k].id >= 0) nint++;
+        }
+        for (int a = 0; a < 3; a++) { rec[(2 * a) * 4 + k] = l[a]; rec[(2 * a + 1) * 4 + k] = h[a]; }
+    }
+    for (int k = 0; k < 4; k++) rec[24 + k] = wb_asf(ids[k]);
+    MptVec4 *wo = wnode + (size_t)w * 8;
+    for (int k = 0; k < 8; k++) wo[k] = { rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3] };
+    // ---- the quantised record: child planes as bytes over the node's own box, rounded outwards by a quarter of a step
+    // more than needed (the kernel's decode q * (scale * inv) + (origin * inv - o * inv) is off by far less)
+    float plo[3] = { INFINITY, INFINITY, INFINITY }, phi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int k = 0; k < cnt; k++)
+        for (int a = 0; a < 3; a++) { plo[a] = fminf(plo[a], ch[k].lo[a]); phi[a] = fmaxf(phi[a], ch[k].hi[a]); }
+    float scale[3];
+    unsigned qlo[3] = { 0, 0, 0 }, qhi[3] = { 0, 0, 0 };
+    for (int a = 0; a < 3; a++) {
+        const float e = phi[a] - plo[a];
+        float sc = e > 0.f ? e / 255.f : 0.f;
+        // 255 steps must reach the far side in f32, and a flat node still needs a positive step
+        while (e > 0.f && plo[a] + 255.f * sc < phi[a]) sc = nextafterf(sc, INFINITY);
+        if (!(sc > 0.f)) sc = fmaxf(fabsf(plo[a]) * 1e-6f, 1e-30f);
+        scale[a] = sc;
+        for (int k = 0; k < 4; k++) {
+            unsigned l = 255, h = 0;                  // unused child: an inverted box
+            if (k < cnt) {
+                const float fl = floorf((ch[k].lo[a] - plo[a]) / sc - 0.25f), fh = ceilf((ch[k].hi[a] - plo[a]) / sc + 0.25f);
+                l = (unsigned)fminf(255.f, fmaxf(0.f, fl));
+                h = (unsigned)fminf(255.f, fmaxf(0.f, fh));
+            }
+            qlo[a] |= l << (8 * k); qhi[a] |= h << (8 * k);
+        }
+    }
+    MptVec4 *qo = qnode + (size_t)w * 4;
+    qo[0] = { plo[0], plo[1], plo[2], scale[0] };
+    qo[1] = { scale[1], scale[2], wb_asf((int)qlo[0]), wb_asf((int)qhi[0]) };
+    qo[2] = { wb_asf((int)qlo[1]), wb_asf((int)qhi[1]), wb_asf((int)qlo[2]), wb_asf((int)qhi[2]) };
+    qo[3] = { wb_asf(ids[0]), wb_asf(ids[1]), wb_asf(ids[2]), wb_asf(ids[3]) };
+    ncount[t] = nint;
+}
+
+// link: the internal children of wide node lo + t get the numbers next + offset[t] ... in slot order (the host pass's
+// queue order), in both records; bin_of of the new nodes = the binary node they grow from
+__global__ __launch_bounds__(WB_BLOCK) void wb_link_kernel(int lo, int count, int next, const int *__restrict__ offset,
+                                                          MptVec4 *__restrict__ wnode, MptVec4 *__restrict__ qnode, int *__restrict__ bin_of) {
+    const int t = blockIdx.x * WB_BLOCK + threadIdx.x;
+    if (t >= count) return;
+    const int w = lo + t;
+    MptVec4 idv = wnode[(size_t)w * 8 + 6];
+    int ids[4] = { wb_asi(idv.x), wb_asi(idv.y), wb_asi(idv.z), wb_asi(idv.w) };
+    int at = next + offset[t];
+    bool any = false;
+    for (int k = 0; k < 4; k++)
+        if (ids[k] >= 0) { bin_of[at] = ids[k]; ids[k] = at++; any = true; }
+    if (any) {
+        idv = { wb_asf(ids[0]), wb_asf(ids[1]), wb_asf(ids[2]), wb_asf(ids[3]) };
+        wnode[(size_t)w * 8 + 6] = idv;
+        qnode[(size_t)w * 4 + 3] = idv;
+    }
+}
+
+// sum of the surface areas of all binary nodes (the binary tree's expected fetches per ray, same informational figure)
+__global__ __launch_bounds__(WB_BLOCK) void wb_area_kernel(const MptVec4 *__restrict__ fnode, int ni, double *__restrict__ area_sum) {
+    const int b = blockIdx.x * WB_BLOCK + threadIdx.x;
+    double a = 0.0;
+    if (b < ni) {
+        WbChild ch[2];
+        wb_children_of(fnode, b, ch);
+        WbChild own = ch[0];
+        for (int k = 0; k < 3; k++) { own.lo[k] = fminf(ch[0].lo[k], ch[1].lo[k]); own.hi[k] = fmaxf(ch[0].hi[k], ch[1].hi[k]); }
+        a = (double)wb_area(own);
+    }
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if ((threadIdx.x & 63) == 0 && a != 0.0) atomicAdd(area_sum, a);
+}
+
+MPT_KERNEL_API hipError_t mpt_wide_scan_bytes(int ni, size_t *bytes) {
+    int *p = nullptr;
+    return rocprim::exclusive_scan(nullptr, *bytes, p, p, 0, (size_t)std::max(ni, 1), rocprim::plus<int>());
+}
+
+// Builds the wide records of the binary tree in fnode (ni = n - 1 internal nodes) into wnode [ni][8] / qnode [ni][4]
+// (capacity: one wide node per binary node, the worst case).  Outputs: *nwide, *depth (levels), area sums [0] over the wide
+// nodes' source nodes, [1] over all binary nodes.  Reads back one integer per level (<= ~20 levels).
+MPT_KERNEL_API hipError_t mpt_wide_build(const MptVec4 *fnode, int n, MptVec4 *wnode, MptVec4 *qnode, int *bin_of, int *ncount,
+                                     int *offset, void *scan_tmp, size_t scan_bytes, double *d_area, int *nwide, int *depth,
+                                     double area[2], hipStream_t stream) {
+    const int ni = n > 1 ? n - 1 : 0;
+    *nwide = 0; *depth = 0; area[0] = area[1] = 0.0;
+    if (ni < 1) return hipSuccess;
+    hipError_t e;
+    if ((e = hipMemsetAsync(d_area, 0, 2 * sizeof(double), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(bin_of, 0, sizeof(int), stream)) != hipSuccess) return e;        // wide node 0 grows from the root
+    hipLaunchKernelGGL(wb_area_kernel, dim3((ni + WB_BLOCK - 1) / WB_BLOCK), dim3(WB_BLOCK), 0, stream, fnode, ni, d_area + 1);
+    int lo = 0, count = 1, levels = 0;
+    while (count > 0) {
+        levels++;
+        const int grid = (count + WB_BLOCK - 1) / WB_BLOCK;
+        hipLaunchKernelGGL(wb_expand_kernel, dim3(grid), dim3(WB_BLOCK), 0, stream, fnode, bin_of, lo, count, ~n, wnode, qnode, ncount,
+                           d_area);
+        if ((e = rocprim::exclusive_scan(scan_tmp, scan_bytes, ncount, offset, 0, (size_t)count, rocprim::plus<int>(), stream)) != hipSuccess) return e;
+        int last[2] = { 0, 0 };
+        if ((e = hipMemcpyAsync(&last[0], offset + (count - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(&last[1], ncount + (count - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        const int made = last[0] + last[1];
+        if (lo + count + made > ni) return hipErrorInvalidValue;            // (a binary tree has ni internal nodes: cannot happen)
+        if (made > 0)
+            hipLaunchKernelGGL(wb_link_kernel, dim3(grid), dim3(WB_BLOCK), 0, stream, lo, count, lo + count, offset, wnode, qnode, bin_of);
+        lo += count; count = made;
+    }
+    if ((e = hipMemcpyAsync(area, d_area, 2 * sizeof(double), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    *nwide = lo; *depth = levels;
+    return hipGetLastError();
+}

@@ -923,6 +923,49 @@ def test_gpu_lbvh_build_equals_host_build(fresh, n):
     assert sorted(trees[1]['leaf']) == list(range(n))
 
 
+def _wide_records(c, n):
+    import ctypes as C
+    from ptina_amd import _lib
+    nw = C.c_int(0)
+    c.call('mpt_get_wide', None, None, 0, C.byref(nw))
+    w = np.zeros((max(nw.value, 1), 8, 4), np.float32)
+    q = np.zeros((max(nw.value, 1), 4, 4), np.float32)
+    c.call('mpt_get_wide', _lib.fptr(w), _lib.fptr(q), nw.value, C.byref(nw))
+    return w[:nw.value].view(np.uint32), q[:nw.value].view(np.uint32)
+
+
+@pytest.mark.parametrize('name,kw', [('s978', {}), ('c5', {'n': 60000}), ('s34', {})])
+def test_device_wide_collapse_equals_the_host_pass(fresh, name, kw):
+    '''the 4-wide collapse the gather kernels walk (128-byte records with exact boxes, 64-byte records with 8-bit boxes
+    rounded outwards), built on the device level by level (wide_build.hip) == the round-2 host pass over downloaded
+    records, byte for byte, on the SAH tree and on the plain LBVH; unused child slots name the NaN triangle of slot n'''
+    from ptina_amd.things import BVHTree
+    from ptina_amd.common import ctx, reset_all
+    scene = scenes.get_scene(name, **kw)
+    n = scene[1].shape[0]
+    for tree in (1, 0):
+        recs = {}
+        for dev in (1, 0):
+            reset_all()
+            _engine(None, scene, 16, 16, mode='fast', max_faces=max(n + 1, 1 << 21))
+            c = ctx()
+            c.set_option('tree', tree)
+            c.set_option('wide_build', dev)
+            BVHTree().build()
+            recs[dev] = _wide_records(c, n) + (c.get_option('wide_nodes'), c.get_option('wide_depth'), c.get_option('wide_ratio_permille'))
+        reset_all()
+        assert recs[1][2] == recs[0][2] > 0 and recs[1][3] == recs[0][3]
+        assert abs(recs[1][4] - recs[0][4]) <= 1
+        assert np.array_equal(recs[1][0], recs[0][0]), f'{name} tree {tree}: exact-box records differ'
+        assert np.array_equal(recs[1][1], recs[0][1]), f'{name} tree {tree}: quantised records differ'
+        ids = recs[1][0][:, 6, :].view(np.int32)
+        nw = recs[1][2]
+        assert ((ids < nw) & (ids >= -(n + 1))).all() and (ids != 0).all()         # nobody's child is the root
+        assert np.array_equal(np.sort(ids[ids > 0]), np.arange(1, nw))             # every wide node but the root has one parent
+        leaves = ~ids[(ids < 0) & (ids != ~n)]
+        assert np.array_equal(np.sort(leaves), np.arange(n))                       # every triangle in exactly one slot
+
+
 def test_render_does_not_depend_on_where_the_tree_was_built(fresh):
     from ptina_amd.things import FilmTable
     from ptina_amd.common import ctx, reset_all
