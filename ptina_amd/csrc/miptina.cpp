@@ -198,7 +198,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     for (int k = 0; k < MPT_MAX_PIPE; k++) hipFree(c->stack_spill2[k]);
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
-    hipFree(c->gather_buf); hipFree(c->d_pieces);
+    hipFree(c->gather_buf); hipFree(c->d_pieces); hipFree(c->sah_ws);
     hipFree(c->wb_bin_of); hipFree(c->wb_ncount); hipFree(c->wb_offset); hipFree(c->wb_scan); hipFree(c->wb_area);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
     if (c->h_watchdog) hipHostFree(c->h_watchdog);
@@ -307,6 +307,9 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->node_soa = value ? 1 : 0;
     } else if (k == "wide") {
         c->use_wide = value ? 1 : 0;
+    } else if (k == "sah_build") {
+        if (value < -1 || value > 1) return fail("sah_build must be -1 (auto), 0 (host) or 1 (device)");
+        if (value != c->sah_build) { c->sah_build = value; c->tree_valid = false; }
     } else if (k == "wide_build") {
         if ((value ? 1 : 0) != c->wide_build) { c->wide_build = value ? 1 : 0; c->tree_valid = false; }
     } else if (k == "wide_quant") {
@@ -354,6 +357,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "wide") *value = c->use_wide;
     else if (k == "wide_quant") *value = c->use_quant;
     else if (k == "wide_build") *value = c->wide_build;
+    else if (k == "sah_build") *value = c->sah_build;
     else if (k == "wide_nodes") *value = c->wide_nodes;
     else if (k == "wide_ratio_permille") *value = (int)(c->wide_ratio * 1000.f + 0.5f);
     else if (k == "wide_depth") *value = c->wide_depth;

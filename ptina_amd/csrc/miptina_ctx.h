@@ -55,6 +55,10 @@ struct MptLbvhBuffers {
     int *depth;
     MptVec4 *snode, *fnode, *tgeo, *tshade;
 };
+MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n);
+MPT_KERNEL_API size_t mpt_sah_seg_words(void);
+MPT_KERNEL_API hipError_t mpt_sah_scan_bytes(int n, size_t *bytes);
+MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipStream_t stream);
 MPT_KERNEL_API hipError_t mpt_wide_scan_bytes(int ni, size_t *bytes);
 MPT_KERNEL_API hipError_t mpt_wide_build(const MptVec4 *fnode, int n, MptVec4 *wnode, MptVec4 *qnode, int *bin_of, int *ncount,
                                      int *offset, void *scan_tmp, size_t scan_bytes, double *d_area, int *nwide, int *depth,
@@ -128,6 +132,10 @@ struct mpt_ctx {
     MptVec4 *wnode = nullptr; size_t wnode_cap = 0;   // 4-wide nodes of the fast tree (gather kernel), 8 float4 each
     int wide_nodes = 0, wide_depth = 0;               // 0 nodes: not built (scene fits LDS, or too deep)
     float wide_ratio = 1.f;                           // expected fetches per ray, wide / binary (surface-area sums)
+    int sah_build = -1;                               // SAH re-partition: 1 on the device (sah_build.hip), 0 host pass, -1 auto
+                                                      // (device above 32768 faces: the host's exact sweep is the better tree
+                                                      // for small scenes and costs them milliseconds)
+    void *sah_ws = nullptr; size_t sah_ws_bytes = 0;  // one allocation, carved up in build_sah_device
     int wide_build = 1;                               // 1: the 4-wide collapse runs on the device (wide_build.hip), 0: host pass
     int *wb_bin_of = nullptr, *wb_ncount = nullptr, *wb_offset = nullptr; void *wb_scan = nullptr; size_t wb_scan_bytes = 0;
     double *wb_area = nullptr; size_t wb_cap = 0;

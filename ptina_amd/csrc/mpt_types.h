@@ -63,6 +63,22 @@ struct MptLight {              // light/__init__.py:14-18
 // one contiguous float4 range of the film gather's pack / unpack (comm.cpp): count elements from src to dst
 struct MptPiece { long long src, dst, count; };
 
+// device workspace of the SAH re-partition (sah_build.hip); capacities: n leaf slots, SC = mpt_sah_seg_capacity(n) segments
+struct MptSahBuffers {
+    const float *verts; const int *leaf; int n;          // the LBVH build's inputs / leaf order, on the device
+    float *plo, *phi, *pct;                              // [n][3] box and centre per leaf slot
+    int *idx[2], *seg[2];                                // [n] slot permutation and segment of every position (double-buffered)
+    int *pred, *pscan;                                   // [n]
+    int *sb[2], *se[2], *snode[2];                       // [SC] segment tables (double-buffered)
+    int *segw;                                           // [SC][mpt_sah_seg_words()] bounds + bins
+    int *dec, *flag, *foff;                              // [SC][4], [2 SC], [2 SC]
+    int *small;                                          // [n / 2 + 1][4]
+    int *counters;                                       // [4]: small segments, depth
+    int *child; float *blo, *bhi;                        // [n-1][2], [n-1][3], [n-1][3]
+    void *scan_tmp; size_t scan_bytes;
+    MptVec4 *fnode;                                      // out: [n-1][4]
+};
+
 struct MptImage { int32_t nx, ny, base, pad; };   // image.py:14-16
 
 // LDS-resident kernel: bytes from one node record to the next in LDS.  72, not 64: a ds_read_b64 is served in two

@@ -1,0 +1,429 @@
+// sah_build.hip -- the SAH re-partition of the fast build's leaves, on the device.
+//
+// The production traversal walks a better tree than the reference's LBVH over the SAME leaf slots (the image does not
+// depend on the tree's shape, only on which of two equal-depth hits wins).  Round 2 built it on the host (a threaded
+// recursive pass: 0.22 s at 1 M triangles, plus the leaf order down and 64 MB of node records up).  Here it is built on
+// the device, top-down and level by level:
+//   prims     per leaf slot: box and box centre of its triangle
+//   per level, for the segments (ranges of the slot permutation) with more than 32 triangles:
+//     bounds   per segment: bounds of the centres and of the boxes (wave-reduced ordered-int atomics)
+//     bin      32 bins per axis over the centre bounds: count and box per bin (atomics)
+//     choose   one lane per segment: SAH cost of the 3 x 31 splits (area x count on both sides), best one; the node's
+//              number follows from the range sizes (DFS pre-order: left child me + 1, right child me + left size), so no
+//              counter is shared; children with <= 32 triangles go to the small list, single triangles become leaves
+//     scatter  stable partition of every segment by its split (one global prefix sum of the predicates)
+//   small     one lane per small segment: the exact sweep (every split of every axis, sorted by centre) of the host pass,
+//              down to the leaves
+//   pack      the 64-byte traversal records (both children's boxes + ids)
+// Same cost function, bin count and tie rules as the host pass (tree_build.cpp SahBuild); segments between 33 and 8192
+// triangles are binned here where the host sweeps them exactly, so the trees differ slightly (measured: C5 28.1 node
+// fetches per ray against 27.95) -- films agree up to equal-depth ties like any two trees (tests).  Deterministic: every
+// decision is a function of sums of integers and min / max of floats.
+
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include <cmath>
+#include "mpt_types.h"
+
+#define SB_BLOCK 256
+#define SB_BINS 32
+#define SB_SMALL 32            // segments of at most this many triangles are finished by one lane (exact sweep)
+#define SB_SEG_WORDS (12 + 3 * SB_BINS + 3 * SB_BINS * 6)
+
+__device__ __forceinline__ int sb_f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float sb_ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__device__ __forceinline__ float sb_half_area(const float *l, const float *h) {
+    const float dx = fmaxf(h[0] - l[0], 0.f), dy = fmaxf(h[1] - l[1], 0.f), dz = fmaxf(h[2] - l[2], 0.f);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// per leaf slot: box and centre of its triangle (verts [3n][8], leaf: slot -> face)
+__global__ __launch_bounds__(SB_BLOCK) void sb_prims_kernel(const float *__restrict__ verts, const int *__restrict__ leaf, int n,
+                                                           float *__restrict__ plo, float *__restrict__ phi, float *__restrict__ pct,
+                                                           int *__restrict__ idx, int *__restrict__ seg) {
+    const int slot = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (slot >= n) return;
+    const float *p0 = verts + (size_t)leaf[slot] * 24, *p1 = p0 + 8, *p2 = p0 + 16;
+    for (int a = 0; a < 3; a++) {
+        const float l = fminf(fminf(p0[a], p1[a]), p2[a]), h = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
+        plo[(size_t)slot * 3 + a] = l; phi[(size_t)slot * 3 + a] = h; pct[(size_t)slot * 3 + a] = 0.5f * (l + h);
+    }
+    idx[slot] = slot; seg[slot] = 0;
+}
+
+// per-segment words: [0..5] centre bounds lo3 hi3, [6..11] box bounds lo3 hi3 (ordered ints), then bin counts [3][32],
+// then bin boxes [3][32][6] (ordered ints)
+__global__ __launch_bounds__(SB_BLOCK) void sb_reset_kernel(int nseg, int *__restrict__ sw) {
+    const size_t t = (size_t)blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (t >= (size_t)nseg * SB_SEG_WORDS) return;
+    const int w = (int)(t % SB_SEG_WORDS);
+    int v;
+    if (w < 12) v = (w % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+    else if (w < 12 + 3 * SB_BINS) v = 0;
+    else v = ((w - 12 - 3 * SB_BINS) % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+    sw[t] = v;
+}
+
+__global__ __launch_bounds__(SB_BLOCK) void sb_bounds_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
+                                                            const float *__restrict__ pct, const float *__restrict__ plo,
+                                                            const float *__restrict__ phi, int *__restrict__ sw) {
+    const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
+    const int s = i < n ? seg[i] : -1;
+    int v[12];
+    if (s >= 0) {
+        const int slot = idx[i];
+        for (int a = 0; a < 3; a++) {
+            const int c = sb_f2ord(pct[(size_t)slot * 3 + a]);
+            v[a] = c; v[3 + a] = c;
+            v[6 + a] = sb_f2ord(plo[(size_t)slot * 3 + a]); v[9 + a] = sb_f2ord(phi[(size_t)slot * 3 + a]);
+        }
+    } else {
+        for (int k = 0; k < 12; k++) v[k] = (k % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+    }
+    // a wave whose lanes all belong to one segment (the rule near the root) reduces first: one atomic per word and wave
+    const int s0 = __shfl(s, 0);
+    if (__all(s == s0)) {
+        if (s0 < 0) return;
+        for (int k = 0; k < 12; k++)
+            for (int off = 32; off > 0; off >>= 1) {
+                const int o = __shfl_xor(v[k], off);
+                v[k] = (k % 6) < 3 ? min(v[k], o) : max(v[k], o);
+            }
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 12; k++) {
+                if ((k % 6) < 3) atomicMin(sw + (size_t)s0 * SB_SEG_WORDS + k, v[k]);
+                else atomicMax(sw + (size_t)s0 * SB_SEG_WORDS + k, v[k]);
+            }
+    } else if (s >= 0) {
+        for (int k = 0; k < 12; k++) {
+            if ((k % 6) < 3) atomicMin(sw + (size_t)s * SB_SEG_WORDS + k, v[k]);
+            else atomicMax(sw + (size_t)s * SB_SEG_WORDS + k, v[k]);
+        }
+    }
+}
+
+__device__ __forceinline__ int sb_bin_of(float c, float cl, float scale) {
+    return min(SB_BINS - 1, max(0, (int)((c - cl) * scale)));
+}
+
+__global__ __launch_bounds__(SB_BLOCK) void sb_bin_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
+                                                         const float *__restrict__ pct, const float *__restrict__ plo,
+                                                         const float *__restrict__ phi, int *__restrict__ sw) {
+    // A workgroup whose 256 positions all belong to one segment (every workgroup near the root, where a million lanes would
+    // otherwise hammer 96 bins of one segment: 14 ms for the first level alone) bins into LDS and merges once
+    __shared__ int lb[3 * SB_BINS * 7];               // [axis][bin]{count, lo3, hi3}
+    const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
+    const int s = i < n ? seg[i] : -2;
+    const int sfirst = seg[min((int)(blockIdx.x * SB_BLOCK), n - 1)];
+    const bool uniform = __syncthreads_and(s == sfirst || s == -2) != 0;
+    if (uniform) {
+        if (sfirst < 0) return;
+        for (int k = threadIdx.x; k < 3 * SB_BINS * 7; k += SB_BLOCK) {
+            const int f = k % 7;
+            lb[k] = f == 0 ? 0 : (f < 4 ? 0x7fffffff : (int)0x80000000);
+        }
+        __syncthreads();
+    }
+    if (s >= 0) {
+        const int slot = idx[i];
+        int *w = sw + (size_t)s * SB_SEG_WORDS;
+        int bl[3], bh[3];
+        for (int a = 0; a < 3; a++) { bl[a] = sb_f2ord(plo[(size_t)slot * 3 + a]); bh[a] = sb_f2ord(phi[(size_t)slot * 3 + a]); }
+        for (int a = 0; a < 3; a++) {
+            const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
+            if (!(ch > cl)) continue;
+            const float scale = SB_BINS / (ch - cl);
+            const int q = sb_bin_of(pct[(size_t)slot * 3 + a], cl, scale);
+            if (uniform) {
+                int *e = lb + (a * SB_BINS + q) * 7;
+                atomicAdd(e, 1);
+                for (int r = 0; r < 3; r++) { atomicMin(e + 1 + r, bl[r]); atomicMax(e + 4 + r, bh[r]); }
+            } else {
+                atomicAdd(w + 12 + a * SB_BINS + q, 1);
+                int *bb = w + 12 + 3 * SB_BINS + (a * SB_BINS + q) * 6;
+                for (int r = 0; r < 3; r++) { atomicMin(bb + r, bl[r]); atomicMax(bb + 3 + r, bh[r]); }
+            }
+        }
+    }
+    if (uniform) {
+        __syncthreads();
+        int *w = sw + (size_t)sfirst * SB_SEG_WORDS;
+        for (int k = threadIdx.x; k < 3 * SB_BINS; k += SB_BLOCK) {
+            const int *e = lb + k * 7;
+            if (e[0] == 0) continue;
+            atomicAdd(w + 12 + k, e[0]);
+            int *bb = w + 12 + 3 * SB_BINS + k * 6;
+            for (int r = 0; r < 3; r++) { atomicMin(bb + r, e[1 + r]); atomicMax(bb + 3 + r, e[4 + r]); }
+        }
+    }
+}
+
+// dec[s] = {axis (-1: split the range in half), first bin of the right side, m (first position of the right side), -}
+// flag[2 s + k] = 1: child k is a segment of the next level.  small: {b, e, node, level} per small segment.
+__global__ __launch_bounds__(SB_BLOCK) void sb_choose_kernel(int nseg, const int *__restrict__ sb, const int *__restrict__ se,
+                                                            const int *__restrict__ snode, const int *__restrict__ sw, int level,
+                                                            int *__restrict__ child, float *__restrict__ blo, float *__restrict__ bhi,
+                                                            int *__restrict__ dec, int *__restrict__ flag, int *__restrict__ small,
+                                                            int *__restrict__ counters) {
+    const int s = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (s >= nseg) return;
+    const int b = sb[s], e = se[s], me = snode[s], cnt = e - b;
+    const int *w = sw + (size_t)s * SB_SEG_WORDS;
+    for (int a = 0; a < 3; a++) { blo[(size_t)me * 3 + a] = sb_ord2f(w[6 + a]); bhi[(size_t)me * 3 + a] = sb_ord2f(w[9 + a]); }
+    float best = INFINITY;
+    int best_axis = -1, best_k = -1, best_q = 0;
+    for (int a = 0; a < 3; a++) {
+        const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
+        if (!(ch > cl)) continue;
+        const int *bc = w + 12 + a * SB_BINS;
+        const int *bb = w + 12 + 3 * SB_BINS + a * SB_BINS * 6;
+        float ra[SB_BINS]; int rc[SB_BINS];
+        float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
+        int c2 = 0;
+        for (int q = SB_BINS - 1; q > 0; q--) {
+            c2 += bc[q];
+            if (bc[q]) for (int r = 0; r < 3; r++) { l[r] = fminf(l[r], sb_ord2f(bb[q * 6 + r])); h[r] = fmaxf(h[r], sb_ord2f(bb[q * 6 + 3 + r])); }
+            ra[q] = sb_half_area(l, h); rc[q] = c2;
+        }
+        for (int r = 0; r < 3; r++) { l[r] = INFINITY; h[r] = -INFINITY; }
+        int c1 = 0;
+        for (int q = 1; q < SB_BINS; q++) {
+            c1 += bc[q - 1];
+            if (bc[q - 1]) for (int r = 0; r < 3; r++) { l[r] = fminf(l[r], sb_ord2f(bb[(q - 1) * 6 + r])); h[r] = fmaxf(h[r], sb_ord2f(bb[(q - 1) * 6 + 3 + r])); }
+            if (c1 == 0 || rc[q] == 0) continue;
+            const float cost = sb_half_area(l, h) * c1 + ra[q] * rc[q];
+            if (cost < best) { best = cost; best_axis = a; best_k = c1; best_q = q; }
+        }
+    }
+    const int m = best_axis < 0 ? b + cnt / 2 : b + best_k;          // all centres equal: split the range in half
+    dec[s * 4 + 0] = best_axis; dec[s * 4 + 1] = best_q; dec[s * 4 + 2] = m; dec[s * 4 + 3] = 0;
+    const int node[2] = { me + 1, me + (m - b) };
+    const int lo_[2] = { b, m }, hi_[2] = { m, e };
+    for (int k = 0; k < 2; k++) {
+        const int sz = hi_[k] - lo_[k];
+        flag[2 * s + k] = 0;
+        if (sz == 1) continue;                                       // a leaf: the scatter pass writes ~slot
+        child[(size_t)me * 2 + k] = node[k];
+        if (sz <= SB_SMALL) {
+            const int at = atomicAdd(counters + 0, 1);
+            small[at * 4 + 0] = lo_[k]; small[at * 4 + 1] = hi_[k]; small[at * 4 + 2] = node[k]; small[at * 4 + 3] = level + 1;
+        } else {
+            flag[2 * s + k] = 1;
+        }
+    }
+    atomicMax(counters + 1, level);
+}
+
+__global__ __launch_bounds__(SB_BLOCK) void sb_newseg_kernel(int nseg, const int *__restrict__ sb, const int *__restrict__ se,
+                                                            const int *__restrict__ snode, const int *__restrict__ dec,
+                                                            const int *__restrict__ flag, const int *__restrict__ foff,
+                                                            int *__restrict__ sb2, int *__restrict__ se2, int *__restrict__ snode2) {
+    const int s = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (s >= nseg) return;
+    const int b = sb[s], e = se[s], me = snode[s], m = dec[s * 4 + 2];
+    if (flag[2 * s + 0]) { const int ns = foff[2 * s + 0]; sb2[ns] = b; se2[ns] = m; snode2[ns] = me + 1; }
+    if (flag[2 * s + 1]) { const int ns = foff[2 * s + 1]; sb2[ns] = m; se2[ns] = e; snode2[ns] = me + (m - b); }
+}
+
+__global__ __launch_bounds__(SB_BLOCK) void sb_pred_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
+                                                          const float *__restrict__ pct, const int *__restrict__ sw,
+                                                          const int *__restrict__ dec, int *__restrict__ pred) {
+    const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int s = seg[i];
+    int p = 0;
+    if (s >= 0) {
+        const int a = dec[s * 4 + 0];
+        if (a < 0) p = i < dec[s * 4 + 2];
+        else {
+            const int *w = sw + (size_t)s * SB_SEG_WORDS;
+            const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
+            const float scale = SB_BINS / (ch - cl);
+            p = sb_bin_of(pct[(size_t)idx[i] * 3 + a], cl, scale) < dec[s * 4 + 1];
+        }
+    }
+    pred[i] = p;
+}
+
+__global__ __launch_bounds__(SB_BLOCK) void sb_scatter_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
+                                                             const int *__restrict__ pred, const int *__restrict__ pscan,
+                                                             const int *__restrict__ sb, const int *__restrict__ se,
+                                                             const int *__restrict__ snode, const int *__restrict__ dec,
+                                                             const int *__restrict__ flag, const int *__restrict__ foff,
+                                                             int *__restrict__ child, int *__restrict__ idx2, int *__restrict__ seg2) {
+    const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int s = seg[i], slot = idx[i];
+    if (s < 0) { idx2[i] = slot; seg2[i] = -1; return; }
+    const int b = sb[s], e = se[s], m = dec[s * 4 + 2], me = snode[s];
+    const int left_before = pscan[i] - pscan[b];
+    const int k = pred[i] ? 0 : 1;
+    const int dest = k == 0 ? b + left_before : m + ((i - b) - left_before);
+    idx2[dest] = slot;
+    const int sz = k == 0 ? m - b : e - m;
+    if (sz == 1) child[(size_t)me * 2 + k] = ~slot;
+    seg2[dest] = flag[2 * s + k] ? foff[2 * s + k] : -1;
+}
+
+// one lane per small segment: exact sweep SAH (tree_build.cpp SahBuild::split, the path for ranges <= 8192) down to the leaves
+__global__ __launch_bounds__(64) void sb_small_kernel(int nsmall, const int *__restrict__ small, int *__restrict__ idx,
+                                                     const float *__restrict__ pct, const float *__restrict__ plo,
+                                                     const float *__restrict__ phi, int *__restrict__ child, float *__restrict__ blo,
+                                                     float *__restrict__ bhi, int *__restrict__ counters) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= nsmall) return;
+    const int b0 = small[t * 4 + 0], e0 = small[t * 4 + 1];
+    int ids[SB_SMALL];
+    for (int k = 0; k < e0 - b0; k++) ids[k] = idx[b0 + k];
+    int stb[SB_SMALL], ste[SB_SMALL], stn[SB_SMALL], std_[SB_SMALL];
+    int sp = 0, maxdep = 0;
+    stb[0] = 0; ste[0] = e0 - b0; stn[0] = small[t * 4 + 2]; std_[0] = small[t * 4 + 3]; sp = 1;
+    while (sp > 0) {
+        sp--;
+        const int b = stb[sp], e = ste[sp], me = stn[sp], dep = std_[sp], cnt = e - b;
+        maxdep = max(maxdep, dep);
+        float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
+        float cl[3] = { INFINITY, INFINITY, INFINITY }, ch[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (int q = b; q < e; q++)
+            for (int a = 0; a < 3; a++) {
+                l[a] = fminf(l[a], plo[(size_t)ids[q] * 3 + a]); h[a] = fmaxf(h[a], phi[(size_t)ids[q] * 3 + a]);
+                cl[a] = fminf(cl[a], pct[(size_t)ids[q] * 3 + a]); ch[a] = fmaxf(ch[a], pct[(size_t)ids[q] * 3 + a]);
+            }
+        for (int a = 0; a < 3; a++) { blo[(size_t)me * 3 + a] = l[a]; bhi[(size_t)me * 3 + a] = h[a]; }
+        float best = INFINITY;
+        int best_axis = -1, best_k = -1;
+        int ord[SB_SMALL];
+        float rarea[SB_SMALL];
+        for (int a = 0; a < 3; a++) {
+            if (!(ch[a] > cl[a])) continue;
+            for (int q = 0; q < cnt; q++) {                        // insertion sort by (centre, slot): std::sort on pairs
+                const int s = ids[b + q];
+                const float key = pct[(size_t)s * 3 + a];
+                int p = q;
+                while (p > 0) {
+                    const int o = ord[p - 1];
+                    const float ko = pct[(size_t)o * 3 + a];
+                    if (ko < key || (ko == key && o < s)) break;
+                    ord[p] = o; p--;
+                }
+                ord[p] = s;
+            }
+            float rl[3] = { INFINITY, INFINITY, INFINITY }, rh[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (int q = cnt - 1; q > 0; q--) {
+                const int s = ord[q];
+                for (int r = 0; r < 3; r++) { rl[r] = fminf(rl[r], plo[(size_t)s * 3 + r]); rh[r] = fmaxf(rh[r], phi[(size_t)s * 3 + r]); }
+                rarea[q] = sb_half_area(rl, rh);
+            }
+            for (int r = 0; r < 3; r++) { rl[r] = INFINITY; rh[r] = -INFINITY; }
+            for (int k = 1; k < cnt; k++) {
+                const int s = ord[k - 1];
+                for (int r = 0; r < 3; r++) { rl[r] = fminf(rl[r], plo[(size_t)s * 3 + r]); rh[r] = fmaxf(rh[r], phi[(size_t)s * 3 + r]); }
+                const float cost = sb_half_area(rl, rh) * k + rarea[k] * (cnt - k);
+                if (cost < best) { best = cost; best_axis = a; best_k = k; }
+            }
+        }
+        int m = b + cnt / 2;
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            for (int q = 0; q < cnt; q++) {
+                const int s = ids[b + q];
+                const float key = pct[(size_t)s * 3 + a];
+                int p = q;
+                while (p > 0) {
+                    const int o = ord[p - 1];
+                    const float ko = pct[(size_t)o * 3 + a];
+                    if (ko < key || (ko == key && o < s)) break;
+                    ord[p] = o; p--;
+                }
+                ord[p] = s;
+            }
+            for (int q = 0; q < cnt; q++) ids[b + q] = ord[q];
+            m = b + best_k;
+        }
+        const int left = me + 1, right = me + (m - b);
+        if (m - b == 1) child[(size_t)me * 2 + 0] = ~ids[b];
+        else { child[(size_t)me * 2 + 0] = left; stb[sp] = b; ste[sp] = m; stn[sp] = left; std_[sp] = dep + 1; sp++; }
+        if (e - m == 1) child[(size_t)me * 2 + 1] = ~ids[m];
+        else { child[(size_t)me * 2 + 1] = right; stb[sp] = m; ste[sp] = e; stn[sp] = right; std_[sp] = dep + 1; sp++; }
+    }
+    atomicMax(counters + 1, maxdep);
+}
+
+// the 64-byte traversal record: {c0.lo.x, c1.lo.x, c0.hi.x, c1.hi.x} {y} {z} {id0, id1, 0, 0}
+__global__ __launch_bounds__(SB_BLOCK) void sb_pack_kernel(int ni, const int *__restrict__ child, const float *__restrict__ blo,
+                                                          const float *__restrict__ bhi, const float *__restrict__ plo,
+                                                          const float *__restrict__ phi, MptVec4 *__restrict__ fnode) {
+    const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (i >= ni) return;
+    float l[2][3], h[2][3];
+    int id[2];
+    for (int k = 0; k < 2; k++) {
+        id[k] = child[(size_t)i * 2 + k];
+        const float *sl = id[k] < 0 ? plo + (size_t)(~id[k]) * 3 : blo + (size_t)id[k] * 3;
+        const float *sh = id[k] < 0 ? phi + (size_t)(~id[k]) * 3 : bhi + (size_t)id[k] * 3;
+        for (int a = 0; a < 3; a++) { l[k][a] = sl[a]; h[k][a] = sh[a]; }
+    }
+    for (int a = 0; a < 3; a++) fnode[(size_t)i * 4 + a] = { l[0][a], l[1][a], h[0][a], h[1][a] };
+    fnode[(size_t)i * 4 + 3] = { __int_as_float(id[0]), __int_as_float(id[1]), 0.f, 0.f };
+}
+
+MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n) { return (size_t)n / (SB_SMALL + 1) + 2; }
+MPT_KERNEL_API size_t mpt_sah_seg_words(void) { return SB_SEG_WORDS; }
+MPT_KERNEL_API hipError_t mpt_sah_scan_bytes(int n, size_t *bytes) {
+    int *p = nullptr;
+    return rocprim::exclusive_scan(nullptr, *bytes, p, p, 0, (size_t)std::max(n, 2), rocprim::plus<int>());
+}
+
+// verts [3n][8] and leaf [n] on the device (the LBVH build's); writes fnode [n-1][4] and *depth.  Needs n > SB_SMALL.
+MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipStream_t stream) {
+    const int n = B->n, ni = n - 1;
+    if (n <= SB_SMALL) return hipErrorInvalidValue;
+    hipError_t e;
+    const int gp = (n + SB_BLOCK - 1) / SB_BLOCK;
+    if ((e = hipMemsetAsync(B->counters, 0, 4 * sizeof(int), stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(sb_prims_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, B->verts, B->leaf, n, B->plo, B->phi, B->pct, B->idx[0], B->seg[0]);
+    int seed[3] = { 0, n, 0 };
+    if ((e = hipMemcpyAsync(B->sb[0], &seed[0], sizeof(int), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(B->se[0], &seed[1], sizeof(int), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(B->snode[0], &seed[2], sizeof(int), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    int nseg = 1, cur = 0, level = 1;
+    size_t scan_bytes = B->scan_bytes;
+    while (nseg > 0) {
+        if (level > 62) return hipErrorInvalidValue;
+        const int gs = (nseg + SB_BLOCK - 1) / SB_BLOCK;
+        const size_t words = (size_t)nseg * SB_SEG_WORDS;
+        hipLaunchKernelGGL(sb_reset_kernel, dim3((unsigned)((words + SB_BLOCK - 1) / SB_BLOCK)), dim3(SB_BLOCK), 0, stream, nseg, B->segw);
+        hipLaunchKernelGGL(sb_bounds_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->plo, B->phi, B->segw);
+        hipLaunchKernelGGL(sb_bin_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->plo, B->phi, B->segw);
+        hipLaunchKernelGGL(sb_choose_kernel, dim3(gs), dim3(SB_BLOCK), 0, stream, nseg, B->sb[cur], B->se[cur], B->snode[cur], B->segw, level,
+                           B->child, B->blo, B->bhi, B->dec, B->flag, B->small, B->counters);
+        if ((e = rocprim::exclusive_scan(B->scan_tmp, scan_bytes, B->flag, B->foff, 0, (size_t)(2 * nseg), rocprim::plus<int>(), stream)) != hipSuccess) return e;
+        int last[2] = { 0, 0 };
+        if ((e = hipMemcpyAsync(&last[0], B->foff + (2 * nseg - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(&last[1], B->flag + (2 * nseg - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(sb_newseg_kernel, dim3(gs), dim3(SB_BLOCK), 0, stream, nseg, B->sb[cur], B->se[cur], B->snode[cur], B->dec, B->flag,
+                           B->foff, B->sb[cur ^ 1], B->se[cur ^ 1], B->snode[cur ^ 1]);
+        hipLaunchKernelGGL(sb_pred_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->segw, B->dec, B->pred);
+        if ((e = rocprim::exclusive_scan(B->scan_tmp, scan_bytes, B->pred, B->pscan, 0, (size_t)n, rocprim::plus<int>(), stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(sb_scatter_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pred, B->pscan, B->sb[cur],
+                           B->se[cur], B->snode[cur], B->dec, B->flag, B->foff, B->child, B->idx[cur ^ 1], B->seg[cur ^ 1]);
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        nseg = last[0] + last[1];
+        if ((size_t)nseg > mpt_sah_seg_capacity(n)) return hipErrorInvalidValue;
+        cur ^= 1; level++;
+    }
+    int cnt[4] = { 0, 0, 0, 0 };
+    if ((e = hipMemcpyAsync(cnt, B->counters, sizeof cnt, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    if (cnt[0] > 0)
+        hipLaunchKernelGGL(sb_small_kernel, dim3((cnt[0] + 63) / 64), dim3(64), 0, stream, cnt[0], B->small, B->idx[cur], B->pct, B->plo, B->phi,
+                           B->child, B->blo, B->bhi, B->counters);
+    hipLaunchKernelGGL(sb_pack_kernel, dim3((ni + SB_BLOCK - 1) / SB_BLOCK), dim3(SB_BLOCK), 0, stream, ni, B->child, B->blo, B->bhi, B->plo,
+                       B->phi, B->fnode);
+    if ((e = hipMemcpyAsync(cnt, B->counters, sizeof cnt, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    *depth = cnt[1];
+    return hipGetLastError();
+}

@@ -390,6 +390,45 @@ static void pack_fnode(mpt_ctx *c, int n, const std::vector<int32_t> &fchild, co
     }
 }
 
+// workspace of mpt_sah_build: one device allocation carved into the arrays of MptSahBuffers
+static int build_sah_device(mpt_ctx *c) {
+    const int n = c->nfaces, ni = n - 1;
+    const size_t SC = mpt_sah_seg_capacity(n), SW = mpt_sah_seg_words();
+    size_t scan_bytes = 0;
+    HIP_TRY(mpt_sah_scan_bytes((int)std::max<size_t>((size_t)n, 2 * SC), &scan_bytes));
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t f3 = al((size_t)n * 3 * 4), i1 = al((size_t)n * 4), s1 = al(SC * 4);
+    size_t total = 3 * f3 + 6 * i1 + 6 * s1 + al(SC * SW * 4) + al(SC * 16) + 2 * al(2 * SC * 4) + al(((size_t)n / 2 + 1) * 16) + al(16) +
+                   al((size_t)ni * 8) + 2 * al((size_t)ni * 12) + al(std::max<size_t>(scan_bytes, 16));
+    if (total > c->sah_ws_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->sah_ws); c->sah_ws = nullptr; c->sah_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&c->sah_ws, total));
+        c->sah_ws_bytes = total;
+    }
+    char *q = (char *)c->sah_ws;
+    auto take = [&](size_t b) { char *r = q; q += al(b); return r; };
+    MptSahBuffers B{};
+    B.verts = c->d_verts; B.leaf = c->d_leaf; B.n = n;
+    B.plo = (float *)take((size_t)n * 12); B.phi = (float *)take((size_t)n * 12); B.pct = (float *)take((size_t)n * 12);
+    for (int k = 0; k < 2; k++) { B.idx[k] = (int *)take((size_t)n * 4); B.seg[k] = (int *)take((size_t)n * 4); }
+    B.pred = (int *)take((size_t)n * 4); B.pscan = (int *)take((size_t)n * 4);
+    for (int k = 0; k < 2; k++) { B.sb[k] = (int *)take(SC * 4); B.se[k] = (int *)take(SC * 4); B.snode[k] = (int *)take(SC * 4); }
+    B.segw = (int *)take(SC * SW * 4);
+    B.dec = (int *)take(SC * 16); B.flag = (int *)take(2 * SC * 4); B.foff = (int *)take(2 * SC * 4);
+    B.small = (int *)take(((size_t)n / 2 + 1) * 16);
+    B.counters = (int *)take(16);
+    B.child = (int *)take((size_t)ni * 8); B.blo = (float *)take((size_t)ni * 12); B.bhi = (float *)take((size_t)ni * 12);
+    B.scan_tmp = take(std::max<size_t>(scan_bytes, 16)); B.scan_bytes = scan_bytes;
+    B.fnode = c->fnode;
+    int depth = 0;
+    hipError_t e = mpt_sah_build(&B, &depth, c->stream);
+    if (e != hipSuccess) return fail("device SAH build failed: %s", hipGetErrorString(e));
+    if (depth + 2 > 64) return fail("BVH depth %d exceeds the 64-entry traversal stack", depth);
+    c->fast_depth = depth;
+    return 0;
+}
+
 // lbvh.py:297-305 entirely on the device (lbvh_build.hip); only the depth (4 bytes) comes back,
 // plus the leaf order when the fast build wants its SAH re-partition (a host pass today)
 static int build_tree_gpu(mpt_ctx *c) {
@@ -447,7 +486,11 @@ static int build_tree_gpu(mpt_ctx *c) {
     c->tree_depth = depth;
     c->fast_depth = depth;
     c->host_tree_valid = false;
-    if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max) {
+    const bool sah_on_device = c->sah_build == 1 || (c->sah_build < 0 && n > 32768);
+    if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max && sah_on_device && n > 64) {
+        // SAH re-partition of the leaves on the device (sah_build.hip): nothing comes back but the depth
+        if (build_sah_device(c)) return 1;
+    } else if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max) {
         // SAH re-partition of the leaves for the fast build (host pass over the leaf order)
         c->h_leaf.resize(n);
         HIP_TRY(hipMemcpy(c->h_leaf.data(), c->d_leaf, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -966,6 +966,49 @@ def test_device_wide_collapse_equals_the_host_pass(fresh, name, kw):
         assert np.array_equal(np.sort(leaves), np.arange(n))                       # every triangle in exactly one slot
 
 
+def test_device_sah_pass_builds_a_tree_as_good_as_the_host_pass(fresh, oracle_mod):
+    '''the SAH re-partition on the device (sah_build.hip: binned above 32 triangles, the host pass's exact sweep below)
+    against the round-2 host pass (exact sweep up to 8192) on 60 000 random triangles: a valid tree over the same leaf
+    slots (every triangle in exactly one slot of the collapse, DFS numbering, depth within the stack), node fetches and
+    triangle tests per ray within 5 % of the host tree's, the film within the FAST bounds of the host tree's film and of the
+    oracle's on a window; run twice: the same bytes (deterministic)'''
+    from helpers import assert_parity, setup_oracle
+    from ptina_amd.things import FilmTable, BVHTree
+    from ptina_amd.common import ctx, reset_all
+    scene = scenes.get_scene('c5', n=60000)
+    n = scene[1].shape[0]
+    nx, ny, spp = 192, 160, 4
+    out = {}
+    for dev in (1, 0, 1):
+        reset_all()
+        eng = _engine(None, scene, nx, ny, mode='fast', max_faces=n + 1)
+        c = ctx()
+        c.set_option('sah_build', dev)
+        BVHTree().build()
+        w, q = _wide_records(c, n)
+        ids = w[:, 6, :].view(np.int32)
+        nw = c.get_option('wide_nodes')
+        assert nw > 0 and 2 < c.get_option('fast_depth') <= 62
+        assert np.array_equal(np.sort(ids[ids > 0]), np.arange(1, nw))
+        assert np.array_equal(np.sort(~ids[(ids < 0) & (ids != ~n)]), np.arange(n))
+        c.set_option('count', 1)
+        c.call('mpt_reset_counters')
+        eng.render(spp)
+        cnt = c.counters()
+        key = ('dev2' if dev and 'dev' in out else 'dev') if dev else 'host'
+        out[key] = (FilmTable().get_image().copy(), cnt['n_node'] / cnt['rays'], cnt['n_tri'] / cnt['rays'], w.copy(), c.get_option('last_kernel'))
+    reset_all()
+    assert out['dev'][4] == out['host'][4] == 2
+    assert np.array_equal(out['dev'][3], out['dev2'][3]) and np.array_equal(out['dev'][0], out['dev2'][0])
+    print(f'node fetches per ray: device SAH {out["dev"][1]:.2f}, host SAH {out["host"][1]:.2f}; triangle tests {out["dev"][2]:.2f} / {out["host"][2]:.2f}')
+    assert out['dev'][1] <= 1.05 * out['host'][1] and out['dev'][2] <= 1.05 * out['host'][2]
+    assert_parity(out['dev'][0], out['host'][0], *FAST, what='device SAH tree vs host SAH tree')
+    ref = setup_oracle(oracle_mod, scene, nx, ny)
+    ref.set_window(80, 96)
+    ref.render(spp)
+    assert_parity(out['dev'][0][80:96], ref.get_image()[80:96], *FAST, what='device SAH tree vs oracle (16 columns)')
+
+
 def test_render_does_not_depend_on_where_the_tree_was_built(fresh):
     from ptina_amd.things import FilmTable
     from ptina_amd.common import ctx, reset_all
