@@ -307,6 +307,9 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->node_soa = value ? 1 : 0;
     } else if (k == "wide") {
         c->use_wide = value ? 1 : 0;
+    } else if (k == "sah_exact_max") {
+        if (value < 2) return fail("sah_exact_max must be >= 2");
+        c->sah_exact_max = value; c->tree_valid = false;
     } else if (k == "sah_build") {
         if (value < -1 || value > 1) return fail("sah_build must be -1 (auto), 0 (host) or 1 (device)");
         if (value != c->sah_build) { c->sah_build = value; c->tree_valid = false; }

@@ -15,9 +15,10 @@
 //   small     one lane per small segment: the exact sweep (every split of every axis, sorted by centre) of the host pass,
 //              down to the leaves
 //   pack      the 64-byte traversal records (both children's boxes + ids)
-// Same cost function, bin count and tie rules as the host pass (tree_build.cpp SahBuild); segments between 33 and 8192
-// triangles are binned here where the host sweeps them exactly, so the trees differ slightly (measured: C5 28.1 node
-// fetches per ray against 27.95) -- films agree up to equal-depth ties like any two trees (tests).  Deterministic: every
+// Same cost function and tie rules as the host pass (tree_build.cpp SahBuild).  Segments between 33 and 8192 triangles are
+// binned here where the host sweeps them exactly; what that costs depends on the scene and on the bin count (see SB_MAXBINS),
+// so the bins are spent where they matter: as many per axis as a fixed budget divided by the level's segment count allows.
+// Films agree up to equal-depth ties like any two trees (tests).  Deterministic: every
 // decision is a function of sums of integers and min / max of floats.
 
 #include <cstring>
@@ -27,9 +28,21 @@
 #include "mpt_types.h"
 
 #define SB_BLOCK 256
-#define SB_BINS 32
+#ifndef SB_MINBINS
+#define SB_MINBINS 32          // bins per axis at the deep levels (many small segments) ...
+#endif
+#ifndef SB_MAXBINS
+#define SB_MAXBINS 1024        // ... and near the root: as many as SB_BIN_BUDGET / segments allows.  Measured on the 99 382-triangle
+#endif                         // scene of BASELINE config 4 (a dense mesh inside ten huge wall triangles): 32 bins everywhere 10.5
+#ifndef SB_BIN_BUDGET          // node fetches per ray, 128 everywhere 9.97, the host pass (exact sweep up to 8192 leaves) 9.44
+#define SB_BIN_BUDGET (1 << 20)
+#endif
+#ifndef SB_SMALL
 #define SB_SMALL 32            // segments of at most this many triangles are finished by one lane (exact sweep)
-#define SB_SEG_WORDS (12 + 3 * SB_BINS + 3 * SB_BINS * 6)
+#endif
+#define SB_LDS_BINS 64         // up to this many bins a segment-uniform workgroup bins into LDS first
+// words per segment at nb bins: bounds (12) | counts [3][nb] | boxes [3][nb][6] | suffix areas [3][nb] | suffix counts [3][nb]
+#define SB_SEG_WORDS(nb) (12 + 27 * (nb))
 
 __device__ __forceinline__ int sb_f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float sb_ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
@@ -55,20 +68,21 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_prims_kernel(const float *__restr
 
 // per-segment words: [0..5] centre bounds lo3 hi3, [6..11] box bounds lo3 hi3 (ordered ints), then bin counts [3][32],
 // then bin boxes [3][32][6] (ordered ints)
-__global__ __launch_bounds__(SB_BLOCK) void sb_reset_kernel(int nseg, int *__restrict__ sw) {
+__global__ __launch_bounds__(SB_BLOCK) void sb_reset_kernel(int nseg, int nb, int *__restrict__ sw) {
+    const size_t sws = SB_SEG_WORDS(nb);
     const size_t t = (size_t)blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (t >= (size_t)nseg * SB_SEG_WORDS) return;
-    const int w = (int)(t % SB_SEG_WORDS);
-    int v;
+    if (t >= (size_t)nseg * sws) return;
+    const int w = (int)(t % sws);
+    int v = 0;
     if (w < 12) v = (w % 6) < 3 ? 0x7fffffff : (int)0x80000000;
-    else if (w < 12 + 3 * SB_BINS) v = 0;
-    else v = ((w - 12 - 3 * SB_BINS) % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+    else if (w >= 12 + 3 * nb && w < 12 + 21 * nb) v = ((w - 12 - 3 * nb) % 6) < 3 ? 0x7fffffff : (int)0x80000000;
     sw[t] = v;
 }
 
 __global__ __launch_bounds__(SB_BLOCK) void sb_bounds_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
                                                             const float *__restrict__ pct, const float *__restrict__ plo,
-                                                            const float *__restrict__ phi, int *__restrict__ sw) {
+                                                            const float *__restrict__ phi, int nb, int *__restrict__ sw) {
+    const size_t sws = SB_SEG_WORDS(nb);
     const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
     const int s = i < n ? seg[i] : -1;
     int v[12];
@@ -93,34 +107,35 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_bounds_kernel(int n, const int *_
             }
         if ((threadIdx.x & 63) == 0)
             for (int k = 0; k < 12; k++) {
-                if ((k % 6) < 3) atomicMin(sw + (size_t)s0 * SB_SEG_WORDS + k, v[k]);
-                else atomicMax(sw + (size_t)s0 * SB_SEG_WORDS + k, v[k]);
+                if ((k % 6) < 3) atomicMin(sw + (size_t)s0 * sws + k, v[k]);
+                else atomicMax(sw + (size_t)s0 * sws + k, v[k]);
             }
     } else if (s >= 0) {
         for (int k = 0; k < 12; k++) {
-            if ((k % 6) < 3) atomicMin(sw + (size_t)s * SB_SEG_WORDS + k, v[k]);
-            else atomicMax(sw + (size_t)s * SB_SEG_WORDS + k, v[k]);
+            if ((k % 6) < 3) atomicMin(sw + (size_t)s * sws + k, v[k]);
+            else atomicMax(sw + (size_t)s * sws + k, v[k]);
         }
     }
 }
 
-__device__ __forceinline__ int sb_bin_of(float c, float cl, float scale) {
-    return min(SB_BINS - 1, max(0, (int)((c - cl) * scale)));
+__device__ __forceinline__ int sb_bin_of(float c, float cl, float scale, int nb) {
+    return min(nb - 1, max(0, (int)((c - cl) * scale)));
 }
 
 __global__ __launch_bounds__(SB_BLOCK) void sb_bin_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
                                                          const float *__restrict__ pct, const float *__restrict__ plo,
-                                                         const float *__restrict__ phi, int *__restrict__ sw) {
-    // A workgroup whose 256 positions all belong to one segment (every workgroup near the root, where a million lanes would
-    // otherwise hammer 96 bins of one segment: 14 ms for the first level alone) bins into LDS and merges once
-    __shared__ int lb[3 * SB_BINS * 7];               // [axis][bin]{count, lo3, hi3}
+                                                         const float *__restrict__ phi, int nb, int *__restrict__ sw) {
+    // A workgroup whose 256 positions all belong to one segment bins into LDS and merges once (with few bins a segment's
+    // lanes would otherwise hammer the same few words: 14 ms for the first level of a million triangles at 32 bins)
+    __shared__ int lb[3 * SB_LDS_BINS * 7];           // [axis][bin]{count, lo3, hi3}
+    const size_t sws = SB_SEG_WORDS(nb);
     const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
     const int s = i < n ? seg[i] : -2;
     const int sfirst = seg[min((int)(blockIdx.x * SB_BLOCK), n - 1)];
-    const bool uniform = __syncthreads_and(s == sfirst || s == -2) != 0;
+    const bool uniform = nb <= SB_LDS_BINS && __syncthreads_and(s == sfirst || s == -2) != 0;
     if (uniform) {
         if (sfirst < 0) return;
-        for (int k = threadIdx.x; k < 3 * SB_BINS * 7; k += SB_BLOCK) {
+        for (int k = threadIdx.x; k < 3 * nb * 7; k += SB_BLOCK) {
             const int f = k % 7;
             lb[k] = f == 0 ? 0 : (f < 4 ? 0x7fffffff : (int)0x80000000);
         }
@@ -128,68 +143,72 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_bin_kernel(int n, const int *__re
     }
     if (s >= 0) {
         const int slot = idx[i];
-        int *w = sw + (size_t)s * SB_SEG_WORDS;
+        int *w = sw + (size_t)s * sws;
         int bl[3], bh[3];
         for (int a = 0; a < 3; a++) { bl[a] = sb_f2ord(plo[(size_t)slot * 3 + a]); bh[a] = sb_f2ord(phi[(size_t)slot * 3 + a]); }
         for (int a = 0; a < 3; a++) {
             const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
             if (!(ch > cl)) continue;
-            const float scale = SB_BINS / (ch - cl);
-            const int q = sb_bin_of(pct[(size_t)slot * 3 + a], cl, scale);
+            const float scale = nb / (ch - cl);
+            const int q = sb_bin_of(pct[(size_t)slot * 3 + a], cl, scale, nb);
             if (uniform) {
-                int *e = lb + (a * SB_BINS + q) * 7;
+                int *e = lb + (a * nb + q) * 7;
                 atomicAdd(e, 1);
                 for (int r = 0; r < 3; r++) { atomicMin(e + 1 + r, bl[r]); atomicMax(e + 4 + r, bh[r]); }
             } else {
-                atomicAdd(w + 12 + a * SB_BINS + q, 1);
-                int *bb = w + 12 + 3 * SB_BINS + (a * SB_BINS + q) * 6;
+                atomicAdd(w + 12 + a * nb + q, 1);
+                int *bb = w + 12 + 3 * nb + (a * nb + q) * 6;
                 for (int r = 0; r < 3; r++) { atomicMin(bb + r, bl[r]); atomicMax(bb + 3 + r, bh[r]); }
             }
         }
     }
     if (uniform) {
         __syncthreads();
-        int *w = sw + (size_t)sfirst * SB_SEG_WORDS;
-        for (int k = threadIdx.x; k < 3 * SB_BINS; k += SB_BLOCK) {
+        int *w = sw + (size_t)sfirst * sws;
+        for (int k = threadIdx.x; k < 3 * nb; k += SB_BLOCK) {
             const int *e = lb + k * 7;
             if (e[0] == 0) continue;
             atomicAdd(w + 12 + k, e[0]);
-            int *bb = w + 12 + 3 * SB_BINS + k * 6;
+            int *bb = w + 12 + 3 * nb + k * 6;
             for (int r = 0; r < 3; r++) { atomicMin(bb + r, e[1 + r]); atomicMax(bb + 3 + r, e[4 + r]); }
         }
     }
 }
 
+__device__ __forceinline__ void sb_emit(int s, int b, int e, int me, const int *w, int best_axis, int best_k, int best_q, int level,
+                                        int *__restrict__ child, float *__restrict__ blo, float *__restrict__ bhi, int *__restrict__ dec,
+                                        int *__restrict__ flag, int *__restrict__ small, int *__restrict__ counters);
+
 // dec[s] = {axis (-1: split the range in half), first bin of the right side, m (first position of the right side), -}
 // flag[2 s + k] = 1: child k is a segment of the next level.  small: {b, e, node, level} per small segment.
 __global__ __launch_bounds__(SB_BLOCK) void sb_choose_kernel(int nseg, const int *__restrict__ sb, const int *__restrict__ se,
-                                                            const int *__restrict__ snode, const int *__restrict__ sw, int level,
+                                                            const int *__restrict__ snode, int nb, int *__restrict__ sw, int level,
                                                             int *__restrict__ child, float *__restrict__ blo, float *__restrict__ bhi,
                                                             int *__restrict__ dec, int *__restrict__ flag, int *__restrict__ small,
                                                             int *__restrict__ counters) {
     const int s = blockIdx.x * SB_BLOCK + threadIdx.x;
     if (s >= nseg) return;
-    const int b = sb[s], e = se[s], me = snode[s], cnt = e - b;
-    const int *w = sw + (size_t)s * SB_SEG_WORDS;
-    for (int a = 0; a < 3; a++) { blo[(size_t)me * 3 + a] = sb_ord2f(w[6 + a]); bhi[(size_t)me * 3 + a] = sb_ord2f(w[9 + a]); }
+    const int b = sb[s], e = se[s], me = snode[s];
+    int *w = sw + (size_t)s * SB_SEG_WORDS(nb);
     float best = INFINITY;
     int best_axis = -1, best_k = -1, best_q = 0;
     for (int a = 0; a < 3; a++) {
         const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
         if (!(ch > cl)) continue;
-        const int *bc = w + 12 + a * SB_BINS;
-        const int *bb = w + 12 + 3 * SB_BINS + a * SB_BINS * 6;
-        float ra[SB_BINS]; int rc[SB_BINS];
+        const int *bc = w + 12 + a * nb;
+        const int *bb = w + 12 + 3 * nb + a * nb * 6;
+        float *ra = (float *)(w + 12 + 21 * nb + a * nb);         // suffix areas / counts: the segment's own scratch words
+        int *rc = w + 12 + 24 * nb + a * nb;
         float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
         int c2 = 0;
-        for (int q = SB_BINS - 1; q > 0; q--) {
+        for (int q = nb - 1; q > 0; q--) {
             c2 += bc[q];
             if (bc[q]) for (int r = 0; r < 3; r++) { l[r] = fminf(l[r], sb_ord2f(bb[q * 6 + r])); h[r] = fmaxf(h[r], sb_ord2f(bb[q * 6 + 3 + r])); }
             ra[q] = sb_half_area(l, h); rc[q] = c2;
         }
         for (int r = 0; r < 3; r++) { l[r] = INFINITY; h[r] = -INFINITY; }
         int c1 = 0;
-        for (int q = 1; q < SB_BINS; q++) {
+        for (int q = 1; q < nb; q++) {
             c1 += bc[q - 1];
             if (bc[q - 1]) for (int r = 0; r < 3; r++) { l[r] = fminf(l[r], sb_ord2f(bb[(q - 1) * 6 + r])); h[r] = fmaxf(h[r], sb_ord2f(bb[(q - 1) * 6 + 3 + r])); }
             if (c1 == 0 || rc[q] == 0) continue;
@@ -197,6 +216,15 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_choose_kernel(int nseg, const int
             if (cost < best) { best = cost; best_axis = a; best_k = c1; best_q = q; }
         }
     }
+    sb_emit(s, b, e, me, w, best_axis, best_k, best_q, level, child, blo, bhi, dec, flag, small, counters);
+}
+
+// the tail of a segment's decision, shared by both choose kernels: node box, split, children
+__device__ __forceinline__ void sb_emit(int s, int b, int e, int me, const int *w, int best_axis, int best_k, int best_q, int level,
+                                        int *__restrict__ child, float *__restrict__ blo, float *__restrict__ bhi, int *__restrict__ dec,
+                                        int *__restrict__ flag, int *__restrict__ small, int *__restrict__ counters) {
+    const int cnt = e - b;
+    for (int a = 0; a < 3; a++) { blo[(size_t)me * 3 + a] = sb_ord2f(w[6 + a]); bhi[(size_t)me * 3 + a] = sb_ord2f(w[9 + a]); }
     const int m = best_axis < 0 ? b + cnt / 2 : b + best_k;          // all centres equal: split the range in half
     dec[s * 4 + 0] = best_axis; dec[s * 4 + 1] = best_q; dec[s * 4 + 2] = m; dec[s * 4 + 3] = 0;
     const int node[2] = { me + 1, me + (m - b) };
@@ -216,6 +244,102 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_choose_kernel(int nseg, const int
     atomicMax(counters + 1, level);
 }
 
+// the same decision by one WAVE per segment, for the levels with many bins per axis (few, big segments: one lane walking
+// 3 x 1024 bins through global memory took 15 ms per level): lane l owns nb / 64 consecutive bins, the boxes and counts of
+// the lanes before / after it come from wave scans, and the lanes' best splits are reduced with the serial loop's tie rule
+// (lowest cost, then lowest axis, then lowest bin)
+struct SbAgg { int c; float l[3], h[3]; };
+__device__ __forceinline__ void sb_agg_add(SbAgg &a, const SbAgg &b) {
+    a.c += b.c;
+    for (int r = 0; r < 3; r++) { a.l[r] = fminf(a.l[r], b.l[r]); a.h[r] = fmaxf(a.h[r], b.h[r]); }
+}
+__device__ __forceinline__ SbAgg sb_agg_shfl_up(const SbAgg &a, int d) {
+    SbAgg o; o.c = __shfl_up(a.c, d);
+    for (int r = 0; r < 3; r++) { o.l[r] = __shfl_up(a.l[r], d); o.h[r] = __shfl_up(a.h[r], d); }
+    return o;
+}
+__device__ __forceinline__ SbAgg sb_agg_shfl_down(const SbAgg &a, int d) {
+    SbAgg o; o.c = __shfl_down(a.c, d);
+    for (int r = 0; r < 3; r++) { o.l[r] = __shfl_down(a.l[r], d); o.h[r] = __shfl_down(a.h[r], d); }
+    return o;
+}
+__global__ __launch_bounds__(64) void sb_choose_wave_kernel(int nseg, const int *__restrict__ sb, const int *__restrict__ se,
+                                                           const int *__restrict__ snode, int nb, const int *__restrict__ sw, int level,
+                                                           int *__restrict__ child, float *__restrict__ blo, float *__restrict__ bhi,
+                                                           int *__restrict__ dec, int *__restrict__ flag, int *__restrict__ small,
+                                                           int *__restrict__ counters) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= nseg) return;
+    const int b = sb[s], e = se[s], me = snode[s];
+    const int *w = sw + (size_t)s * SB_SEG_WORDS(nb);
+    const int per = nb >> 6;                          // bins per lane (nb is a multiple of 64 here, at most 16 per lane)
+    float best = INFINITY;
+    int best_axis = -1, best_k = -1, best_q = 0;
+    for (int a = 0; a < 3; a++) {
+        const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
+        if (!(ch > cl)) continue;                     // (wave-uniform)
+        const int *bc = w + 12 + a * nb;
+        const int *bb = w + 12 + 3 * nb + a * nb * 6;
+        const int q0 = lane * per;
+        SbAgg own; own.c = 0;
+        for (int r = 0; r < 3; r++) { own.l[r] = INFINITY; own.h[r] = -INFINITY; }
+        for (int t = 0; t < per; t++) {
+            const int q = q0 + t, c = bc[q];
+            if (c) {
+                own.c += c;
+                for (int r = 0; r < 3; r++) { own.l[r] = fminf(own.l[r], sb_ord2f(bb[q * 6 + r])); own.h[r] = fmaxf(own.h[r], sb_ord2f(bb[q * 6 + 3 + r])); }
+            }
+        }
+        // what lies in the lanes before this one (exclusive prefix) and after it (exclusive suffix)
+        SbAgg pre = own, suf = own;
+        for (int d = 1; d < 64; d <<= 1) {
+            SbAgg o = sb_agg_shfl_up(pre, d);
+            if (lane >= d) sb_agg_add(pre, o);
+            SbAgg u = sb_agg_shfl_down(suf, d);
+            if (lane + d < 64) sb_agg_add(suf, u);
+        }
+        SbAgg left = sb_agg_shfl_up(pre, 1), right = sb_agg_shfl_down(suf, 1);
+        if (lane == 0) { left.c = 0; for (int r = 0; r < 3; r++) { left.l[r] = INFINITY; left.h[r] = -INFINITY; } }
+        if (lane == 63) { right.c = 0; for (int r = 0; r < 3; r++) { right.l[r] = INFINITY; right.h[r] = -INFINITY; } }
+        // the right side of a split at the lane's bin t = its bins t .. per-1 + the lanes after it: suffixes inside the chunk
+        float ral[16][3], rah[16][3]; int rcn[16];
+        {
+            SbAgg acc = right;
+            for (int t = per - 1; t >= 0; t--) {
+                const int q = q0 + t, c = bc[q];
+                if (c) {
+                    acc.c += c;
+                    for (int r = 0; r < 3; r++) { acc.l[r] = fminf(acc.l[r], sb_ord2f(bb[q * 6 + r])); acc.h[r] = fmaxf(acc.h[r], sb_ord2f(bb[q * 6 + 3 + r])); }
+                }
+                rcn[t] = acc.c;
+                for (int r = 0; r < 3; r++) { ral[t][r] = acc.l[r]; rah[t][r] = acc.h[r]; }
+            }
+        }
+        // candidate splits: left = bins 0 .. q-1, right = bins q .. nb-1, for q = q0 + t (q >= 1)
+        float lbest = INFINITY; int lk = -1, lq = 0;
+        SbAgg acc = left;
+        for (int t = 0; t < per; t++) {
+            const int q = q0 + t;
+            if (q >= 1 && acc.c != 0 && rcn[t] != 0) {
+                const float cost = sb_half_area(acc.l, acc.h) * acc.c + sb_half_area(ral[t], rah[t]) * rcn[t];
+                if (cost < lbest) { lbest = cost; lk = acc.c; lq = q; }
+            }
+            const int c = bc[q];
+            if (c) {
+                acc.c += c;
+                for (int r = 0; r < 3; r++) { acc.l[r] = fminf(acc.l[r], sb_ord2f(bb[q * 6 + r])); acc.h[r] = fmaxf(acc.h[r], sb_ord2f(bb[q * 6 + 3 + r])); }
+            }
+        }
+        // wave argmin: lowest cost, ties to the lowest bin (= the serial loop's first strict minimum)
+        for (int d = 32; d > 0; d >>= 1) {
+            const float oc = __shfl_xor(lbest, d); const int ok = __shfl_xor(lk, d), oq = __shfl_xor(lq, d);
+            if (oc < lbest || (oc == lbest && ok >= 0 && (lk < 0 || oq < lq))) { lbest = oc; lk = ok; lq = oq; }
+        }
+        if (lk >= 0 && lbest < best) { best = lbest; best_axis = a; best_k = lk; best_q = lq; }
+    }
+    if (lane == 0) sb_emit(s, b, e, me, w, best_axis, best_k, best_q, level, child, blo, bhi, dec, flag, small, counters);
+}
+
 __global__ __launch_bounds__(SB_BLOCK) void sb_newseg_kernel(int nseg, const int *__restrict__ sb, const int *__restrict__ se,
                                                             const int *__restrict__ snode, const int *__restrict__ dec,
                                                             const int *__restrict__ flag, const int *__restrict__ foff,
@@ -228,7 +352,7 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_newseg_kernel(int nseg, const int
 }
 
 __global__ __launch_bounds__(SB_BLOCK) void sb_pred_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
-                                                          const float *__restrict__ pct, const int *__restrict__ sw,
+                                                          const float *__restrict__ pct, int nb, const int *__restrict__ sw,
                                                           const int *__restrict__ dec, int *__restrict__ pred) {
     const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -238,10 +362,10 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_pred_kernel(int n, const int *__r
         const int a = dec[s * 4 + 0];
         if (a < 0) p = i < dec[s * 4 + 2];
         else {
-            const int *w = sw + (size_t)s * SB_SEG_WORDS;
+            const int *w = sw + (size_t)s * SB_SEG_WORDS(nb);
             const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
-            const float scale = SB_BINS / (ch - cl);
-            p = sb_bin_of(pct[(size_t)idx[i] * 3 + a], cl, scale) < dec[s * 4 + 1];
+            const float scale = nb / (ch - cl);
+            p = sb_bin_of(pct[(size_t)idx[i] * 3 + a], cl, scale, nb) < dec[s * 4 + 1];
         }
     }
     pred[i] = p;
@@ -370,7 +494,8 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_pack_kernel(int ni, const int *__
 }
 
 MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n) { return (size_t)n / (SB_SMALL + 1) + 2; }
-MPT_KERNEL_API size_t mpt_sah_seg_words(void) { return SB_SEG_WORDS; }
+// words of segment workspace: enough for every level's (segments x words at that level's bin count)
+MPT_KERNEL_API size_t mpt_sah_seg_words(int n) { return 12 * mpt_sah_seg_capacity(n) + 27 * (size_t)SB_BIN_BUDGET + SB_SEG_WORDS(SB_MAXBINS); }
 MPT_KERNEL_API hipError_t mpt_sah_scan_bytes(int n, size_t *bytes) {
     int *p = nullptr;
     return rocprim::exclusive_scan(nullptr, *bytes, p, p, 0, (size_t)std::max(n, 2), rocprim::plus<int>());
@@ -393,19 +518,26 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
     while (nseg > 0) {
         if (level > 62) return hipErrorInvalidValue;
         const int gs = (nseg + SB_BLOCK - 1) / SB_BLOCK;
-        const size_t words = (size_t)nseg * SB_SEG_WORDS;
-        hipLaunchKernelGGL(sb_reset_kernel, dim3((unsigned)((words + SB_BLOCK - 1) / SB_BLOCK)), dim3(SB_BLOCK), 0, stream, nseg, B->segw);
-        hipLaunchKernelGGL(sb_bounds_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->plo, B->phi, B->segw);
-        hipLaunchKernelGGL(sb_bin_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->plo, B->phi, B->segw);
-        hipLaunchKernelGGL(sb_choose_kernel, dim3(gs), dim3(SB_BLOCK), 0, stream, nseg, B->sb[cur], B->se[cur], B->snode[cur], B->segw, level,
-                           B->child, B->blo, B->bhi, B->dec, B->flag, B->small, B->counters);
+        // bins per axis at this level: as many as the budget allows for this many segments
+        int nb = SB_MINBINS;
+        while (nb < SB_MAXBINS && (size_t)nseg * (size_t)(2 * nb) <= (size_t)SB_BIN_BUDGET) nb *= 2;
+        const size_t words = (size_t)nseg * SB_SEG_WORDS(nb);
+        hipLaunchKernelGGL(sb_reset_kernel, dim3((unsigned)((words + SB_BLOCK - 1) / SB_BLOCK)), dim3(SB_BLOCK), 0, stream, nseg, nb, B->segw);
+        hipLaunchKernelGGL(sb_bounds_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->plo, B->phi, nb, B->segw);
+        hipLaunchKernelGGL(sb_bin_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->plo, B->phi, nb, B->segw);
+        if (nb > 64)
+            hipLaunchKernelGGL(sb_choose_wave_kernel, dim3(nseg), dim3(64), 0, stream, nseg, B->sb[cur], B->se[cur], B->snode[cur], nb, B->segw,
+                               level, B->child, B->blo, B->bhi, B->dec, B->flag, B->small, B->counters);
+        else
+            hipLaunchKernelGGL(sb_choose_kernel, dim3(gs), dim3(SB_BLOCK), 0, stream, nseg, B->sb[cur], B->se[cur], B->snode[cur], nb, B->segw,
+                               level, B->child, B->blo, B->bhi, B->dec, B->flag, B->small, B->counters);
         if ((e = rocprim::exclusive_scan(B->scan_tmp, scan_bytes, B->flag, B->foff, 0, (size_t)(2 * nseg), rocprim::plus<int>(), stream)) != hipSuccess) return e;
         int last[2] = { 0, 0 };
         if ((e = hipMemcpyAsync(&last[0], B->foff + (2 * nseg - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(&last[1], B->flag + (2 * nseg - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         hipLaunchKernelGGL(sb_newseg_kernel, dim3(gs), dim3(SB_BLOCK), 0, stream, nseg, B->sb[cur], B->se[cur], B->snode[cur], B->dec, B->flag,
                            B->foff, B->sb[cur ^ 1], B->se[cur ^ 1], B->snode[cur ^ 1]);
-        hipLaunchKernelGGL(sb_pred_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->segw, B->dec, B->pred);
+        hipLaunchKernelGGL(sb_pred_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, nb, B->segw, B->dec, B->pred);
         if ((e = rocprim::exclusive_scan(B->scan_tmp, scan_bytes, B->pred, B->pscan, 0, (size_t)n, rocprim::plus<int>(), stream)) != hipSuccess) return e;
         hipLaunchKernelGGL(sb_scatter_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pred, B->pscan, B->sb[cur],
                            B->se[cur], B->snode[cur], B->dec, B->flag, B->foff, B->child, B->idx[cur ^ 1], B->seg[cur ^ 1]);

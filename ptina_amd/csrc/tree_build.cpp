@@ -46,6 +46,7 @@ struct SahBuild {
     std::vector<int32_t> child;                // [n-1][2]: >= 0 internal, ~slot leaf
     std::vector<float> blo, bhi;               // per internal node [n-1][3]: its own box
     int depth = 0;
+    int exact_max = 8192;                      // ranges up to this many leaves: every split of every axis (exact sweep); above: 32 bins
 
     static float half_area(const float *l, const float *h) {
         float dx = std::max(h[0] - l[0], 0.f), dy = std::max(h[1] - l[1], 0.f), dz = std::max(h[2] - l[2], 0.f);
@@ -57,7 +58,7 @@ struct SahBuild {
         float best = INFINITY;
         int best_axis = -1, best_k = -1;
         float best_pos = 0.f;
-        bool binned = cnt > 8192;
+        bool binned = cnt > exact_max;
         std::vector<std::pair<float, int>> key(binned ? 0 : cnt);
         std::vector<float> rarea(binned ? 0 : cnt);
         float cl[3] = { INFINITY, INFINITY, INFINITY }, ch[3] = { -INFINITY, -INFINITY, -INFINITY };
@@ -302,6 +303,7 @@ static int build_tree_host(mpt_ctx *c) {
     if (c->tree_kind == 1 && ni > 0) {
         SahBuild sb;
         sb.n = n;
+        sb.exact_max = c->sah_exact_max;
         sb.lo.resize((size_t)n * 3); sb.hi.resize((size_t)n * 3); sb.ctr.resize((size_t)n * 3);
         for (int slot = 0; slot < n; slot++) {
             float l[3], h[3];
@@ -393,12 +395,12 @@ static void pack_fnode(mpt_ctx *c, int n, const std::vector<int32_t> &fchild, co
 // workspace of mpt_sah_build: one device allocation carved into the arrays of MptSahBuffers
 static int build_sah_device(mpt_ctx *c) {
     const int n = c->nfaces, ni = n - 1;
-    const size_t SC = mpt_sah_seg_capacity(n), SW = mpt_sah_seg_words();
+    const size_t SC = mpt_sah_seg_capacity(n), SEGW = mpt_sah_seg_words(n);
     size_t scan_bytes = 0;
     HIP_TRY(mpt_sah_scan_bytes((int)std::max<size_t>((size_t)n, 2 * SC), &scan_bytes));
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t f3 = al((size_t)n * 3 * 4), i1 = al((size_t)n * 4), s1 = al(SC * 4);
-    size_t total = 3 * f3 + 6 * i1 + 6 * s1 + al(SC * SW * 4) + al(SC * 16) + 2 * al(2 * SC * 4) + al(((size_t)n / 2 + 1) * 16) + al(16) +
+    size_t total = 3 * f3 + 6 * i1 + 6 * s1 + al(SEGW * 4) + al(SC * 16) + 2 * al(2 * SC * 4) + al(((size_t)n / 2 + 1) * 16) + al(16) +
                    al((size_t)ni * 8) + 2 * al((size_t)ni * 12) + al(std::max<size_t>(scan_bytes, 16));
     if (total > c->sah_ws_bytes) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -414,7 +416,7 @@ static int build_sah_device(mpt_ctx *c) {
     for (int k = 0; k < 2; k++) { B.idx[k] = (int *)take((size_t)n * 4); B.seg[k] = (int *)take((size_t)n * 4); }
     B.pred = (int *)take((size_t)n * 4); B.pscan = (int *)take((size_t)n * 4);
     for (int k = 0; k < 2; k++) { B.sb[k] = (int *)take(SC * 4); B.se[k] = (int *)take(SC * 4); B.snode[k] = (int *)take(SC * 4); }
-    B.segw = (int *)take(SC * SW * 4);
+    B.segw = (int *)take(SEGW * 4);
     B.dec = (int *)take(SC * 16); B.flag = (int *)take(2 * SC * 4); B.foff = (int *)take(2 * SC * 4);
     B.small = (int *)take(((size_t)n / 2 + 1) * 16);
     B.counters = (int *)take(16);
@@ -496,6 +498,7 @@ static int build_tree_gpu(mpt_ctx *c) {
         HIP_TRY(hipMemcpy(c->h_leaf.data(), c->d_leaf, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
         SahBuild sb;
         sb.n = n;
+        sb.exact_max = c->sah_exact_max;
         sb.lo.resize((size_t)n * 3); sb.hi.resize((size_t)n * 3); sb.ctr.resize((size_t)n * 3);
         const float *V = c->verts.data();
         for (int slot = 0; slot < n; slot++) {

@@ -42,6 +42,9 @@ for title, name, kw, n, spp, world in CONFIGS:
     c.set_option('batch', 32)
     for kv in filter(None, os.environ.get('MIPTINA_OPTS', '').split(',')):
         c.set_option(kv.split('=')[0], int(kv.split('=')[1]))
+    if os.environ.get('MIPTINA_OPTS'):
+        from ptina_amd.things import BVHTree
+        BVHTree().build()                     # (options that change the tree take effect at the next build)
     if os.environ.get('MIPTINA_WIDE'):
         c.set_option('wide', int(os.environ['MIPTINA_WIDE']))
     eng.render(1)
