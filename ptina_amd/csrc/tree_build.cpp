@@ -4,6 +4,7 @@
 #include "miptina_ctx.h"
 #include "tri_records.h"
 #include <atomic>
+#include <system_error>
 #include <thread>
 
 // ------------------------------------------------------------------ LBVH build (tree/lbvh.py:169-305)
@@ -156,10 +157,18 @@ struct SahBuild {
             if (e - m == 1) child[(size_t)me * 2 + 1] = ~idx[m]; else child[(size_t)me * 2 + 1] = right;
             const bool has_l = m - b > 1, has_r = e - m > 1;
             if (has_l && has_r) {
-                if (spawn_levels > 0 && std::min(m - b, e - m) > 16384) {
-                    std::thread th([=] { build_range(b, m, left, dep + 1, spawn_levels - 1); });
+                if (spawn_levels > 0 && std::max(m - b, e - m) > 16384) {
+                    // (a lopsided split keeps its spawn levels for the big half; a thread that cannot be created -- pid /
+                    // ulimit limits in a container -- must not take the process down: the half is built here instead)
+                    bool spawned = false;
+                    std::thread th;
+                    if (std::min(m - b, e - m) > 4096) {
+                        try { th = std::thread([=] { build_range(b, m, left, dep + 1, spawn_levels - 1); }); spawned = true; }
+                        catch (const std::system_error &) { spawned = false; }
+                    }
+                    if (!spawned) build_range(b, m, left, dep + 1, spawn_levels - 1);
                     build_range(m, e, right, dep + 1, spawn_levels - 1);
-                    th.join();
+                    if (spawned) th.join();
                     return;
                 }
                 build_range(b, m, left, dep + 1, 0);          // the smaller worlds recurse; depth is bounded by the tree's

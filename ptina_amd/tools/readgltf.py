@@ -83,9 +83,9 @@ def readgltf(path):
         pbr = m.get('pbrMetallicRoughness', {})
         if 'metallicRoughnessTexture' in pbr:
             raise AssertionError('metallicRoughness texture not supported')      # as the reference
+        # the reference hands the glTF TEXTURE index on as the image id, without going through textures[i].source
+        # (readgltf.py:121-122); exporters write texture i -> image i, so the two coincide on its assets.  Kept as it is.
         tex = pbr.get('baseColorTexture', {}).get('index', -1)
-        if tex != -1:
-            tex = doc['textures'][tex].get('source', tex)
         materials.append(((pbr.get('baseColorFactor', [1.0, 1.0, 1.0, 1.0]), tex),
                           (pbr.get('metallicFactor', 1.0), -1), (pbr.get('roughnessFactor', 1.0), -1)))
 

@@ -196,3 +196,37 @@ def test_benchmark_asset_round_trip(tmp_path):
     assert np.allclose(vertices.reshape(-1, 3, 8), ref_v.reshape(-1, 3, 8)[order], atol=1e-6)
     assert len(materials) == len(ref_mats) and all(len(m) == 3 for m in materials)
     assert np.allclose(materials[3][0][0][:3], ref_mats[3][0][0])
+
+
+def test_readgltf_pinned_to_the_reference_loaders_steps():
+    '''tools/readgltf.py against a committed hand-made scene (tests/golden/minimal_scene.gltf) and the outputs the
+    reference's loader produces for it, derived step by step from ptina/tools/readgltf.py:15-240 by
+    tests/golden/make_gltf_golden.py (gltflib is not installed, so the reference's loader itself cannot run): node
+    transforms (scale, rotation, translation; parent @ child), indexed primitives, a primitive without uvs and
+    material, the 3-of-12 material parameters of SURVEY Q7, the texture index handed on as the image id, images as
+    [x][y][c]'''
+    from ptina_amd.tools.readgltf import readgltf
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    z = np.load(os.path.join(here, 'gltf_expected.npz'))
+    vertices, mtlids, materials, images = readgltf(os.path.join(here, 'minimal_scene.gltf'))
+    assert vertices.dtype == np.float64 and vertices.shape == z['vertices'].shape == (9, 8)
+    assert np.abs(vertices - z['vertices']).max() <= 1e-12
+    assert np.array_equal(np.asarray(mtlids, np.int64), z['mtlids']) and z['mtlids'].tolist() == [1, 1, -1]
+    assert len(materials) == 2 and all(len(m) == 3 for m in materials)          # base colour, metallic, roughness only
+    for k, m in enumerate(materials):
+        assert np.allclose(np.asarray(m[0][0], float), z['material_factors'][k, 0])
+        assert float(m[1][0]) == z['material_factors'][k, 1, 0] and float(m[2][0]) == z['material_factors'][k, 2, 0]
+        assert [int(m[0][1]), int(m[1][1]), int(m[2][1])] == z['material_textures'][k].tolist()
+    assert z['material_textures'][1].tolist() == [1, -1, -1]                     # TEXTURE index 1, not its source (image 0)
+    assert len(images) == 2
+    for k in (0, 1):
+        assert images[k].shape[:2] == (2, 3) and np.array_equal(images[k][..., :3], z[f'image{k}'])
+    # and the loaded scene goes into the pools the way exams/benchmark.py does it (host packing only, no GPU)
+    from ptina_amd.mtllib import MaterialPool
+    pool = MaterialPool.__new__(MaterialPool)
+    MaterialPool.__init__(pool, 4)
+    for i, m in enumerate(materials):
+        for pair, (fac, tex) in zip((pool.basecolor, pool.metallic, pool.roughness), m):
+            pair.load(i, fac, tex)
+    assert np.allclose(pool._fac[1, 0], [0.2, 0.4, 0.6, 1.0]) and pool._tex[1, 0] == 1
+    assert np.all(pool._fac[1, 3:] == 0)                                          # the nine unset parameters stay zero (Q7)
