@@ -244,6 +244,8 @@ struct Stack {
     int sp;
     DEV void push(int v) { base[sp * MPT_BLOCK] = v; sp++; }
     DEV int pop() { sp--; return base[sp * MPT_BLOCK]; }
+    static constexpr bool PEEK = true;                 // the entry a pop would return can be read ahead of the decision
+    DEV int peek(int at) const { return base[at * MPT_BLOCK]; }
 };
 
 // scene records served from HBM/L2 through the vector L1 (any scene size)
@@ -356,6 +358,8 @@ struct SpillStack {
         sp--;
         return sp < CAP ? base[sp * MPT_BLOCK] : spill[sp - CAP];
     }
+    static constexpr bool PEEK = false;
+    DEV int peek(int) const { return 0; }
 };
 
 // scene records resident in the CU's LDS (small scenes): ds_read_b128 instead of divergent
@@ -417,6 +421,8 @@ struct Stack16 {
     int sp;
     DEV void push(int v) { base[sp * MPT_LDS_BLOCK] = (short)v; sp++; }
     DEV int pop() { sp--; return (int)base[sp * MPT_LDS_BLOCK]; }
+    static constexpr bool PEEK = true;
+    DEV int peek(int at) const { return (int)base[at * MPT_LDS_BLOCK]; }
 };
 
 // the same LIFO for the tracer waves of the pooled kernel: [level][tracer lane], the lane count a launch parameter
@@ -428,6 +434,8 @@ struct Stack16V {
     int sp;
     DEV void push(int v) { base[sp * stride] = (short)v; sp++; }
     DEV int pop() { sp--; return (int)base[sp * stride]; }
+    static constexpr bool PEEK = true;
+    DEV int peek(int at) const { return (int)base[at * stride]; }
 };
 
 #if MPT_STRICT

@@ -26,6 +26,10 @@
 #include "pt_device.h"
 #include <atomic>
 
+#ifndef MPT_SPEC_POP
+#define MPT_SPEC_POP 1        // the stack entry a step may pop is read together with the step's node / triangle record
+#endif
+
 #if MPT_STRICT
 #define MPT_SUFFIX(x) x##_strict
 #else
@@ -334,6 +338,10 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     float tn0, tn1;
     bool h0, h1;
     if (COUNT) { cnt.n_node++; cnt.n_box += 2; }
+#if MPT_SPEC_POP
+    int spec = 0;
+    if constexpr (STACK::PEEK) spec = stk.peek(L.sp - 1);      // (the sentinel sits at level 0: sp >= 1 while a ray is traversed)
+#endif
     if constexpr (SCENE::SIGNED_PLANES) {
         mpt_f2 nx, fx, ny, fy, nz, fz, ids;
         sc.node_planes(L.curr, L.offx, L.offy, L.offz, nx, fx, ny, fy, nz, fz, ids);
@@ -360,10 +368,23 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     bool swap = tn1 < tn0;
     int nearid = swap ? id1 : id0, farid = swap ? id0 : id1;
     int next = h0 ? (h1 ? nearid : id0) : id1;
-    stk.sp = L.sp;
-    if (h0 && h1) stk.push(farid);
-    if (!(h0 || h1)) next = stk.pop();
-    L.sp = stk.sp;
+#if MPT_SPEC_POP
+    if constexpr (STACK::PEEK) {
+        // the entry a pop would return was asked for with the node record (spec, below the function's head): a step that
+        // pops does not wait a second LDS round trip behind the box tests.  Push (both hit) and pop (both missed) exclude
+        // each other, and a push goes to level sp, not sp - 1
+        int sp = L.sp;
+        if (h0 && h1) { stk.sp = sp; stk.push(farid); sp++; }
+        if (!(h0 || h1)) { next = spec; sp--; }
+        L.sp = sp;
+    } else
+#endif
+    {
+        stk.sp = L.sp;
+        if (h0 && h1) stk.push(farid);
+        if (!(h0 || h1)) next = stk.pop();
+        L.sp = stk.sp;
+    }
     L.curr = next;
     L.st = classify<STACK>(next);
 }
@@ -454,6 +475,10 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     int slot = ~L.curr;
     bool stop = false;
     if (COUNT) cnt.n_tri++;
+#if MPT_SPEC_POP
+    int spec = 0;
+    if constexpr (STACK::PEEK) spec = stk.peek(L.sp - 1);      // a leaf step always pops: asked for with the triangle record
+#endif
     MptVec4 g0, g1, g2;
     sc.tri(slot, g0, g1, g2);
     float dd, su, sv;
@@ -464,9 +489,15 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
             L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv;
         }
     }
-    stk.sp = L.sp;
-    int next = stk.pop();
-    L.sp = stk.sp;
+    int next;
+#if MPT_SPEC_POP
+    if constexpr (STACK::PEEK) { next = spec; L.sp = L.sp - 1; } else
+#endif
+    {
+        stk.sp = L.sp;
+        next = stk.pop();
+        L.sp = stk.sp;
+    }
     L.curr = next;
     L.st = stop ? ST_DONE : classify<STACK>(next);
 }
