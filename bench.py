@@ -54,7 +54,7 @@ SPP = 32
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_SIMD = 256 * 4             # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 SIMD_LANES = 32              # a wave64 VALU instruction issues over 2 cycles on a SIMD-32
-PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')
+PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r03_pmc_summary.json')
 C3_N = 2048                  # BASELINE.json configs[2]: 2048 x 2048 film (32 spp per step here, 256 stated: 8 steps)
 # the launch model of DESIGN.md section 6, measured on ONE MI355X (tools/gpu_diag.py shares_sync): a launch of 1/N of
 # a film costs a / N + b -- b = the end-of-launch drain, independent of N

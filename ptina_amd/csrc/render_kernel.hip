@@ -847,7 +847,8 @@ DEV bool tile_pixel(const MptRenderParams &p, int tile, int *pi, int *pj) {
 #if MPT_STRICT
 #define MPT_RENDER_BOUNDS __launch_bounds__(MPT_BLOCK)
 #else
-// gathers from L2 / Infinity Cache are latency-bound: ask for 4 waves per SIMD (126 VGPRs, no spills)
+// gathers from L2 / Infinity Cache are latency-bound: ask for 4 waves per SIMD (the 32-level kernels then sit at the 128-VGPR
+// cap; tools/kernel_resources.py prints registers / scratch of every kernel as built)
 #define MPT_RENDER_BOUNDS __launch_bounds__(MPT_BLOCK, 4)
 #endif
 template <int STACK, bool COUNT>
