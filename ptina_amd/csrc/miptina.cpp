@@ -551,7 +551,6 @@ extern "C" int mpt_set_world_light(mpt_ctx *c, const float fac[4], int tex) {
 extern "C" int mpt_sobol_init(mpt_ctx *c, const int32_t *V, int rows, int dim) {
     if (use(c)) return 1;
     if (rows < 2 || dim < 1 || !V) return fail("bad sobol grid %dx%d", rows, dim);
-    if (dim >= (1 << 24)) return fail("sobol table of %d dimensions: at most 2^24 - 1 (the reference's has 21201)", dim);
     HIP_TRY(hipStreamSynchronize(c->stream));
     hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
     c->sV = c->sX = nullptr; c->sP = nullptr;

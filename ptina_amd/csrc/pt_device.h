@@ -395,7 +395,7 @@ struct LdsScene {
     // and 12 v_min / v_max fewer per step.
     DEV void node_planes(int i, int ox, int oy, int oz, mpt_f2 &nx, mpt_f2 &fx, mpt_f2 &ny, mpt_f2 &fy,
                          mpt_f2 &nz, mpt_f2 &fz, mpt_f2 &ids) const {
-        LdsBytePtr nd = (LdsBytePtr)fnode + (int)__umul24((unsigned)i, (unsigned)nstride);      // (node ids and strides fit 24 bits: v_mul_u32_u24, not the quarter-rate v_mul_lo_u32)
+        LdsBytePtr nd = (LdsBytePtr)fnode + i * nstride;
         LdsBytePtr ax = nd + ox, ay = nd + oy, az = nd + oz;
         nx = *(LdsVec2Ptr)ax;        fx = *(LdsVec2Ptr)(nd + (ox ^ 8));
         ny = *(LdsVec2Ptr)(ay + 16); fy = *(LdsVec2Ptr)(nd + 16 + (oy ^ 8));

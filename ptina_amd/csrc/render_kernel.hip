@@ -238,9 +238,7 @@ DEV int reduce_mod_dim(int h, int dim, float inv_dim) {
 // along with the counter, so a draw costs a load and a compare.  The wrapping case takes the literal path.
 template <int N>
 DEV void lane_draws(const MptRenderParams &p, LaneState &L, float *out) {
-    // frame < 64 and the table has < 2^24 dimensions (mpt_sobol_init): one full-rate v_mul_u32_u24 instead of a 64-bit multiply
-    // (v_mul_lo / v_mul_hi_u32 are quarter rate)
-    const float *P = p.P + __umul24((unsigned)L.frame, (unsigned)p.sobol_dim);
+    const float *P = p.P + (size_t)L.frame * p.sobol_dim;
     const int dim = p.sobol_dim;
     if (L.rng_i <= 0x7fffffff - N && L.rng_k + N <= dim) {
         // the N numbers are consecutive words (no wrap at dim inside them): two 16-byte gathers (any 4-byte
@@ -322,10 +320,7 @@ DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, STACK &stk, V3
         if (p.n < 2) L.st = ST_DONE;
     } else {
         MptVec4 o; o.x = L.result.x; o.y = L.result.y; o.z = L.result.z; o.w = 1.0f;
-        // path.py:93, summed by combine.  (frame < 64; a frame of the slab has < 2^24 float4 unless the film is larger than 4096^2)
-        const size_t at = p.partial_stride < (1 << 24) ? (size_t)(__umul24((unsigned)L.frame, (unsigned)p.partial_stride) + (unsigned)L.pix)
-                                                       : (size_t)L.frame * (size_t)p.partial_stride + L.pix;
-        p.partial[at] = o;
+        p.partial[(size_t)L.frame * (size_t)p.partial_stride + L.pix] = o;   // path.py:93, summed by combine
         L.st = ST_NEW;
     }
 }
