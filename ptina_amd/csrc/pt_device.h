@@ -62,6 +62,15 @@ DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 DEV float norm_sqr(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 DEV V3 normalized(V3 a) { return a * m_rnorm(norm_sqr(a)); }
+// the same with the sum of squares left unfused in every build: the path direction is normalised where a ray starts, a piece of
+// code the production kernels hold in more than one inlined copy, and -ffp-contract=fast would fuse each copy as it pleases --
+// the films of two kernels (or of one kernel with and without an option) would then differ in last bits for no arithmetic reason
+DEV V3 normalized_unfused(V3 a) {
+#pragma clang fp contract(off)
+    const float xx = a.x * a.x, yy = a.y * a.y, zz = a.z * a.z;
+    const float s = xx + yy + zz;
+    return a * m_rnorm(s);
+}
 #if MPT_STRICT
 DEV float vavg(V3 a) { return m_div(a.x + a.y + a.z, 3.0f); }                 // common.py:73-77
 #else
@@ -330,6 +339,21 @@ struct QuantScene {
         const unsigned o = (unsigned)i << 6;
         a = *(const MptVec4 *)(base + o); b = *(const MptVec4 *)(base + 16 + o);
         c = *(const MptVec4 *)(base + 32 + o); id = *(const MptVec4 *)(base + 48 + o);
+#if MPT_X_DUP_QNODE
+        // sensitivity A/B (same film): MPT_X_DUP_QNODE extra 4-byte gathers per step -- what is one gather more or less worth?
+        {
+            unsigned o2 = o;
+            asm volatile("" : "+v"(o2));
+            const float e0 = *(const float *)(base + 4 + o2);
+            a.y = e0 == a.y ? a.y : e0;
+#if MPT_X_DUP_QNODE > 1
+            unsigned o3 = o;
+            asm volatile("" : "+v"(o3));
+            const float e1 = *(const float *)(base + 20 + o3);
+            b.y = e1 == b.y ? b.y : e1;
+#endif
+        }
+#endif
     }
     DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2) const {       // tfast: 48-byte records
         const MptVec4 *g = tgeo + (size_t)slot * 3;

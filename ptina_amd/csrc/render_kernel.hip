@@ -30,6 +30,9 @@
 #define MPT_SPEC_POP 1        // the stack entry a step may pop is read together with the step's node / triangle record
 #endif
 
+#ifndef MPT_ONE_START
+#define MPT_ONE_START 1       // one ray-start block per shading pass (0: each stage starts its own lanes' rays, as before)
+#endif
 #if MPT_STRICT
 #define MPT_SUFFIX(x) x##_strict
 #else
@@ -191,7 +194,10 @@ DEV void trace_pixel(const MptRenderParams &p, const TR &tr, int i, int j, int f
 // there is one shading stage per bounce and the order of additions into `result` is the
 // reference's (path.py:31-56).  Rays, samples and sums do not depend on the schedule: each sample's
 // radiance goes to p.partial[frame][column of the share][y] and the combine pass adds frames in order.
-enum { ST_NODE = 0, ST_LEAF = 1, ST_DONE = 2, ST_NEW = 3, ST_DEAD = 4 };   // DONE: this lane's ray is finished
+enum { ST_NODE = 0, ST_LEAF = 1, ST_DONE = 2, ST_NEW = 3, ST_DEAD = 4,     // DONE: this lane's ray is finished
+       // inside one shading pass only (MPT_ONE_START): the lane's next ray starts in the pass's common block, from L.to --
+       // a closest-hit ray along L.prd (head of the path_trace loop first) | a shadow ray along L.td up to L.tbest
+       ST_BOUNCE = 5, ST_SHADOW = 6 };
 
 // Per-lane state: live across the whole loop, so every word costs a VGPR for the kernel's lifetime.
 struct LaneState {
@@ -317,7 +323,7 @@ DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, STACK &stk, V3
     if (L.depth < 5 && any_gt0(L.throughput) && any_ne0(L.prd)) {
         L.depth += 1;
         if (COUNT) cnt.bounces++;
-        L.prd = normalized(L.prd);
+        L.prd = normalized_unfused(L.prd);
         lane_start_ray<COUNT>(L, stk, ro, L.prd, MPT_INF, false, cnt);
         // lbvh.py:218,319: with fewer than two faces the root box is never written: no hit
         if (p.n < 2) L.st = ST_DONE;
@@ -326,6 +332,31 @@ DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, STACK &stk, V3
         p.partial[(size_t)L.frame * (size_t)p.partial_stride + L.pix] = o;   // path.py:93, summed by combine
         L.st = ST_NEW;
     }
+}
+
+// The loop head alone (path.py:25): a lane about to bounce whose path is over stores its sample and waits for a new one
+DEV bool path_continues(const LaneState &L) { return L.depth < 5 && any_gt0(L.throughput) && any_ne0(L.prd); }
+DEV void lane_store_sample(const MptRenderParams &p, LaneState &L) {
+    MptVec4 o; o.x = L.result.x; o.y = L.result.y; o.z = L.result.z; o.w = 1.0f;
+    p.partial[(size_t)L.frame * (size_t)p.partial_stride + L.pix] = o;       // path.py:93, summed by combine
+    L.st = ST_NEW;
+}
+// The one place of a shading pass where rays start (MPT_ONE_START): the lanes whose shadow ray just ended, the lanes that
+// shaded and the lanes that took a new sample all come here, so the direction set-up (a normalisation, three reciprocals,
+// the stack reset) is issued once per pass at the width of all of them, not three times at a third each
+template <bool COUNT, class STACK>
+DEV void lane_begin_ray(const MptRenderParams &p, LaneState &L, STACK &stk, Cnt &cnt) {
+    const bool sh = L.st == ST_SHADOW;
+    const V3 n = normalized_unfused(L.prd);
+    if (!sh) {
+        L.depth += 1;
+        if (COUNT) cnt.bounces++;
+        L.prd = n;
+    }
+    const V3 d = sh ? L.td : n;
+    lane_start_ray<COUNT>(L, stk, L.to, d, sh ? L.tbest : MPT_INF, sh, cnt);
+    // lbvh.py:218,319: with fewer than two faces the root box is never written: no hit
+    if (!sh && p.n < 2) L.st = ST_DONE;
 }
 
 // Traversal steps touch only (curr, sp, st) and, for leaves, the hit record: everything a finished
@@ -517,7 +548,20 @@ DEV void stage_shadow_done(const MptRenderParams &p, LaneState &L, STACK &stk, C
 // (L.hidx >= 0, L.tbest, L.hidx, L.hu, L.hv) the closest hit.  shade_core is the bounce itself; what follows it --
 // a shadow ray from hitpos towards the sampled light, or the next bounce from hitpos -- is the caller's: the wave that
 // shaded starts it in the same lane (stage_shade), or hands it to another wave through the workgroup's ray pool.
-enum { SH_END = 0, SH_BOUNCE = 1, SH_SHADOW = 2 };   // path over (miss: world light added) | next bounce from hitpos | shadow ray first
+enum { SH_END = 0, SH_BOUNCE = 1, SH_SHADOW = 2 };
+// Diagnostic build -DMPT_X_STAMPS=2 (counting kernels): shader-clock cycles (units of 16) of the segments of SHADE, added by the
+// first active lane into the pl_* counters: lights hit | geometry + material (waits for the gathers) | light sample |
+// BSDF eval + MIS | BSDF sample | ray start
+#if MPT_X_STAMPS == 2
+#define MPT_SEG_BEGIN unsigned long long seg_t = 0; if (COUNT) { __builtin_amdgcn_sched_barrier(0); seg_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define MPT_SEG(field) if (COUNT) { __builtin_amdgcn_sched_barrier(0); const unsigned long long seg_n = __builtin_amdgcn_s_memtime(); \
+        const unsigned long long seg_m = __ballot(true); \
+        const bool seg_first = __builtin_amdgcn_mbcnt_hi((unsigned)(seg_m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)seg_m, 0u)) == 0; \
+        cnt.field += seg_first ? (unsigned)((seg_n - seg_t) >> 4) : 0u; seg_t = seg_n; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MPT_SEG_BEGIN
+#define MPT_SEG(field)
+#endif   // path over (miss: world light added) | next bounce from hitpos | shadow ray first
 template <bool COUNT, class SCENE>
 DEV int shade_core(const MptRenderParams &p, const SCENE &sc, LaneState &L, Cnt &cnt, V3 &hitpos, V3 &sdir, float &sdis) {
     V3 ro = L.to, rd = L.prd;
@@ -528,6 +572,7 @@ DEV int shade_core(const MptRenderParams &p, const SCENE &sc, LaneState &L, Cnt 
     // light tests, instead of three in a row
     ShadeRec rec = {};
     float u[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    MPT_SEG_BEGIN
     if (was_hit) {
         rec = shade_rec_load(p, L.hidx);
         lane_draws<6>(p, L, u);
@@ -538,6 +583,7 @@ DEV int shade_core(const MptRenderParams &p, const SCENE &sc, LaneState &L, Cnt 
         L.result = L.result + L.throughput * (lit.color * mis);
     }
     hitpos = ro; sdir = v3s(0.0f); sdis = 0.0f;
+    MPT_SEG(pl_local)
     if (!was_hit) {
         L.result = L.result + L.throughput * world_at(p, rd);
         L.depth = 5;                                                         // break, path.py:39
@@ -550,9 +596,11 @@ DEV int shade_core(const MptRenderParams &p, const SCENE &sc, LaneState &L, Cnt 
     if (COUNT) { cnt.n_shade++; cnt.n_draws += 6; }
     float sign = -dot(rd, normal);                                           // path.py:44-46 (never negative)
     if (sign < 0.0f) normal = -normal;
+    MPT_SEG(pl_batches)
 
     LightSample li = lights_sample(p, hitpos, v3(u[0], u[1], u[2]));
     bool want_shadow = any_gt0(li.color);
+    MPT_SEG(pl_batch_lanes)
     L.direct = v3s(0.0f);
     if (want_shadow) {
         // evaluated before the visibility is known; dropped if the shadow ray hits (path.py:50-56)
@@ -562,10 +610,12 @@ DEV int shade_core(const MptRenderParams &p, const SCENE &sc, LaneState &L, Cnt 
         V3 direct_li = li.color * mis * brdf_clr * dot_or_zero(normal, li.dir);
         L.direct = L.throughput * direct_li;
     }
+    MPT_SEG(pl_prim)
     BsdfSample brdf = disney_bounce(mat, normal, sign, -rd, v3(u[3], u[4], u[5]));
     L.throughput = L.throughput * brdf.color;
     L.prd = brdf.outdir;
     L.last_brdf_pdf = brdf.pdf;
+    MPT_SEG(pl_tidle)
     // A shadow ray decides whether `direct` is added (path.py:50-56).  When direct is exactly zero -- the light is behind the
     // surface (cos = 0), a black lobe, a dead throughput -- adding it or not is the same bits, so the ray is not traced:
     // an exact elimination (x + 0 == x; a NaN is != 0 and still takes the ray).  On the benchmark scene that is every
@@ -587,8 +637,10 @@ DEV void stage_shade(const MptRenderParams &p, const SCENE &sc, LaneState &L, ST
     V3 hitpos, sdir;
     float sdis;
     const int next = shade_core<COUNT>(p, sc, L, cnt, hitpos, sdir, sdis);
+    MPT_SEG_BEGIN
     if (next == SH_SHADOW) lane_start_ray<COUNT>(L, stk, hitpos, sdir, sdis, true, cnt);
     else lane_next_bounce<COUNT>(p, L, stk, hitpos, cnt);                    // SH_END: depth is 5, the sample is stored
+    MPT_SEG(pl_sidle)
 }
 
 // do_render up to the camera ray, path.py:82-90, in two halves.  A wave prepares the primary rays of the next 64
@@ -764,6 +816,32 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             }
         }
         // ---- shading mode
+#if MPT_ONE_START
+        if (wave_count(L.st == ST_DONE && !L.shadow) != 0) {
+            if (COUNT && (threadIdx.x & 63) == 0) cnt.it_shade++;
+            MPT_STAMP_BEGIN
+            if (L.st == ST_DONE && !L.shadow) {
+                V3 hitpos, sdir;
+                float sdis;
+                const int nk = shade_core<COUNT>(p, sc, L, cnt, hitpos, sdir, sdis);
+                L.to = hitpos;
+                if (nk == SH_SHADOW) { L.td = sdir; L.tbest = sdis; L.st = ST_SHADOW; }
+                else L.st = ST_BOUNCE;                                       // SH_END: depth is 5, the sample is stored below
+            }
+            MPT_STAMP_END(acc_shade)
+        }
+        {
+            MPT_STAMP_BEGIN
+            // a shadow ray has finished: the candidate direct light is added if nothing was hit (path.py:51,56); the next
+            // bounce starts from hitpos (= the shadow ray's origin, still in L.to), path.py:60
+            if (L.st == ST_DONE) {                                           // (the closest-hit lanes have left DONE above)
+                if (L.hidx < 0) L.result = L.result + L.direct;
+                L.st = ST_BOUNCE;
+            }
+            if (L.st == ST_BOUNCE && !path_continues(L)) lane_store_sample(p, L);   // path.py:25,93: these lanes take a new sample below
+            MPT_STAMP_END(acc_sdone)
+        }
+#else
         if (wave_count(L.st == ST_DONE && L.shadow) != 0) {
             MPT_STAMP_BEGIN
             if (L.st == ST_DONE && L.shadow) stage_shadow_done<COUNT>(p, L, stk, cnt);
@@ -775,6 +853,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             if (L.st == ST_DONE && !L.shadow) stage_shade<COUNT>(p, sc, L, stk, cnt);
             MPT_STAMP_END(acc_shade)
         }
+#endif
         MPT_STAMP_BEGIN
         unsigned long long m_new = __ballot(L.st == ST_NEW);
         if (m_new != 0ull) {
@@ -820,7 +899,13 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                     L.navoid = 0; L.depth = 0;
                     L.result = v3s(0.0f); L.throughput = v3s(1.0f); L.last_brdf_pdf = 0.0f;
                     if (COUNT) { cnt.samples++; cnt.n_draws += 2; }
+#if MPT_ONE_START
+                    L.to = ro;
+                    L.st = ST_BOUNCE;
+                    if (!path_continues(L)) lane_store_sample(p, L);          // (a camera ray of zero length: path.py:25)
+#else
                     lane_next_bounce<COUNT>(p, L, stk, ro, cnt);
+#endif
                 }
                 // NEW lanes beyond the pool's end keep waiting: the next pass prepares the next 64 samples
                 next = min(next + (int)__builtin_popcountll(m_new), pool_end);
@@ -830,6 +915,13 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             }
         }
         MPT_STAMP_END(acc_new)
+#if MPT_ONE_START
+        {
+            MPT_STAMP_BEGIN
+            if (L.st == ST_BOUNCE || L.st == ST_SHADOW) lane_begin_ray<COUNT>(p, L, stk, cnt);
+            MPT_STAMP_END(acc_sdone)
+        }
+#endif
         if (ndead == 64) break;
     }
 #if MPT_X_STAMPS

