@@ -124,7 +124,7 @@ struct MptRenderParams {
     MptVec4 *partial;                        // fast build: per-sample radiance [nframes][columns of the share][ny]
     unsigned long long *counters;            // mpt_counters when counting, else unused
     unsigned int *work_counter;              // persistent kernels: 8 per-range item counters
-    int *stack_spill;                        // wide kernel: 88 overflow stack entries per lane of the grid
+    int *stack_spill;                        // wide kernel: the overflow stack entries (128 - the LDS levels) of every lane of the grid
     unsigned int *watchdog;                  // host-pinned flag a persistent wave raises when it gives up
     unsigned long long *timeline;            // diagnostics: per wave {start, scene ready, queue empty, exit} in
                                              // 100 MHz ticks, or null

@@ -365,22 +365,23 @@ struct QuantScene {
 // levels live in LDS like Stack's, the (rare) rest in a per-lane strip of global memory
 struct SpillStack {
     static constexpr int SENTINEL = (int)0x80000000;
-    static constexpr int PLANE_OFF = 16;               // bytes between the lo and hi float4 of an axis in a wide record
+    static constexpr int PLANE_OFF = 0;                // (the 4-wide steps pick the entry planes by the sign of L.inv themselves: no per-ray offsets to carry)
 #ifndef MPT_X_SPILL_CAP
-#define MPT_X_SPILL_CAP 40     // (a test build sets it to a handful of levels so that every ray uses the global strip)
+#define MPT_X_SPILL_CAP 24     // (a test build sets it to a handful of levels so that every ray uses the global strip)
 #endif
-    static constexpr int CAP = MPT_X_SPILL_CAP, SPILL = 128 - CAP;    // 40 levels x 256 lanes x 4 B = 40 KiB of LDS: four workgroups per CU
+    static constexpr int CAP = MPT_X_SPILL_CAP, SPILL = 128 - CAP;    // 24 levels x 256 lanes x 4 B = 24 KiB of LDS: the five workgroups per CU the registers allow (and a sixth)
     int *base;                 // &lds[threadIdx.x]
-    int *spill;                // this lane's SPILL entries
+    int *spill;                // the launch's strips (wave-uniform: stays in scalar registers) ...
+    unsigned lane_off;         // ... and this lane's first entry in them: one register instead of a 64-bit pointer per lane
     int sp;
     DEV void push(int v) {
         if (sp < CAP) base[sp * MPT_BLOCK] = v;
-        else spill[sp - CAP] = v;
+        else spill[lane_off + (unsigned)(sp - CAP)] = v;
         sp++;
     }
     DEV int pop() {
         sp--;
-        return sp < CAP ? base[sp * MPT_BLOCK] : spill[sp - CAP];
+        return sp < CAP ? base[sp * MPT_BLOCK] : spill[lane_off + (unsigned)(sp - CAP)];
     }
     static constexpr bool PEEK = false;
     DEV int peek(int) const { return 0; }

@@ -305,9 +305,11 @@ DEV void lane_start_ray(LaneState &L, STACK &stk, V3 o, V3 d, float tmax, bool s
     L.inv = v3(m_rcp(d.x), m_rcp(d.y), m_rcp(d.z));
     L.oinv = o * L.inv;
     // which of an axis' two planes the ray enters through: offset of that plane in the node record
-    L.offx = __float_as_int(L.inv.x) < 0 ? STACK::PLANE_OFF : 0;
-    L.offy = __float_as_int(L.inv.y) < 0 ? STACK::PLANE_OFF : 0;
-    L.offz = __float_as_int(L.inv.z) < 0 ? STACK::PLANE_OFF : 0;
+    if constexpr (STACK::PLANE_OFF != 0) {     // (the 4-wide gather kernels read the signs off L.inv in the step: three registers less to carry)
+        L.offx = __float_as_int(L.inv.x) < 0 ? STACK::PLANE_OFF : 0;
+        L.offy = __float_as_int(L.inv.y) < 0 ? STACK::PLANE_OFF : 0;
+        L.offz = __float_as_int(L.inv.z) < 0 ? STACK::PLANE_OFF : 0;
+    }
     L.tbest = tmax; L.shadow = shadow ? 1 : 0; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f;
     stk.sp = 0;
     stk.push(STACK::SENTINEL);
@@ -445,9 +447,10 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
         const unsigned loy = (unsigned)__float_as_int(rc.x), hiy = (unsigned)__float_as_int(rc.y);
         const unsigned loz = (unsigned)__float_as_int(rc.z), hiz = (unsigned)__float_as_int(rc.w);
         // entry planes: the low ones for a ray going up the axis, the high ones for one going down (L.off*: per-ray flags)
-        const unsigned nxq = L.offx ? hix : lox, fxq = L.offx ? lox : hix;
-        const unsigned nyq = L.offy ? hiy : loy, fyq = L.offy ? loy : hiy;
-        const unsigned nzq = L.offz ? hiz : loz, fzq = L.offz ? loz : hiz;
+        const bool dnx = __float_as_int(L.inv.x) < 0, dny = __float_as_int(L.inv.y) < 0, dnz = __float_as_int(L.inv.z) < 0;
+        const unsigned nxq = dnx ? hix : lox, fxq = dnx ? lox : hix;
+        const unsigned nyq = dny ? hiy : loy, fyq = dny ? loy : hiy;
+        const unsigned nzq = dnz ? hiz : loz, fzq = dnz ? loz : hiz;
 #define MPT_UB(w, c) ((float)(((w) >> (8 * (c))) & 0xffu))
 #define MPT_QSLAB(c, tn, h)                                                                                            \
         tn = fmaxf(fmaxf(__builtin_fmaf(MPT_UB(nxq, c), sx, bx), __builtin_fmaf(MPT_UB(nyq, c), sy, by)),               \
@@ -459,7 +462,8 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
 #undef MPT_UB
     } else {
         MptVec4 nx, fx, ny, fy, nz, fz, idv;
-        sc.node4(L.curr, L.offx, L.offy, L.offz, nx, fx, ny, fy, nz, fz, idv);
+        sc.node4(L.curr, __float_as_int(L.inv.x) < 0 ? 16 : 0, __float_as_int(L.inv.y) < 0 ? 16 : 0, __float_as_int(L.inv.z) < 0 ? 16 : 0,
+                 nx, fx, ny, fy, nz, fz, idv);
         id0 = __float_as_int(idv.x); id1 = __float_as_int(idv.y); id2 = __float_as_int(idv.z); id3 = __float_as_int(idv.w);
 #define MPT_SLAB(c, tn, h)                                                                                              \
         tn = fmaxf(fmaxf(__builtin_fmaf(nx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(ny.c, L.inv.y, -L.oinv.y)),            \
@@ -975,14 +979,18 @@ __global__ MPT_RENDER_BOUNDS void MPT_SUFFIX(render_kernel)(const MptRenderParam
 #if !MPT_STRICT
 // ---------------------------------------------------------------- gather kernel over 4-wide nodes
 #ifndef MPT_WIDE_WAVES
-#define MPT_WIDE_WAVES 4      // waves per SIMD the 4-wide gather kernel is compiled for (its register budget: 512 / this)
+#define MPT_WIDE_WAVES 5      // waves per SIMD the 4-wide gather kernel is compiled for (its register budget: 512 / this = 96 VGPRs).
+                              // At 96 the allocator parks 27 dwords per lane in scratch, all of them in the shading pass (SHADE's own
+                              // temporaries and the prepared primary rays), none in the traversal loop: MI355X C4 1520 -> 1580,
+                              // C5 778 -> 825 Msamples/s.  Six waves (80 VGPRs) spill into the steps and lose a third.
 #endif
 template <bool COUNT, bool QUANT>
 __global__ __launch_bounds__(MPT_BLOCK, MPT_WIDE_WAVES) void render_kernel_wide(const MptRenderParams p) {
     __shared__ int s_stack[SpillStack::CAP * MPT_BLOCK];
     SpillStack stk;
     stk.base = s_stack + threadIdx.x;
-    stk.spill = p.stack_spill + ((size_t)blockIdx.x * MPT_BLOCK + threadIdx.x) * SpillStack::SPILL;
+    stk.spill = p.stack_spill;
+    stk.lane_off = (blockIdx.x * MPT_BLOCK + threadIdx.x) * (unsigned)SpillStack::SPILL;   // (grid x 256 x 88 entries: far below 2^32)
     stk.sp = 0;
     Cnt cnt = {};
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
