@@ -259,6 +259,7 @@ struct Stack {
 
 // scene records served from HBM/L2 through the vector L1 (any scene size)
 struct GlobalScene {
+    static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false;
     const MptVec4 *fnode, *tgeo;
     int soa_n;                 // node count, for the layout A/B build below
@@ -283,6 +284,7 @@ struct GlobalScene {
 // those fetches, not their bytes, are what bounds the big scenes (measured: binary16 boxes at half the bytes
 // bought 3-7 %)
 struct WideScene {
+    static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr bool WIDE = true, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false;
     const MptVec4 *wnode, *tgeo;
     // entry (n*) and exit (f*) planes of the four children, picked by the ray's direction signs: o* is 0 for a ray
@@ -332,6 +334,7 @@ struct WideScene {
 // for is the number of divergent gathers, not bytes -- and the 36 extra VALU instructions of the decode are free
 // at 34-43 % issue utilisation.
 struct QuantScene {
+    static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false;
     const MptVec4 *qnode, *tgeo;
     DEV void node4q(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &id) const {
@@ -403,6 +406,10 @@ typedef __attribute__((address_space(3))) const unsigned char *LdsU8Ptr;
 #define MPT_LDS_MAT_VEC4 6      // float4 of a material record kept in LDS: p[0..15] and the derived terms d[0..7]
 
 struct LdsScene {
+#ifndef MPT_SHADE_MIN_LDS
+#define MPT_SHADE_MIN_LDS 24
+#endif
+    static constexpr int SHADE_MIN = MPT_SHADE_MIN_LDS; // SHADE waits until this many lanes want it (render_kernel.hip trace_stream)
     static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = true, LDS_MATS = true;
     LdsVec4Ptr fnode, tgeo;
     // The material records (parameters + derived terms, 96 B each, the default material last) and one byte per

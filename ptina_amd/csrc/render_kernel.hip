@@ -738,6 +738,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     int S = 0, next = 0;                            // wave-uniform: current pool = 64*frames samples; next unassigned
     int ti = 0, tj = 0, f0 = 0, tx_cur = 0;
     int ndead = 0;                                  // wave-uniform: lanes that have left for good
+    int deferred = 0;                               // wave-uniform: lanes whose SHADE the last pass put off (MPT_SHADE_MIN)
     bool more = true;
     PrimaryPool pool;                               // lane l: primary ray of sample pool_base + l of the current item
     pool.ro = v3s(0.0f); pool.rd = v3s(0.0f); pool.rng_i = 0; pool.rng_k = -1;
@@ -774,7 +775,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             if (trav == 0) break;
             // leave when the waiting lanes (DONE or NEW: everything alive that is not traversing) outnumber the
             // traversing ones 2 : 1 (best of the ratios tried on MI355X)
-            if (trav * MPT_LEAVE_A < (64 - ndead - trav) * MPT_LEAVE_B) break;
+            if (trav * MPT_LEAVE_A < (64 - ndead - trav - deferred) * MPT_LEAVE_B) break;
             MPT_STAMP_BEGIN
             if (cn * MPT_PREF_NODE >= cl * MPT_PREF_LEAF) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
@@ -821,7 +822,19 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
         }
         // ---- shading mode
 #if MPT_ONE_START
-        if (wave_count(L.st == ST_DONE && !L.shadow) != 0) {
+        bool shade_now = wave_count(L.st == ST_DONE && !L.shadow) != 0;
+        if constexpr (SCENE::SHADE_MIN > 0) {
+            // SHADE costs a wave the same whatever the number of lanes in it (8 400 cycles; a NODE step 575): with fewer than
+            // SHADE_MIN lanes waiting for it, and other lanes still traversing, the pass serves the cheap stages only and the
+            // lanes wait for company (they are left out of the traversal loop's leave test meanwhile).  LDS-resident kernel:
+            // SHADE at 36 lanes instead of 26, 3.18 -> 3.06 ms; the gather kernels, where a step costs three times as much and
+            // an idle lane with it, lose 5-14 % and keep SHADE_MIN = 0.
+            const int ns = wave_count(L.st == ST_DONE && !L.shadow);
+            const int ntrav = wave_count(L.st == ST_NODE || L.st == ST_LEAF);
+            shade_now = ns != 0 && (ns >= SCENE::SHADE_MIN || ns * 2 >= 64 - ndead || ntrav == 0);
+            deferred = shade_now ? 0 : ns;
+        }
+        if (shade_now) {
             if (COUNT && (threadIdx.x & 63) == 0) cnt.it_shade++;
             MPT_STAMP_BEGIN
             if (L.st == ST_DONE && !L.shadow) {
@@ -838,7 +851,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             MPT_STAMP_BEGIN
             // a shadow ray has finished: the candidate direct light is added if nothing was hit (path.py:51,56); the next
             // bounce starts from hitpos (= the shadow ray's origin, still in L.to), path.py:60
-            if (L.st == ST_DONE) {                                           // (the closest-hit lanes have left DONE above)
+            if (L.st == ST_DONE && L.shadow) {
                 if (L.hidx < 0) L.result = L.result + L.direct;
                 L.st = ST_BOUNCE;
             }
