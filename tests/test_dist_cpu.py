@@ -272,8 +272,8 @@ def test_bench_n_gpu_line_carries_the_config3_leg(tmp_path):
     c3 = line['c3']
     assert c3['n_gpus'] == 2 and c3['steps'] == 2 and '2048x2048' in c3['workload']
     assert c3['msamples_s'] > 0 and c3['ms_per_step'] > 0
-    assert abs(c3['model_ms_per_step'] - (45.0 / 2 + 0.5)) < 1e-6 and 'a / N + b' in c3['model']
-    assert abs(line['model_ms_per_step'] - (2.8 / 2 + 0.5)) < 1e-6
+    assert abs(c3['model_ms_per_step'] - (41.0 / 2 + 0.5)) < 1e-6 and 'a / N + b' in c3['model']
+    assert abs(line['model_ms_per_step'] - (2.55 / 2 + 0.5)) < 1e-6
     # one GPU: no c3 leg, no model keys
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--stub'],
                        env=env, capture_output=True, text=True, timeout=120)
