@@ -771,7 +771,7 @@ def test_scene_scale_dependence_is_the_references(fresh, oracle_mod, k):
             # a scene 500x smaller than the constants eps = 1e-6, inf = 1e6 were chosen for: many hits sit on the
             # |b| >= eps threshold of geometries.py:129 and flip with the last bit (measured: strict 0.12 % of the
             # pixels / rel-RMSE 1.9e-3, fast 0.61 % / 2.9e-3)
-            b = (1e-4, 0.005, 6e-3) if mode == 'strict' else (1e-3, 0.02, 1e-2)
+            b = (1e-4, 0.0025, 3.5e-3) if mode == 'strict' else (1e-3, 0.012, 5e-3)
         else:
             b = bounds(mode)
         assert_parity(FilmTable().get_image(), want, *b, what=f'scale {k} {mode}')
@@ -943,7 +943,7 @@ def test_full_size_properties_and_oracle_parity(fresh, oracle_mod, name):
     ref.render(spp)
     want = ref.get_image()[x0:x1]
     # rel-RMSE of the whole 262 144-pixel film: a handful of flipped 32-spp pixels put it at 9e-5 (measured)
-    assert_parity(imgs['strict'][x0:x1], want, STRICT[0], STRICT[1], 3e-4, what=f'full-size strict, columns [{x0},{x1})')
+    assert_parity(imgs['strict'][x0:x1], want, STRICT[0], STRICT[1], 1.5e-4, what=f'full-size strict, columns [{x0},{x1})')
     assert_parity(imgs['fast'][x0:x1], want, *FAST, what=f'full-size fast, columns [{x0},{x1})')
 
 
@@ -1403,7 +1403,7 @@ def test_config5_reference_build_fails_on_the_stated_scene(fresh, oracle_mod):
     strict = FilmTable().get_image()
     reset_all()
     from helpers import assert_parity
-    assert_parity(fast[x0:x1], strict[x0:x1], FAST[0], FAST[1], 6e-3, what='C5 (seed 12345) fast vs strict, 8 columns')
+    assert_parity(fast[x0:x1], strict[x0:x1], FAST[0], FAST[1], 3e-3, what='C5 (seed 12345) fast vs strict, 8 columns')   # measured 1.7e-3
 
 
 def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
@@ -1443,7 +1443,7 @@ def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
     assert np.all(raw[..., 3] == spp) and np.isfinite(raw).all() and raw[..., :3].min() >= 0
     # 8192 pixels at 16 spp over a triangle soup: a handful of pixels whose closest hit flips between two
     # nearly coincident triangles carry the RMSE (measured: 0.10 % outliers, rel-RMSE 2.9e-3, max diff 0.14)
-    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 6e-3, what='C5 1M triangles fast, 8 columns x 16 spp')
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 4.5e-3, what='C5 1M triangles fast, 8 columns x 16 spp')
     assert ctx().get_option('last_kernel') == 2           # gather kernel over the 4-wide collapse (465 k nodes, 8-bit child boxes)
     # the same with the exact child boxes (option wide_quant = 0: 128-B records)
     ctx().set_option('wide_quant', 0)
@@ -1452,7 +1452,7 @@ def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
     eng.render(spp)
     raw = FilmTable().get_raw().reshape(nx, ny, 4)
     assert ctx().get_option('last_kernel') == 2 and np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
-    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 6e-3, what='C5 1M triangles fast, exact 4-wide boxes, 8 columns x 16 spp')
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 4.5e-3, what='C5 1M triangles fast, exact 4-wide boxes, 8 columns x 16 spp')
     # the same through the binary tree (option wide = 0)
     ctx().set_option('wide', 0)
     FilmTable().clear()
@@ -1460,13 +1460,13 @@ def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
     eng.render(spp)
     raw = FilmTable().get_raw().reshape(nx, ny, 4)
     assert ctx().get_option('last_kernel') == 0 and np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
-    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 6e-3, what='C5 1M triangles fast over the binary tree, 8 columns x 16 spp')
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 4.5e-3, what='C5 1M triangles fast over the binary tree, 8 columns x 16 spp')
     reset_all()
     eng = _engine(None, scene, nx, ny, mode='strict', slab=(x0, x1))
     eng.render(spp)
     # one pixel of the 8192 picks the other of two nearly coincident triangles (libm's last bit): 0.012 %
     # outliers, but its 0.03 difference alone puts the window's rel-RMSE at 3.4e-4 (measured)
-    assert_parity(FilmTable().get_image()[x0:x1], want, STRICT[0], STRICT[1], 1e-3, what='C5 1M triangles strict, 8 columns x 16 spp')
+    assert_parity(FilmTable().get_image()[x0:x1], want, STRICT[0], STRICT[1], 5.5e-4, what='C5 1M triangles strict, 8 columns x 16 spp')
     reset_all()
 
 
@@ -1494,7 +1494,7 @@ def test_config4_full_scene_with_environment_vs_oracle(fresh, oracle_mod):
     raw = FilmTable().get_raw().reshape(nx, ny, 4)
     assert np.all(raw[..., 3] == spp) and np.isfinite(raw).all() and raw[..., :3].min() >= 0
     # one pixel next to the environment map's sun lobe differs by 0.79 at 8 spp: it alone is 1.4e-3 of rel-RMSE
-    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 4e-3, what='C4 99k triangles + env fast, 32 columns x 8 spp')
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 2.5e-3, what='C4 99k triangles + env fast, 32 columns x 8 spp')
     reset_all()
     eng = _engine(None, scene, nx, ny, mode='strict', world=world, slab=(x0, x1))
     eng.render(spp)
