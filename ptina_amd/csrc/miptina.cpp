@@ -843,9 +843,16 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         }
         p.fnode = c->fnode_soa; p.fnode_soa_n = (int)ni;
     }
+    // Lanes per persistent workgroup of the LDS-resident kernel.  A launch that gives a lane fewer than six samples (an eighth
+    // of the benchmark film: four) is over before a steady state forms: its length is a few path latencies, and a path is
+    // faster with three waves per SIMD than with four (MI355X, 1/8 share: 0.78 ms at 768 lanes against 0.84 at 1024; from a
+    // quarter share upwards 1024 is as good or better).  Same film either way.
+    int lds_block_used = c->lds_block ? c->lds_block : 1024;
+    if (lds_kernel && !pool_kernel && c->lds_block == 0 &&
+        (long long)p.nitems * 64 * chunk < 6ll * launch_cus * 1024) lds_block_used = 768;
     p.timeline = nullptr;
     if (c->timeline && lds_kernel) {
-        const int block = c->lds_block ? c->lds_block : 1024;
+        const int block = lds_block_used;
         const int waves = launch_cus * (block / 64);
         if (waves != c->timeline_waves) {
             HIP_TRY(hipDeviceSynchronize());
@@ -859,7 +866,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     HIP_TRY(hipEventRecord(e0, rs));
     if (!fast) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, rs));
     else if (pool_kernel) HIP_TRY(mpt_launch_render_pool(&p, launch_cus, 1024, pool_bytes, c->count, rs));
-    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, launch_cus, c->lds_block ? c->lds_block : 1024, lds_bytes, c->count, rs));
+    else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, launch_cus, lds_block_used, lds_bytes, c->count, rs));
     else if (wide_kernel) HIP_TRY(mpt_launch_render_wide(&p, wide_blocks, c->count, c->use_quant, rs));
     else HIP_TRY(mpt_launch_render_fast(&p, launch_cus, stack, c->count, rs));
     c->last_kernel = pool_kernel ? 3 : lds_kernel ? 1 : wide_kernel ? 2 : 0;
