@@ -96,6 +96,8 @@ void mpt_destroy(mpt_ctx *ctx);
  * walks the LBVH itself; default 2^22), "grid_div" (each launch takes 1/G of the CUs so that G launches are resident
  * in different phases; 0 = choose by samples per lane, and the whole chip for a launch that finds nothing else in flight: default), "pipe_depth" (batches in flight,
  * 2..6; 0 = auto), "lds_block" (lanes per persistent workgroup of the LDS kernel, diagnostics),
+ * "zero_copy" (1, default: mpt_get_image into an mpt_host_alloc array has the resolve pass write the image straight into it over
+ * PCIe; 0: device buffer + DMA -- same image, 20 us more per call),
  * "skip_dark" (1 = a shadow ray whose candidate direct light is exactly zero -- the light behind the surface -- is not traced:
  * adding zero or not is the same sum; 0 = traced like the reference does; -1 = on in the production build, off in the strict build: default), "pool" /
  * "pool_shaders" (the LDS kernel with its waves specialised into tracers and shaders and two path pools in LDS between them:

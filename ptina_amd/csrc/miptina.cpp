@@ -283,6 +283,8 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->count = value ? 1 : 0;
     } else if (k == "lds") {
         c->use_lds = value ? 1 : 0;
+    } else if (k == "zero_copy") {
+        c->zero_copy = value ? 1 : 0;
     } else if (k == "skip_dark") {
         if (value < -1 || value > 1) return fail("skip_dark must be -1 (auto), 0 or 1");
         c->skip_dark = value;
@@ -350,6 +352,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "pending") *value = c->pending;
     else if (k == "lds") *value = c->use_lds;
     else if (k == "lds_block") *value = c->lds_block;
+    else if (k == "zero_copy") *value = c->zero_copy;
     else if (k == "pool") *value = c->use_pool;
     else if (k == "skip_dark") *value = c->skip_dark;
     else if (k == "pool_shaders") *value = c->pool_shaders;
@@ -980,8 +983,20 @@ extern "C" int mpt_resolve(mpt_ctx *c, int pass) {
 }
 
 extern "C" int mpt_get_image(mpt_ctx *c, int pass, float *out) {               // filmtable.py:47-63
+    const size_t bytes = (size_t)c->nx * c->ny * sizeof(MptVec4);
+    void *mapped = nullptr;
+    if (c->zero_copy && is_locked_range(out, bytes) && hipHostGetDevicePointer(&mapped, out, 0) == hipSuccess && mapped) {
+        // the caller's array is page-locked memory of ours: the resolve pass writes the image straight into it over PCIe,
+        // instead of into a device buffer that a DMA then copies (one dependent hop and the copy engine's start-up less)
+        if (use_ro(c)) return 1;
+        if (mpt_flush(c)) return 1;
+        if (check_pass(c, pass)) return 1;
+        HIP_TRY(mpt_launch_resolve(c->film[pass], (MptVec4 *)mapped, (size_t)c->nx * c->ny, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return check_watchdog(c);
+    }
     if (mpt_resolve(c, pass)) return 1;
-    if (read_back(c, out, c->resolved, (size_t)c->nx * c->ny * sizeof(MptVec4))) return 1;
+    if (read_back(c, out, c->resolved, bytes)) return 1;
     return check_watchdog(c);
 }
 

@@ -85,7 +85,7 @@ struct mpt_ctx {
     mpt_caps caps{};
 
     // options
-    int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1, lds_block = 0;
+    int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1, lds_block = 0, zero_copy = 1;
     int skip_dark = -1;                  // -1 auto (production build on, strict build off), 0 / 1 as set: do not trace shadow rays whose candidate direct light is exactly zero (production build: default;
                                          // the strict build traces them like the reference unless the option is set explicitly to 1 there)
     int use_pool = 0, pool_shaders = 3;  // LDS kernel with specialised waves and path pools (render_pool.h)

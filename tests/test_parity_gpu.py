@@ -131,6 +131,16 @@ def test_film_api_semantics(fresh):
     img = film.get_image()
     assert np.all(raw[..., 3] == 2.0)
     assert np.array_equal(img[..., :3], raw[..., :3] / raw[..., 3:4]) and np.all(img[..., 3] == 1)
+    # the same image whichever way it travels: written by the resolve pass straight into the page-locked array (default),
+    # through a device buffer and a DMA (zero_copy = 0), or into an ordinary numpy array through the staging buffer
+    from ptina_amd.common import ctx
+    from ptina_amd._lib import fptr
+    ctx().set_option('zero_copy', 0)
+    assert np.array_equal(film.get_image().view(np.uint32), img.view(np.uint32))
+    ctx().set_option('zero_copy', 1)
+    plain = np.empty((20, 12, 4), np.float32)
+    ctx().call('mpt_get_image', 0, fptr(plain))
+    assert np.array_equal(plain.view(np.uint32), img.view(np.uint32))
     flat = np.zeros(20 * 12 * 3, np.float32)
     film.fast_export_image(flat)
     assert np.array_equal(flat.reshape(12, 20, 3), np.swapaxes(img[..., :3], 0, 1))   # (y*nx + x)*3
