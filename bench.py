@@ -515,6 +515,10 @@ def main():
         sys.exit(rc)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        # dmabuf IPC is what RCCL needs on this driver; a launcher that did not export it (torchrun passes its own
+        # environment on) would fail in hipIpcGetMemHandle.  Set before this process makes its first HIP call.
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     pmc, pmc_source = None, 'not collected'
