@@ -589,6 +589,68 @@ def test_lights_and_area_light_parity(fresh, oracle_mod):
         assert_parity(FilmTable().get_image(), ref.get_image(), *bounds(mode), what=f'lights {mode}')
 
 
+
+@pytest.mark.parametrize('seed', [11, 12, 13, 14, 15, 16])
+def test_random_scenes_parity(fresh, oracle_mod, seed):
+    '''seeded random scenes -- the cornell walls plus 5..300 triangles of random place, size and (smooth) normals, random
+    opaque Disney materials (every parameter but clearcoat and transmission, whose reference arithmetic is its own subject
+    above), 1..3 point / area lights, a random constant world light -- through the strict build and through the production
+    build's LDS-resident, binary gather and 4-wide gather kernels, against the oracle at the calibrated bounds.  Nothing here
+    is tuned to the benchmark scene: different lane mixes for the in-wave scheduler, paths that end early (dark materials),
+    shadow rays that are skipped, lights that are hit directly.'''
+    from helpers import setup_oracle, assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd.tools.matrix import translate
+    rng = np.random.default_rng(seed)
+    walls = scenes.cornell_walls()
+    k = int(rng.integers(5, 301)) if seed % 2 else int(rng.integers(5, 61))
+    c = rng.uniform([-1.6, 0.3, -1.6], [1.6, 3.4, 1.2], (k, 1, 3))
+    P = c + rng.normal(0.0, 1.0, (k, 3, 3)) * rng.uniform(0.08, 0.7, (k, 1, 1))
+    fn = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    fn /= np.linalg.norm(fn, axis=1, keepdims=True) + 1e-30
+    N = fn[:, None, :] + rng.normal(0.0, 0.25, (k, 3, 3))
+    N /= np.linalg.norm(N, axis=2, keepdims=True)
+    T = rng.uniform(0.0, 1.0, (k, 3, 2))
+    nm = int(rng.integers(2, 6))
+    M = rng.integers(3, 3 + nm, k).astype(np.int32)
+    vertices, mtlids = scenes._compose([walls, (P, N, T, M)])
+    mats = list(scenes.WALL_MATERIALS)
+    for _ in range(nm):
+        mats.append(scenes.material(basecolor=tuple(rng.uniform(0.0, 1.0, 3) * (rng.random() > 0.15)), metallic=float(rng.random() ** 2),
+                                    roughness=float(rng.uniform(0.05, 1.0)), specular=float(rng.random()),
+                                    specularTint=float(rng.random()), subsurface=float(rng.random() * (rng.random() > 0.5)),
+                                    sheen=float(rng.random() * (rng.random() > 0.5)), sheenTint=float(rng.random())))
+    scene = (vertices, mtlids, mats, [])
+    rot = np.eye(4)
+    rot[:3, :3] = [[1, 0, 0], [0, 0, 1], [0, -1, 0]]
+    lights = []
+    for _ in range(int(rng.integers(1, 4))):
+        pos = rng.uniform([-1.5, 2.2, -1.5], [1.5, 3.8, 1.5])
+        if rng.random() < 0.5:
+            lights.append((translate(list(pos)) @ rot, rng.uniform(4.0, 20.0, 3), float(rng.uniform(0.2, 0.7)), 'AREA'))
+        else:
+            lights.append((translate(list(pos)), rng.uniform(4.0, 20.0, 3), float(rng.uniform(0.05, 0.4)), 'POINT'))
+    world = ([float(x) for x in rng.uniform(0.0, 0.4, 3)] + [1.0], -1)
+    nx, ny, spp = 48, 40, 8
+    ref = setup_oracle(oracle_mod, scene, nx, ny, lights=lights, world=world)
+    ref.render(spp)
+    want = ref.get_image()
+    assert np.isfinite(want).all()
+    for mode, opts in (('strict', {}), ('fast', {}), ('fast', {'lds': 0, 'wide': 0}), ('fast', {'lds': 0})):
+        reset_all()
+        eng = _engine(None, scene, nx, ny, mode=mode, lights=lights, world=world)
+        for key, val in opts.items():
+            ctx().set_option(key, val)
+        eng.render(spp)
+        raw = FilmTable().get_raw().reshape(nx, ny, 4)
+        assert np.all(raw[..., 3] == spp)
+        kernel = ctx().get_option('last_kernel')
+        if mode == 'fast':
+            assert kernel == (1 if not opts else 0 if 'wide' in opts else 2), (opts, kernel)
+        assert_parity(FilmTable().get_image(), want, *bounds(mode), what=f'random scene {seed} ({k} triangles) {mode} {opts}')
+    reset_all()
+
 def test_textures_and_environment_parity(fresh, oracle_mod):
     from helpers import setup_oracle, assert_parity
     from ptina_amd.things import FilmTable
