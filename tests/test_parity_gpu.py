@@ -196,6 +196,31 @@ def test_work_item_shape_does_not_change_the_film(fresh):
         assert np.array_equal(film, ref), key
 
 
+def test_workgroup_size_does_not_change_the_film(fresh):
+    '''the LDS-resident kernel picks its persistent workgroup by the launch's size (768 lanes below six samples per lane,
+    1024 above: miptina.cpp); whatever is picked or forced -- 256, 512, 768, 1024 lanes, i.e. 1 to 4 waves per SIMD sharing
+    the scheduler's passes differently -- the film is the same bit for bit, on a film small enough for the rule's small side
+    and on one on its large side'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    for nx, ny, spp in ((52, 43, 8), (640, 512, 6)):          # 0.07 and 7.5 samples per lane of a 256-CU launch
+        films = {}
+        for block in (0, 256, 512, 768, 1024):
+            reset_all()
+            eng = _engine(None, scenes.scene_s978(), nx, ny, mode='fast', max_filmsize=max(nx * ny, 1 << 18))
+            c = ctx()
+            c.set_option('batch', 8)
+            c.set_option('lds_block', block)
+            eng.render(spp)
+            c.call('mpt_flush')
+            assert c.get_option('last_kernel') == 1
+            films[block] = FilmTable().get_raw().copy()
+        reset_all()
+        assert np.all(films[0].reshape(nx, ny, 4)[..., 3] == spp)
+        for block, film in films.items():
+            assert np.array_equal(film.view(np.uint32), films[0].view(np.uint32)), (nx, ny, block)
+
+
 def test_slabs_reassemble_bit_identically(fresh):
     '''two column slabs rendered separately == the full film (what the multi-GPU path relies on)'''
     from ptina_amd.things import FilmTable
