@@ -852,7 +852,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     // quarter share upwards 1024 is as good or better).  Same film either way.
     int lds_block_used = c->lds_block ? c->lds_block : 1024;
     if (lds_kernel && !pool_kernel && c->lds_block == 0 &&
-        (long long)p.nitems * 64 * chunk < 6ll * launch_cus * 1024) lds_block_used = 768;
+        ((long long)p.nitems * chunk << (c->tile_w_shift + c->tile_h_shift)) < 6ll * launch_cus * 1024) lds_block_used = 768;
     p.timeline = nullptr;
     if (c->timeline && lds_kernel) {
         const int block = lds_block_used;
