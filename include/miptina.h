@@ -140,6 +140,12 @@ int mpt_get_tree(mpt_ctx *ctx, int32_t *child /*[n-1][2]*/, int32_t *leaf /*[n]*
  * child boxes, qnode [nw][4][4] with 8-bit boxes; any pointer may be NULL; *nw = wide nodes built (0: none) */
 int mpt_get_wide(mpt_ctx *ctx, float *wnode, float *qnode, int cap_nodes, int *nw);
 
+/* Pure sizing rule of the on-device SAH re-partition's workspace (no context, no GPU; the reference has no counterpart: its
+ * tree is the LBVH of ptina/tree/lbvh.py:297-305).  For a model of n faces: out[0] = segments a level can hold, out[1] = words
+ * of per-segment workspace the build allocates, out[2] = words a level of `nseg` segments writes, out[3] = bins per axis at
+ * that level.  The build is sound iff out[2] <= out[1] for every nseg <= out[0]; returns 0, or 1 for n < 1 / nseg < 0. */
+int mpt_sah_workspace(int n, int64_t nseg, int64_t out[4]);
+
 /* Camera.set_perspective, ptina/camera.py:19-22: the two f32 matrices the reference stores
  * (V2W = inv(pers) computed by the caller in f64 exactly as the reference does) */
 int mpt_set_camera(mpt_ctx *ctx, const float v2w[16], const float w2v[16]);

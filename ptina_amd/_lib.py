@@ -65,6 +65,7 @@ SIGNATURES = {
     'mpt_build_tree': (_i, [_vp]),
     'mpt_get_tree': (_i, [_vp, _ip, _ip, _fp, _fp, _ip, _ip]),
     'mpt_get_wide': (_i, [_vp, _fp, _fp, _i, C.POINTER(_i)]),
+    'mpt_sah_workspace': (_i, [_i, C.c_int64, C.POINTER(C.c_int64)]),
     'mpt_set_camera': (_i, [_vp, _fp, _fp]),
     'mpt_clear_lights': (_i, [_vp]),
     'mpt_add_light': (_i, [_vp, _i, _fp, _fp, _fp, C.c_float, C.POINTER(_i)]),

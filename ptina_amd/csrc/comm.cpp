@@ -167,6 +167,10 @@ extern "C" int mpt_comm_gather_film(mpt_ctx *c, int pass, int root) {
     const int key[6] = { c->nx, c->ny, c->stripe_w, R, c->rank, root };
     if (memcmp(key, c->plan_key, sizeof key) != 0) {
         HIP_TRY(hipStreamSynchronize(c->stream));
+        // the cached plan is dead from here on: a failure below must not leave a key that matches a later call (round-3 ADVICE)
+        for (int k = 0; k < 6; k++) c->plan_key[k] = -1;
+        c->plan_npieces = 0; c->plan_max_count = 0;
+        if (tab.size() > 65535) return fail("film gather: %zu pieces exceed the 65535 the pack kernel's grid takes (wider stripes)", tab.size());
         if ((size_t)total > c->gather_cap) {
             hipFree(c->gather_buf); c->gather_buf = nullptr; c->gather_cap = 0;
             if (dev_alloc(&c->gather_buf, (size_t)total)) return 1;

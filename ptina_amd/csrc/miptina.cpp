@@ -330,6 +330,8 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         (k == "tile_w_shift" ? c->tile_w_shift : c->tile_h_shift) = value;
     } else if (k == "gpu_build") {
         if ((value ? 1 : 0) != c->gpu_build) { c->gpu_build = value ? 1 : 0; c->tree_valid = false; }
+    } else if (k == "sah_inject_fail") {
+        c->sah_inject_fail = value != 0; c->tree_valid = false;
     } else if (k == "sah_max") {
         c->sah_max = value; c->tree_valid = false;
     } else {
@@ -368,6 +370,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "wide_quant") *value = c->use_quant;
     else if (k == "wide_build") *value = c->wide_build;
     else if (k == "sah_build") *value = c->sah_build;
+    else if (k == "sah_fallback") *value = c->sah_fallback;
     else if (k == "wide_nodes") *value = c->wide_nodes;
     else if (k == "wide_ratio_permille") *value = (int)(c->wide_ratio * 1000.f + 0.5f);
     else if (k == "wide_depth") *value = c->wide_depth;
@@ -983,12 +986,12 @@ extern "C" int mpt_resolve(mpt_ctx *c, int pass) {
 }
 
 extern "C" int mpt_get_image(mpt_ctx *c, int pass, float *out) {               // filmtable.py:47-63
+    if (use_ro(c)) return 1;                   // validates the handle and makes the context's device current (round-3 ADVICE)
     const size_t bytes = (size_t)c->nx * c->ny * sizeof(MptVec4);
     void *mapped = nullptr;
     if (c->zero_copy && is_locked_range(out, bytes) && hipHostGetDevicePointer(&mapped, out, 0) == hipSuccess && mapped) {
         // the caller's array is page-locked memory of ours: the resolve pass writes the image straight into it over PCIe,
         // instead of into a device buffer that a DMA then copies (one dependent hop and the copy engine's start-up less)
-        if (use_ro(c)) return 1;
         if (mpt_flush(c)) return 1;
         if (check_pass(c, pass)) return 1;
         HIP_TRY(mpt_launch_resolve(c->film[pass], (MptVec4 *)mapped, (size_t)c->nx * c->ny, c->stream));

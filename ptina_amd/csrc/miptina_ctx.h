@@ -57,6 +57,7 @@ struct MptLbvhBuffers {
 };
 MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n);
 MPT_KERNEL_API size_t mpt_sah_seg_words(int n);
+MPT_KERNEL_API size_t mpt_sah_level_words(size_t nseg, int *nb_out);
 MPT_KERNEL_API hipError_t mpt_sah_scan_bytes(int n, size_t *bytes);
 MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipStream_t stream);
 MPT_KERNEL_API hipError_t mpt_wide_scan_bytes(int ni, size_t *bytes);
@@ -135,6 +136,8 @@ struct mpt_ctx {
     int wide_nodes = 0, wide_depth = 0;               // 0 nodes: not built (scene fits LDS, or too deep)
     float wide_ratio = 1.f;                           // expected fetches per ray, wide / binary (surface-area sums)
     int sah_exact_max = 8192;                         // host SAH pass: ranges up to this size are swept exactly (diagnostics)
+    int sah_inject_fail = 0;                          // test door: treat the device SAH pass as failed after it ran
+    int sah_fallback = 0;                             // last build: the device SAH pass gave up (1: error, 2: depth) and the host pass ran
     int sah_build = -1;                               // SAH re-partition: 1 on the device (sah_build.hip), 0 host pass, -1 auto
                                                       // (device above 32768 faces: the host's exact sweep is the better tree
                                                       // for small scenes and costs them milliseconds)

@@ -70,7 +70,7 @@ struct MptSahBuffers {
     int *idx[2], *seg[2];                                // [n] slot permutation and segment of every position (double-buffered)
     int *pred, *pscan;                                   // [n]
     int *sb[2], *se[2], *snode[2];                       // [SC] segment tables (double-buffered)
-    int *segw;                                           // [mpt_sah_seg_words(n)] per-segment bounds + bins of one level
+    int *segw; size_t seg_words;                         // [seg_words = mpt_sah_seg_words(n)] per-segment bounds + bins of one level
     int *dec, *flag, *foff;                              // [SC][4], [2 SC], [2 SC]
     int *small;                                          // [n / 2 + 1][4]
     int *counters;                                       // [4]: small segments, depth

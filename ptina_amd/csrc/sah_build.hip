@@ -495,7 +495,22 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_pack_kernel(int ni, const int *__
 
 MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n) { return (size_t)n / (SB_SMALL + 1) + 2; }
 // words of segment workspace: enough for every level's (segments x words at that level's bin count)
-MPT_KERNEL_API size_t mpt_sah_seg_words(int n) { return 12 * mpt_sah_seg_capacity(n) + 27 * (size_t)SB_BIN_BUDGET + SB_SEG_WORDS(SB_MAXBINS); }
+// A level with more than SB_MINBINS bins keeps segments x bins within SB_BIN_BUDGET (the rule in mpt_sah_build); once the
+// segments outnumber SB_BIN_BUDGET / (2 SB_MINBINS) the bin count stays at SB_MINBINS and the level needs segments x
+// SB_SEG_WORDS(SB_MINBINS) words, up to the segment capacity: the larger of the two bounds (round-3 ADVICE: the first alone
+// is too small above ~1.08 M faces).
+MPT_KERNEL_API size_t mpt_sah_level_words(size_t nseg, int *nb_out) {
+    int nb = SB_MINBINS;
+    while (nb < SB_MAXBINS && nseg * (size_t)(2 * nb) <= (size_t)SB_BIN_BUDGET) nb *= 2;
+    if (nb_out) *nb_out = nb;
+    return nseg * SB_SEG_WORDS(nb);
+}
+MPT_KERNEL_API size_t mpt_sah_seg_words(int n) {
+    const size_t sc = mpt_sah_seg_capacity(n);
+    const size_t binned = 12 * sc + 27 * (size_t)SB_BIN_BUDGET + SB_SEG_WORDS(SB_MAXBINS);
+    const size_t deep = sc * SB_SEG_WORDS(SB_MINBINS);
+    return binned > deep ? binned : deep;
+}
 MPT_KERNEL_API hipError_t mpt_sah_scan_bytes(int n, size_t *bytes) {
     int *p = nullptr;
     return rocprim::exclusive_scan(nullptr, *bytes, p, p, 0, (size_t)std::max(n, 2), rocprim::plus<int>());
@@ -520,8 +535,8 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
         const int gs = (nseg + SB_BLOCK - 1) / SB_BLOCK;
         // bins per axis at this level: as many as the budget allows for this many segments
         int nb = SB_MINBINS;
-        while (nb < SB_MAXBINS && (size_t)nseg * (size_t)(2 * nb) <= (size_t)SB_BIN_BUDGET) nb *= 2;
-        const size_t words = (size_t)nseg * SB_SEG_WORDS(nb);
+        const size_t words = mpt_sah_level_words((size_t)nseg, &nb);
+        if (words > B->seg_words) return hipErrorOutOfMemory;     // (cannot happen with a workspace of mpt_sah_seg_words(n))
         hipLaunchKernelGGL(sb_reset_kernel, dim3((unsigned)((words + SB_BLOCK - 1) / SB_BLOCK)), dim3(SB_BLOCK), 0, stream, nseg, nb, B->segw);
         hipLaunchKernelGGL(sb_bounds_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->plo, B->phi, nb, B->segw);
         hipLaunchKernelGGL(sb_bin_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->plo, B->phi, nb, B->segw);

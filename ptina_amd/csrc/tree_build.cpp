@@ -401,6 +401,16 @@ static void pack_fnode(mpt_ctx *c, int n, const std::vector<int32_t> &fchild, co
     }
 }
 
+extern "C" int mpt_sah_workspace(int n, int64_t nseg, int64_t out[4]) {
+    if (n < 1 || nseg < 0 || !out) return 1;
+    int nb = 0;
+    out[0] = (int64_t)mpt_sah_seg_capacity(n);
+    out[1] = (int64_t)mpt_sah_seg_words(n);
+    out[2] = (int64_t)mpt_sah_level_words((size_t)nseg, &nb);
+    out[3] = nb;
+    return 0;
+}
+
 // workspace of mpt_sah_build: one device allocation carved into the arrays of MptSahBuffers
 static int build_sah_device(mpt_ctx *c) {
     const int n = c->nfaces, ni = n - 1;
@@ -425,7 +435,7 @@ static int build_sah_device(mpt_ctx *c) {
     for (int k = 0; k < 2; k++) { B.idx[k] = (int *)take((size_t)n * 4); B.seg[k] = (int *)take((size_t)n * 4); }
     B.pred = (int *)take((size_t)n * 4); B.pscan = (int *)take((size_t)n * 4);
     for (int k = 0; k < 2; k++) { B.sb[k] = (int *)take(SC * 4); B.se[k] = (int *)take(SC * 4); B.snode[k] = (int *)take(SC * 4); }
-    B.segw = (int *)take(SEGW * 4);
+    B.segw = (int *)take(SEGW * 4); B.seg_words = SEGW;
     B.dec = (int *)take(SC * 16); B.flag = (int *)take(2 * SC * 4); B.foff = (int *)take(2 * SC * 4);
     B.small = (int *)take(((size_t)n / 2 + 1) * 16);
     B.counters = (int *)take(16);
@@ -434,9 +444,39 @@ static int build_sah_device(mpt_ctx *c) {
     B.fnode = c->fnode;
     int depth = 0;
     hipError_t e = mpt_sah_build(&B, &depth, c->stream);
-    if (e != hipSuccess) return fail("device SAH build failed: %s", hipGetErrorString(e));
-    if (depth + 2 > 64) return fail("BVH depth %d exceeds the 64-entry traversal stack", depth);
+    // Neither is fatal: the caller falls back to the host pass, which re-packs c->fnode from the LBVH leaf order (a failed
+    // device pass may have overwritten part of it) and has its own depth handling (round-3 ADVICE)
+    if (c->sah_inject_fail) e = hipErrorInvalidValue;       // test door: the device pass ran (and wrote c->fnode), then "failed"
+    if (e != hipSuccess) { (void)hipGetLastError(); c->sah_fallback = 1; return 2; }
+    if (depth + 2 > 64) { c->sah_fallback = 2; return 2; }
     c->fast_depth = depth;
+    return 0;
+}
+
+// SAH re-partition of the leaves for the fast build: host pass over the leaf order (exact sweep up to sah_exact_max leaves)
+static int build_sah_host(mpt_ctx *c) {
+    const int n = c->nfaces, ni = n - 1;
+    c->h_leaf.resize(n);
+    HIP_TRY(hipMemcpy(c->h_leaf.data(), c->d_leaf, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    SahBuild sb;
+    sb.n = n;
+    sb.exact_max = c->sah_exact_max;
+    sb.lo.resize((size_t)n * 3); sb.hi.resize((size_t)n * 3); sb.ctr.resize((size_t)n * 3);
+    const float *V = c->verts.data();
+    for (int slot = 0; slot < n; slot++) {
+        int f = c->h_leaf[slot];
+        const float *p0 = V + ((size_t)f * 3) * 8, *p1 = p0 + 8, *p2 = p0 + 16;
+        for (int a = 0; a < 3; a++) {
+            float l = fminf(fminf(p0[a], p1[a]), p2[a]), h = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
+            sb.lo[(size_t)slot * 3 + a] = l; sb.hi[(size_t)slot * 3 + a] = h; sb.ctr[(size_t)slot * 3 + a] = 0.5f * (l + h);
+        }
+    }
+    sb.run();
+    if (sb.depth + 2 > 64) return fail("BVH depth %d exceeds the 64-entry traversal stack", sb.depth);
+    std::vector<MptVec4> fnode;
+    pack_fnode(c, n, sb.child, sb.blo, sb.bhi, fnode);
+    HIP_TRY(hipMemcpy(c->fnode, fnode.data(), (size_t)ni * 4 * sizeof(MptVec4), hipMemcpyHostToDevice));
+    c->fast_depth = sb.depth;
     return 0;
 }
 
@@ -498,32 +538,13 @@ static int build_tree_gpu(mpt_ctx *c) {
     c->fast_depth = depth;
     c->host_tree_valid = false;
     const bool sah_on_device = c->sah_build == 1 || (c->sah_build < 0 && n > 32768);
-    if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max && sah_on_device && n > 64) {
-        // SAH re-partition of the leaves on the device (sah_build.hip): nothing comes back but the depth
-        if (build_sah_device(c)) return 1;
-    } else if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max) {
-        // SAH re-partition of the leaves for the fast build (host pass over the leaf order)
-        c->h_leaf.resize(n);
-        HIP_TRY(hipMemcpy(c->h_leaf.data(), c->d_leaf, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-        SahBuild sb;
-        sb.n = n;
-        sb.exact_max = c->sah_exact_max;
-        sb.lo.resize((size_t)n * 3); sb.hi.resize((size_t)n * 3); sb.ctr.resize((size_t)n * 3);
-        const float *V = c->verts.data();
-        for (int slot = 0; slot < n; slot++) {
-            int f = c->h_leaf[slot];
-            const float *p0 = V + ((size_t)f * 3) * 8, *p1 = p0 + 8, *p2 = p0 + 16;
-            for (int a = 0; a < 3; a++) {
-                float l = fminf(fminf(p0[a], p1[a]), p2[a]), h = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
-                sb.lo[(size_t)slot * 3 + a] = l; sb.hi[(size_t)slot * 3 + a] = h; sb.ctr[(size_t)slot * 3 + a] = 0.5f * (l + h);
-            }
-        }
-        sb.run();
-        if (sb.depth + 2 > 64) return fail("BVH depth %d exceeds the 64-entry traversal stack", sb.depth);
-        std::vector<MptVec4> fnode;
-        pack_fnode(c, n, sb.child, sb.blo, sb.bhi, fnode);
-        HIP_TRY(hipMemcpy(c->fnode, fnode.data(), (size_t)ni * 4 * sizeof(MptVec4), hipMemcpyHostToDevice));
-        c->fast_depth = sb.depth;
+    c->sah_fallback = 0;
+    if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max) {
+        // SAH re-partition of the leaves: on the device (sah_build.hip: nothing comes back but the depth), or the host pass --
+        // also when the device pass gives up (workspace, level or depth limits): both start from the LBVH's leaf order
+        int r = (sah_on_device && n > 64) ? build_sah_device(c) : 2;
+        if (r == 1) return 1;
+        if (r == 2 && build_sah_host(c)) return 1;
     }
     c->tree_valid = true;
     return 0;

@@ -42,10 +42,23 @@ __device__ __forceinline__ float wb_area(const WbChild &c) {
     return dx * dy + dy * dz + dz * dx;
 }
 
+// surface areas are summed as integers in units of 2^-40 of the root's (the sum of <= 2^22 of them stays below 2^63): the
+// figure is the same bits run to run, whatever order the lanes arrive in (round-3 ADVICE: it was a double atomicAdd per lane)
+__device__ __forceinline__ unsigned long long wb_area_fixed(const MptVec4 *__restrict__ fnode, float a) {
+    WbChild ch[2];
+    wb_children_of(fnode, 0, ch);
+    WbChild root = ch[0];
+    for (int k = 0; k < 3; k++) { root.lo[k] = fminf(ch[0].lo[k], ch[1].lo[k]); root.hi[k] = fmaxf(ch[0].hi[k], ch[1].hi[k]); }
+    const double ra = (double)wb_area(root);
+    if (!(ra > 0.0)) return 0ull;
+    const double r = fmin(fmax((double)a / ra, 0.0), 1.0);
+    return (unsigned long long)(r * 1099511627776.0);
+}
+
 // expand: wide nodes [lo, lo + count) of one level.  ncount[t] = internal children of wide node lo + t (0 beyond the level)
 __global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__restrict__ fnode, const int *__restrict__ bin_of, int lo,
                                                             int count, int empty_id, MptVec4 *__restrict__ wnode, MptVec4 *__restrict__ qnode,
-                                                            int *__restrict__ ncount, double *__restrict__ area_sum) {
+                                                            int *__restrict__ ncount, unsigned long long *__restrict__ area_sum) {
     const int t = blockIdx.x * WB_BLOCK + threadIdx.x;
     if (t >= count) return;
     const int w = lo + t;
@@ -56,7 +69,11 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__re
         // the expected fetches per ray (informational: option "wide_ratio_permille")
         WbChild own = ch[0];
         for (int a = 0; a < 3; a++) { own.lo[a] = fminf(ch[0].lo[a], ch[1].lo[a]); own.hi[a] = fmaxf(ch[0].hi[a], ch[1].hi[a]); }
-        atomicAdd(area_sum, (double)wb_area(own));
+        const unsigned long long q = wb_area_fixed(fnode, wb_area(own));
+        unsigned long long tot = q;                           // one atomic per wave, and integers: the sum does not depend on the order
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        const unsigned long long act = __ballot(true);
+        if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) atomicAdd(area_sum, tot);
     }
     while (cnt < 4) {
         int best = -1; float ba = -1.f;
@@ -138,18 +155,18 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_link_kernel(int lo, int count, in
 }
 
 // sum of the surface areas of all binary nodes (the binary tree's expected fetches per ray, same informational figure)
-__global__ __launch_bounds__(WB_BLOCK) void wb_area_kernel(const MptVec4 *__restrict__ fnode, int ni, double *__restrict__ area_sum) {
+__global__ __launch_bounds__(WB_BLOCK) void wb_area_kernel(const MptVec4 *__restrict__ fnode, int ni, unsigned long long *__restrict__ area_sum) {
     const int b = blockIdx.x * WB_BLOCK + threadIdx.x;
-    double a = 0.0;
+    unsigned long long a = 0ull;
     if (b < ni) {
         WbChild ch[2];
         wb_children_of(fnode, b, ch);
         WbChild own = ch[0];
         for (int k = 0; k < 3; k++) { own.lo[k] = fminf(ch[0].lo[k], ch[1].lo[k]); own.hi[k] = fmaxf(ch[0].hi[k], ch[1].hi[k]); }
-        a = (double)wb_area(own);
+        a = wb_area_fixed(fnode, wb_area(own));
     }
     for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-    if ((threadIdx.x & 63) == 0 && a != 0.0) atomicAdd(area_sum, a);
+    if ((threadIdx.x & 63) == 0 && a != 0ull) atomicAdd(area_sum, a);
 }
 
 MPT_KERNEL_API hipError_t mpt_wide_scan_bytes(int ni, size_t *bytes) {
@@ -169,13 +186,14 @@ MPT_KERNEL_API hipError_t mpt_wide_build(const MptVec4 *fnode, int n, MptVec4 *w
     hipError_t e;
     if ((e = hipMemsetAsync(d_area, 0, 2 * sizeof(double), stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(bin_of, 0, sizeof(int), stream)) != hipSuccess) return e;        // wide node 0 grows from the root
-    hipLaunchKernelGGL(wb_area_kernel, dim3((ni + WB_BLOCK - 1) / WB_BLOCK), dim3(WB_BLOCK), 0, stream, fnode, ni, d_area + 1);
+    unsigned long long *d_fixed = (unsigned long long *)d_area;          // (two 8-byte words either way)
+    hipLaunchKernelGGL(wb_area_kernel, dim3((ni + WB_BLOCK - 1) / WB_BLOCK), dim3(WB_BLOCK), 0, stream, fnode, ni, d_fixed + 1);
     int lo = 0, count = 1, levels = 0;
     while (count > 0) {
         levels++;
         const int grid = (count + WB_BLOCK - 1) / WB_BLOCK;
         hipLaunchKernelGGL(wb_expand_kernel, dim3(grid), dim3(WB_BLOCK), 0, stream, fnode, bin_of, lo, count, ~n, wnode, qnode, ncount,
-                           d_area);
+                           d_fixed);
         if ((e = rocprim::exclusive_scan(scan_tmp, scan_bytes, ncount, offset, 0, (size_t)count, rocprim::plus<int>(), stream)) != hipSuccess) return e;
         int last[2] = { 0, 0 };
         if ((e = hipMemcpyAsync(&last[0], offset + (count - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -187,8 +205,10 @@ MPT_KERNEL_API hipError_t mpt_wide_build(const MptVec4 *fnode, int n, MptVec4 *w
             hipLaunchKernelGGL(wb_link_kernel, dim3(grid), dim3(WB_BLOCK), 0, stream, lo, count, lo + count, offset, wnode, qnode, bin_of);
         lo += count; count = made;
     }
-    if ((e = hipMemcpyAsync(area, d_area, 2 * sizeof(double), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    unsigned long long fixed[2] = { 0ull, 0ull };
+    if ((e = hipMemcpyAsync(fixed, d_fixed, sizeof fixed, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    area[0] = (double)fixed[0]; area[1] = (double)fixed[1];              // in units of 2^-40 of the root's area: only their ratio is used
     *nwide = lo; *depth = levels;
     return hipGetLastError();
 }

@@ -1461,6 +1461,45 @@ def test_state_change_between_partial_batches_is_ordered(fresh):
 C5_SEED_REF_CAN_BUILD = 12346
 
 
+def test_device_sah_pass_above_a_million_faces_and_its_host_fallback(fresh):
+    '''round-3 ADVICE: (high) 2.6 M random triangles -- a level of the device SAH pass there has up to ~79 000 segments at 32
+    bins, three times what the round-3 workspace held -- build on the device without falling back: every triangle in exactly
+    one slot of the collapse, every wide node but the root with one parent, every pixel counted, and the film within the FAST
+    bounds of the film through the host pass's tree; (medium) a device pass that fails AFTER it wrote the node records (test
+    door sah_inject_fail) is not an error any more: the host pass re-packs the records and the film is the host tree's bit for bit'''
+    from helpers import assert_parity
+    from ptina_amd.things import FilmTable, BVHTree
+    from ptina_amd.common import ctx, reset_all
+    n = 2_600_000
+    scene = scenes.scene_random_tris(n, seed=7)
+    nx, ny, spp = 96, 96, 2
+    films = {}
+    for key, opts in (('dev', {'sah_build': 1}), ('host', {'sah_build': 0}), ('fallback', {'sah_build': 1, 'sah_inject_fail': 1})):
+        reset_all()
+        eng = _engine(None, scene, nx, ny, mode='fast', max_faces=n + 1)
+        c = ctx()
+        for k, v in opts.items():
+            c.set_option(k, v)
+        BVHTree().build()
+        assert c.get_option('sah_fallback') == (1 if key == 'fallback' else 0), key
+        if key == 'dev':
+            w, q = _wide_records(c, n)
+            ids = w[:, 6, :].view(np.int32)
+            nw = c.get_option('wide_nodes')
+            assert nw > 0 and 2 < c.get_option('fast_depth') <= 62
+            assert np.array_equal(np.sort(ids[ids > 0]), np.arange(1, nw))
+            assert np.array_equal(np.sort(~ids[(ids < 0) & (ids != ~n)]), np.arange(n))
+            del w, q, ids
+        eng.render(spp)
+        raw = FilmTable().get_raw().reshape(nx, ny, 4)
+        assert np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
+        films[key] = FilmTable().get_image().copy()
+    reset_all()
+    assert np.array_equal(films['fallback'], films['host'])
+    # (nearly coincident triangles of a soup: equal-depth ties flip pixels, as on C5; calibrated from the first run)
+    assert_parity(films['dev'], films['host'], FAST[0], 0.02, 5e-3, what='2.6 M triangles: device SAH tree vs host SAH tree')
+
+
 def test_config5_reference_build_fails_on_the_stated_scene(fresh, oracle_mod):
     '''BASELINE configs[4] as generated (seed 12345): three of the 1 M centroids share a 30-bit Morton
     code, and the reference's own hierarchy (tree/lbvh.py:93-146, no index tie-break) is corrupted by
