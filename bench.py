@@ -54,8 +54,11 @@ SPP = 32
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_SIMD = 256 * 4             # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 SIMD_LANES = 32              # a wave64 VALU instruction issues over 2 cycles on a SIMD-32
-PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r03_pmc_summary.json')
-C3_N = 2048                  # BASELINE.json configs[2]: 2048 x 2048 film (32 spp per step here, 256 stated: 8 steps)
+PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r04_pmc_summary.json')
+if not os.path.exists(PROFILE_FALLBACK):
+    PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r03_pmc_summary.json')
+C3_N = 2048                  # BASELINE.json configs[2]: 2048 x 2048 film ...
+C3_SPP = 256                 # ... at 256 spp: one c3 step = render(256) (eight launches of 32 frames, pipelined) + gather + get_image()
 # the launch model of DESIGN.md section 6, measured on ONE MI355X (tools/gpu_diag.py shares_sync): a launch of 1/N of
 # a film costs a / N + b -- b = the end-of-launch drain, independent of N
 MODEL = {'headline': {'a_ms': 2.55, 'b_ms': 0.5}, 'c3': {'a_ms': 41.0, 'b_ms': 0.5},
@@ -67,6 +70,22 @@ PMC_PASSES = [
     ['FETCH_SIZE', 'GRBM_GUI_ACTIVE'],
     ['WRITE_SIZE', 'TCC_HIT_sum', 'TCC_MISS_sum'],
 ]
+
+
+def is_counting_kernel(name):
+    '''the counting instantiation of a render kernel (COUNT = true), by its template arguments:
+    render_kernel_lds<COUNT>, render_kernel_pool<COUNT>, render_kernel_wide<COUNT, QUANT>, render_kernel_fast<STACK, COUNT>.
+    (Round 3 tested for ", true>" and with it threw away the production gather kernel render_kernel_wide<false, true>.)'''
+    import re
+    m = re.search(r'render_kernel_(\w+?)<([^>]*)>', name)
+    if not m:
+        return False
+    kind, args = m.group(1), [a.strip() for a in m.group(2).split(',')]
+    if kind.startswith('wide'):
+        return args[0] == 'true'
+    if kind.startswith('fast') or kind.startswith('strict'):
+        return args[-1] == 'true'
+    return args[0] == 'true'                      # lds, pool
 
 
 def render_kernel_name(mode, last_kernel):
@@ -115,7 +134,7 @@ def collect_pmc(argv_tail, budget_s=150):
             per = {}
             for r in rows:
                 k = r['Kernel_Name']
-                if 'render_kernel' not in k or '<true>' in k or ', true>' in k:   # not the counting build
+                if 'render_kernel' not in k or is_counting_kernel(k):              # not the counting build
                     continue
                 per.setdefault((k, r['Counter_Name']), {}).setdefault(r['Dispatch_Id'], 0.0)
                 per[(k, r['Counter_Name'])][r['Dispatch_Id']] += float(r['Counter_Value'])
@@ -133,7 +152,7 @@ def committed_pmc(kernel):
     try:
         d = json.load(open(PROFILE_FALLBACK))
         for k, v in d.items():
-            if kernel in k and '<true>' not in k and ', true>' not in k:
+            if kernel in k and not is_counting_kernel(k):
                 return {cn: dict(x, kernel=k) for cn, x in v.items()}, 'profiles/' + os.path.basename(PROFILE_FALLBACK)
     except Exception:
         pass
@@ -249,7 +268,8 @@ def cpu_baseline(scene, camera, budget_s=15.0):
     t1 = time.time()
     o1.render(4)
     one = 8 * NY * 4 / (time.time() - t1) / 1e6
-    return {'value': round(samples / dt / 1e6, 4), 'unit': 'Msamples/s', 'cores': threads, 'kind': 'port',
+    return {'value': round(samples / dt / 1e6, 4), 'unit': 'Msamples/s', 'cores': threads, 'host_cores': os.cpu_count(),
+            'kind': 'port',
             'value_1thread': round(one, 4),
             'sample': f'columns [{x0},{x0 + cols}) of the 512x512 film x {frames} spp = {samples} samples '
                       f'in {dt:.1f} s (C restatement of PTina\'s algorithm, OpenMP, {threads} threads)'}
@@ -266,7 +286,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='do not run the rocprofv3 --pmc passes (counters from profiles/)')
     ap.add_argument('--force-comm', action='store_true', help='create the RCCL communicator even for one rank')
-    ap.add_argument('--c3-steps', type=int, default=3, help='N > 1: timed steps of the 2048x2048x32 leg (0 = skip it)')
+    ap.add_argument('--c3-steps', type=int, default=2, help='N > 1: timed steps of the 2048x2048 leg, each --c3-spp samples per pixel (0 = skip it)')
+    ap.add_argument('--c3-spp', type=int, default=C3_SPP, help='samples per pixel of one c3 step (BASELINE configs[2]: 256)')
+    ap.add_argument('--stub-hang', default='', help='tests only (--stub): "RANK:PHASE" -- that rank stops responding in that phase')
     ap.add_argument('--stub', action='store_true',
                     help='tests only: a stand-in renderer that touches no GPU (checks the launcher and the line format)')
     ap.add_argument('--role', default='main', choices=['main', 'pmc-child'],
@@ -279,9 +301,20 @@ class _Stub:
     and no RCCL, so that the rank launcher and the shape of the result line can be checked on a CPU box
     (tests/test_dist_cpu.py).  A "render" sleeps a / N + b of the launch model; nothing is computed.'''
 
-    def __init__(self, rank, world):
+    def __init__(self, rank, world, phases=None, hang=''):
         self.rank, self.world, self.nx, self.lib = rank, world, NX, self
         self.opts = {'nranks': world, 'last_div': 1, 'last_kernel': 1, 'clock_khz': 2400000, 'hw_queues': 0}
+        self.phases, self.hang, self._gathers = phases, hang, 0
+        for ph in ('unique_id', 'CommInitRank', 'first barrier', 'communicator ready'):
+            self._phase(ph)
+
+    def _phase(self, name):
+        if self.phases is not None and self.world > 1:
+            self.phases.enter(name)
+            if self.hang == f'{self.rank}:{name}':
+                time.sleep(3600)                  # a rank that never comes back from a collective
+            if self.hang == f'{self.rank}:{name}:raise':
+                raise RuntimeError('ncclCommInitRank failed: unhandled system error (stand-in)')
 
     # context
     def mpt_device_count(self): return self.world
@@ -309,16 +342,39 @@ class _Stub:
 
     # communicator
     def set_stripes(self, nx): pass
-    def gather(self, id=0, root=0): pass
+    def gather(self, id=0, root=0):
+        if self._gathers == 0:
+            self._phase('first gather')
+            self._phase('first gather done')
+        self._gathers += 1
+
     def barrier(self): pass
     def allreduce_max(self, v): return v
     def close(self): pass
 
 
 def run_rank(args, rank, world, pmc, pmc_source):
+    '''one rank of the benchmark.  Every phase of the multi-rank protocol is named in the PhaseLog: a rank that stays in one
+    for MIPTINA_PHASE_TIMEOUT seconds, or an RCCL call that fails, ends the run with a non-zero exit code and one line saying
+    which phase every rank had reached (VERDICT r03 next #4)'''
+    from ptina_amd.dist import PhaseLog
+    phases = PhaseLog(rank, world)
+    try:
+        _run_rank(args, rank, world, pmc, pmc_source, phases)
+    except SystemExit:
+        raise
+    except BaseException as e:
+        phases.report(f"failed in phase '{phases.name}': {type(e).__name__}: {e}")
+        phases.done = True
+        raise
+    phases.finish()
+
+
+def _run_rank(args, rank, world, pmc, pmc_source, phases):
     import numpy as np  # noqa: F401
+    phases.enter('setup (scene, tree, film)')
     if args.stub:
-        eng = c = film = _Stub(rank, world)
+        eng = c = film = _Stub(rank, world, phases, args.stub_hang)
         comm = c if (world > 1 or args.force_comm) else None
         scene = None
     else:
@@ -334,7 +390,7 @@ def run_rank(args, rank, world, pmc, pmc_source):
         c = ctx()
         if c.lib.mpt_device_count() < world and not _lib.devices_isolated():
             raise SystemExit(f'--gpus {world} but only {c.lib.mpt_device_count()} GPU(s) visible')
-        comm = RcclFilm(rank, world) if (world > 1 or args.force_comm) else None
+        comm = RcclFilm(rank, world, phases) if (world > 1 or args.force_comm) else None
         film = FilmTable()
     if args.chunk >= 0:
         c.set_option('chunk', args.chunk)
@@ -359,12 +415,15 @@ def run_rank(args, rank, world, pmc, pmc_source):
             c.call('mpt_synchronize')
         return None
 
-    def barrier():
+    def barrier(name=None):
+        if name:
+            phases.enter('barrier: ' + name)
         c.call('mpt_synchronize')
         if comm:
             comm.barrier()
 
     # exams/benchmark.py:25-27: warm-up frame, read back, clear
+    phases.enter('warm-up frame')
     eng.render()
     film.get_image()
     film.clear()
@@ -379,9 +438,10 @@ def run_rank(args, rank, world, pmc, pmc_source):
     c.set_option('count', 1)
     c.call('mpt_reset_counters')
     W = max(args.warmup, 1)
+    phases.enter('warm-up steps (counting kernel)')
     for _ in range(W):
         step(True)
-    barrier()
+    barrier('after warm-up')
     cnt = c.counters()
     c.set_option('count', 0)
     c.kernel_time()
@@ -390,11 +450,12 @@ def run_rank(args, rank, world, pmc, pmc_source):
     c.kernel_time()
 
     # ---- timed region: K steps, each ending with the image in host memory (max over ranks)
-    barrier()
+    barrier('before the timed steps')
+    phases.enter('timed steps')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img = step(True)
-    barrier()
+    barrier('after the timed steps')
     dt = time.perf_counter() - t0
     kms, nlaunch = c.kernel_time()
     if comm:
@@ -402,41 +463,59 @@ def run_rank(args, rank, world, pmc, pmc_source):
 
     # ---- the same K steps stopping at the resolved image in HBM (consecutive launches overlap)
     barrier()
+    phases.enter('resolve-only steps')
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step(False)
-    barrier()
+    barrier('after the resolve-only steps')
     dt_resolve = time.perf_counter() - t1
     c.kernel_time()
     if comm:
         dt_resolve = comm.allreduce_max(dt_resolve)
 
-    # ---- N > 1: BASELINE configs[2]'s film (2048 x 2048, 32 spp per step), striped and gathered the same way
+    # ---- N > 1: BASELINE configs[2] as stated: 2048 x 2048 film, 256 spp per step, striped and gathered the same way
     c3 = None
     if comm and world > 1 and args.c3_steps > 0:
+        phases.enter('c3: set-up')
+        c3_spp = max(args.c3_spp, 1)
+
+        def step3(spp):
+            eng.render(spp)                   # launches of 32 frames each, pipelined; the film sums in HBM
+            c.call('mpt_flush')
+            comm.gather(0, 0)
+            if rank == 0:
+                return film.get_image()
+            c.call('mpt_synchronize')
+            return None
+
         film.set_size(C3_N, C3_N)             # (back to one slab: the stripes are dealt again for this width)
         comm.set_stripes(C3_N)
         film.clear()
-        step(True)                            # untimed: sample slabs, gather buffers and the host array are allocated here
-        barrier()
+        step3(SPP)                            # untimed: sample slabs, gather buffers and the host array are allocated here
+        barrier('c3 warm-up')
         c.kernel_time()
+        phases.enter('c3: timed steps')
         t3 = time.perf_counter()
         for _ in range(args.c3_steps):
-            img3 = step(True)
-        barrier()
+            film.clear()
+            img3 = step3(c3_spp)
+        barrier('after the c3 steps')
         dt3 = comm.allreduce_max(time.perf_counter() - t3)
         kms3, nl3 = c.kernel_time()
         if rank == 0:
             assert img3 is not None and img3.shape == (C3_N, C3_N, 4) and float(img3[..., 3].min()) == 1.0
             m = MODEL['c3']
-            c3 = {'msamples_s': round(C3_N * C3_N * SPP * args.c3_steps / dt3 / 1e6, 3),
-                  'ms_per_step': round(dt3 / args.c3_steps * 1e3, 4), 'n_gpus': n_gpus, 'steps': args.c3_steps,
-                  'workload': f'{args.scene} {C3_N}x{C3_N}, {SPP} spp per step (BASELINE configs[2] states 256 spp = 8 such steps), '
-                              'stripes of 16 columns per rank, one-message gather, resolve + D2H of the 64 MiB image',
-                  'render_kernel_ms_rank0': round(kms3 / max(nl3, 1), 4),
-                  'model_ms_per_step': round(m['a_ms'] / n_gpus + m['b_ms'], 3),
-                  'model': f"a / N + b with a = {m['a_ms']} ms, b = {m['b_ms']} ms per launch ({MODEL['from']}); "
-                           'the gather and the 64 MiB read-back are not in the model'}
+            launches = (c3_spp + SPP - 1) // SPP
+            c3 = {'msamples_s': round(C3_N * C3_N * c3_spp * args.c3_steps / dt3 / 1e6, 3),
+                  'ms_per_step': round(dt3 / args.c3_steps * 1e3, 4), 'n_gpus': n_gpus, 'steps': args.c3_steps, 'spp': c3_spp,
+                  'workload': f'BASELINE configs[2]: {args.scene} {C3_N}x{C3_N}, {c3_spp} spp per step (= {launches} pipelined launches of '
+                              f'{SPP} frames), stripes of 16 columns per rank, film cleared, rendered, gathered in one message per rank, '
+                              'resolved and the 64 MiB image read back, every step',
+                  'render_kernel_ms_rank0': round(kms3 / max(nl3, 1), 4), 'render_launches_rank0': nl3,
+                  'model_ms_per_step': round(launches * m['a_ms'] / n_gpus + m['b_ms'], 3),
+                  'model': f"launches x a / N + b with a = {m['a_ms']} ms per 32-frame launch of the whole film, b = {m['b_ms']} ms "
+                           f"(the drain of the last launch; the others overlap theirs) ({MODEL['from']}); "
+                           'the clear, the gather and the 64 MiB read-back are not in the model'}
 
     if rank == 0:
         assert img is not None and img.shape == (NX, NY, 4) and float(img[..., 3].min()) == 1.0
@@ -446,11 +525,19 @@ def run_rank(args, rank, world, pmc, pmc_source):
         concurrent = max(c.get_option('last_div'), 1)
         kernel = render_kernel_name(args.mode, c.get_option('last_kernel'))
         clock_hz = c.get_option('clock_khz') * 1e3 or 2.4e9
-        if pmc is None and world == 1:
+        if pmc is None:
             pmc, pmc_source = committed_pmc(kernel)
+            if pmc is not None and world > 1:
+                # N > 1: counters are not collected in the run (one profiler per rank, and the driver's launcher owns the ranks):
+                # the committed per-launch counters of the whole-film launch, times this rank's share of the film -- instruction
+                # counts and bytes scale with the samples a launch traces, the lane occupancy ratio is kept.  The kernel TIME is
+                # this run's (rank 0, HIP events).  Labelled as such in counters_from
+                share = samples_share = 1.0 / n_gpus
+                pmc = {cn: dict(x, median=x['median'] * samples_share) for cn, x in pmc.items()}
+                pmc_source = (f'{pmc_source}: per-launch counters of the N = 1 launch x {share:.4f} (rank 0\'s share of the film); '
+                              'kernel time measured in this run on rank 0; NOT collected in this run')
         try:
-            roof, hbm = roofline_blocks(pmc if world == 1 else None, pmc_source if world == 1 else 'N > 1: not collected',
-                                        kernel, avg_kernel_s, clock_hz, concurrent)
+            roof, hbm = roofline_blocks(pmc, pmc_source, kernel, avg_kernel_s, clock_hz, concurrent)
         except Exception as e:                # an incomplete counter set must not cost the run its result line
             roof, hbm = roofline_blocks(None, f'counters unusable ({type(e).__name__}: {e})', kernel, avg_kernel_s,
                                         clock_hz, concurrent)

@@ -289,6 +289,9 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         if (value < -1 || value > 1) return fail("skip_dark must be -1 (auto), 0 or 1");
         c->skip_dark = value;
     } else if (k == "pool") {
+#if !MPT_WITH_POOL
+        if (value) return fail("this library is built without the pooled LDS kernel (an A/B build: make -C ptina_amd/csrc pool)");
+#endif
         c->use_pool = value ? 1 : 0;
     } else if (k == "pool_shaders") {
         if (value < 1 || value > 8) return fail("pool_shaders must be in 1..8");
@@ -732,6 +735,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     size_t pool_bytes = 0;
     int pool_stride = 0;
     const int pool_nmats = c->max_mtlid + 1;
+#if MPT_WITH_POOL
     if (lds_kernel && c->use_pool && c->sdim <= 32768 && c->lds_block == 0) {
         for (int stride : { MPT_LDS_NODE_STRIDE, 64 }) {
             const size_t b = ((((size_t)(c->nfaces - 1) * stride + 15) >> 4) + (size_t)c->nfaces * 3 + (size_t)(pool_nmats + 1) * 6) * sizeof(MptVec4) +
@@ -740,6 +744,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
             if (b <= 160 * 1024) { pool_bytes = b; pool_stride = stride; break; }
         }
     }
+#endif
     const bool pool_kernel = pool_bytes != 0;
     p.lds_node_stride = pool_stride; p.lds_nmats = pool_nmats; p.pool_shaders = c->pool_shaders;
     int chunk = B, nchunks = 1;
@@ -863,7 +868,8 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         if (waves != c->timeline_waves) {
             HIP_TRY(hipDeviceSynchronize());
             hipFree(c->d_timeline); c->d_timeline = nullptr;
-            if (dev_alloc(&c->d_timeline, (size_t)waves * 4)) return 1;
+            if (dev_alloc(&c->d_timeline, (size_t)waves * MPT_TIMELINE_WORDS)) return 1;
+            HIP_TRY(hipMemset(c->d_timeline, 0, (size_t)waves * MPT_TIMELINE_WORDS * sizeof(unsigned long long)));
             c->timeline_waves = waves;
         }
         p.timeline = c->d_timeline;
@@ -871,7 +877,9 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(hipEventRecord(e0, rs));
     if (!fast) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, rs));
+#if MPT_WITH_POOL
     else if (pool_kernel) HIP_TRY(mpt_launch_render_pool(&p, launch_cus, 1024, pool_bytes, c->count, rs));
+#endif
     else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, launch_cus, lds_block_used, lds_bytes, c->count, rs));
     else if (wide_kernel) HIP_TRY(mpt_launch_render_wide(&p, wide_blocks, c->count, c->use_quant, rs));
     else HIP_TRY(mpt_launch_render_fast(&p, launch_cus, stack, c->count, rs));
@@ -1042,7 +1050,7 @@ extern "C" int mpt_get_timeline(mpt_ctx *c, unsigned long long *out, int cap_wav
     if (!c->d_timeline) return fail("no timeline recorded: set option 'timeline' and render with the LDS kernel");
     int n = std::min(cap_waves, c->timeline_waves);
     if (out && n > 0)
-        HIP_TRY(hipMemcpy(out, c->d_timeline, (size_t)n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, c->d_timeline, (size_t)n * MPT_TIMELINE_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (nwaves) *nwaves = c->timeline_waves;
     return 0;
 }

@@ -68,6 +68,9 @@ MPT_KERNEL_API hipError_t mpt_lbvh_sort_bytes(int n, size_t *bytes);
 MPT_KERNEL_API hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t stream);
 
 // ------------------------------------------------------------------ errors (miptina.cpp)
+#ifndef MPT_WITH_POOL
+#define MPT_WITH_POOL 0          // 1: the pooled LDS kernel (render_pool.h) is compiled in (A/B build `make pool`)
+#endif
 #define MPT_INTERNAL __attribute__((visibility("hidden")))   // shared between the .cpp files, not exported
 MPT_INTERNAL int fail(const char *fmt, ...);
 

@@ -34,6 +34,7 @@
 #define MPT_BLOCK 256          // 4 waves of 64; one 16x16 pixel tile, an 8x8 sub-tile per wave
 #define MPT_TILE 16
 #define MPT_MAX_BATCH 64       // frames per launch
+#define MPT_TIMELINE_WORDS 8    // diagnostics: 64-bit words per wave of the launch timeline (option "timeline")
 #define MPT_MAX_LIGHTS 64
 #define MPT_MAX_DEVICES 64     // device ids a process may hold contexts on (per-device launch caches)
 

@@ -743,6 +743,10 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     PrimaryPool pool;                               // lane l: primary ray of sample pool_base + l of the current item
     pool.ro = v3s(0.0f); pool.rd = v3s(0.0f); pool.rng_i = 0; pool.rng_k = -1;
     int pool_base = -64;
+#if MPT_X_TIMELINE2      // diagnostic build: also the time of the last work item pulled, their number, the lanes in flight when the
+    int tl_items = 0, tl_passes = 0;     // queues were found empty and the shading passes made after that (timeline words 4..7)
+    unsigned long long tl_lastpull = 0;
+#endif
 #if MPT_X_STAMPS
     unsigned long long acc_node = 0, acc_leaf = 0, acc_sdone = 0, acc_shade = 0, acc_new = 0;
     const unsigned long long stamp_start = __builtin_amdgcn_s_memtime();
@@ -878,8 +882,17 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 int item = wq.pull();               // while the other lanes are still busy (no per-item tail)
                 if (item < 0) {
                     more = false;
-                    if (tl && (threadIdx.x & 63) == 0) tl[2] = wall_clock64();
+                    if (tl && (threadIdx.x & 63) == 0) {
+                        tl[2] = wall_clock64();
+#if MPT_X_TIMELINE2
+                        tl[4] = tl_lastpull; tl[5] = (unsigned long long)tl_items;
+                        tl[6] = (unsigned long long)(64 - (int)__builtin_popcountll(m_new));     // lanes with a path in flight
+#endif
+                    }
                 } else {
+#if MPT_X_TIMELINE2
+                    tl_items++; tl_lastpull = wall_clock64();
+#endif
                     int tile = item / p.nchunks, chunk = item - tile * p.nchunks;
                     int tx = tile / t8y, ty = tile - tx * t8y;
                     int tps_x = p.stripe_w >> tws, st = tx / tps_x;      // stripe of this tile column
@@ -938,6 +951,10 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             if (L.st == ST_BOUNCE || L.st == ST_SHADOW) lane_begin_ray<COUNT>(p, L, stk, cnt);
             MPT_STAMP_END(acc_sdone)
         }
+#endif
+#if MPT_X_TIMELINE2
+        if (!more) tl_passes++;
+        if (ndead == 64 && tl && (threadIdx.x & 63) == 0) tl[7] = (unsigned long long)tl_passes;
 #endif
         if (ndead == 64) break;
     }
@@ -1026,7 +1043,7 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
     // node records MPT_LDS_NODE_STRIDE bytes apart (bank spreading), the region rounded up to whole float4
     const int nnode4 = ((p.n - 1) * MPT_LDS_NODE_STRIDE + 15) >> 4, ntri4 = p.n * 3, nmat4 = (p.default_mtl + 1) * MPT_LDS_MAT_VEC4;
     const int nmtl4 = (p.n + 15) >> 4;
-    unsigned long long *tl = p.timeline ? p.timeline + 4 * (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
+    unsigned long long *tl = p.timeline ? p.timeline + MPT_TIMELINE_WORDS * (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
     if (tl && (threadIdx.x & 63) == 0) tl[0] = wall_clock64();
     {   // one copy of the scene per CU: coalesced 16-B loads, ds_write_b128
         for (int k = threadIdx.x; k < (p.n - 1) * 4; k += blockDim.x) {          // 8-byte stores: the records are 8-byte aligned
@@ -1162,7 +1179,9 @@ MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *p, int gr
 }
 #endif
 
-#if !MPT_STRICT
+#if !MPT_STRICT && MPT_WITH_POOL
+// The pooled LDS kernel (waves specialised into tracers and shaders, paths traded through LDS pools) measured 15-50 % slower
+// than render_kernel_lds: it is an A/B build (make pool -> libmiptina_pool.so), not part of the product library
 #include "render_pool.h"
 #endif
 

@@ -102,6 +102,78 @@ def exchange_unique_id(make_uid, rank, world, timeout=120.0):
         time.sleep(0.01)
 
 
+def phase_dir():
+    '''where the ranks of this job leave the name of the phase they are in (PhaseLog): the launcher's private directory,
+    or under torch.distributed.run a directory named after the agent (the workers' common parent) and its port'''
+    d = os.environ.get('MIPTINA_RDZV_DIR')
+    if d:
+        return d
+    if 'TORCHELASTIC_RUN_ID' in os.environ or 'TORCHELASTIC_RESTART_COUNT' in os.environ:
+        return '/tmp/miptina_phase_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+    return None
+
+
+def read_phases(d, world):
+    '''{rank: "phase (seconds in it)"} from the files the ranks keep in `d`; "?" for a rank that wrote none'''
+    out = {}
+    now = time.time()
+    for r in range(world):
+        try:
+            with open(os.path.join(d, 'phase_%d' % r)) as f:
+                name, t = f.read().rsplit(' ', 1)
+            out[r] = '%s (%.0f s)' % (name, now - float(t))
+        except (OSError, ValueError):
+            out[r] = '?'
+    return out
+
+
+class PhaseLog:
+    '''A multi-rank run must never hang silently: every rank names the phase it enters (unique_id, CommInitRank, first
+    gather, barrier, ...) in a small file, and a watchdog thread of its own ends the rank -- printing which phase EVERY rank
+    had reached -- when it stays in one phase longer than `timeout` seconds (MIPTINA_PHASE_TIMEOUT, default 300).  A collective
+    that one rank never joins blocks the others inside RCCL, where no Python exception can reach them: hence a thread and
+    os._exit, not an exception.  The launcher (launch_ranks, or torchrun's agent) then stops the remaining ranks.'''
+
+    def __init__(self, rank, world, timeout=None):
+        import threading
+        self.rank, self.world = rank, world
+        self.dir = phase_dir() if world > 1 else None
+        self.timeout = float(os.environ.get('MIPTINA_PHASE_TIMEOUT', '300')) if timeout is None else float(timeout)
+        self.name, self.t0, self.done = 'start', time.time(), False
+        if self.dir:
+            os.makedirs(self.dir, exist_ok=True)
+            self.enter('start')
+            th = threading.Thread(target=self._watch, daemon=True)
+            th.start()
+
+    def enter(self, name):
+        self.name, self.t0 = name, time.time()
+        if self.dir:
+            try:
+                tmp = os.path.join(self.dir, 'phase_%d.tmp' % self.rank)
+                with open(tmp, 'w') as f:
+                    f.write('%s %.3f' % (name, self.t0))
+                os.replace(tmp, os.path.join(self.dir, 'phase_%d' % self.rank))
+            except OSError:
+                pass
+
+    def report(self, why):
+        phases = read_phases(self.dir, self.world) if self.dir else {self.rank: self.name}
+        sys_err('rank %d: %s; phase reached by every rank: %s' % (
+            self.rank, why, ', '.join('rank %d: %s' % (r, phases[r]) for r in sorted(phases))))
+
+    def finish(self):
+        self.done = True
+        self.enter('done')
+
+    def _watch(self):
+        while not self.done:
+            time.sleep(0.25)
+            if not self.done and time.time() - self.t0 > self.timeout:
+                self.report("stuck in phase '%s' for more than %.0f s, giving up" % (self.name, self.timeout))
+                os._exit(3)
+
+
 def launch_ranks(world, argv, timeout=None, env=None):
     '''start `world` fresh processes of `argv` (one rank per GPU of this node), wait for them and
     return (exit code, rank 0's stdout).  The caller must not have touched the GPU: the children are
@@ -146,11 +218,11 @@ def launch_ranks(world, argv, timeout=None, env=None):
                 live.discard(r)
                 if code != 0:
                     rc = code if code > 0 else 128 - code
-                    sys_err(f'launch_ranks: rank {r} exited with {code}; stopping the other ranks')
+                    sys_err(f'launch_ranks: rank {r} exited with {code}; stopping the other ranks; phases: {read_phases(rdzv, world)}')
                     break
             if rc is None and timeout is not None and time.time() - t0 > timeout:
                 rc = 124
-                sys_err(f'launch_ranks: no result after {timeout}s; stopping every rank')
+                sys_err(f'launch_ranks: no result after {timeout}s; stopping every rank; phases: {read_phases(rdzv, world)}')
             if live and rc is None:
                 time.sleep(0.02)
         out0 = b''
@@ -185,7 +257,7 @@ def sys_err(msg):
 class RcclFilm:
     '''slab tiling over RCCL for the current ptina_amd context'''
 
-    def __init__(self, rank=None, world=None):
+    def __init__(self, rank=None, world=None, phases=None):
         import ctypes as C
         from . import _lib
         from .common import ctx
@@ -193,14 +265,20 @@ class RcclFilm:
         self.rank = r if rank is None else rank
         self.world = w if world is None else world
         self.ctx = ctx()
+        self.phases = phases
+        self._gathers = 0
 
         def make_uid():
             buf = C.create_string_buffer(128)
             _lib.check(self.ctx.lib.mpt_comm_unique_id(buf))
             return buf.raw
+        self._phase('unique_id')
         uid = exchange_unique_id(make_uid, self.rank, self.world)
+        self._phase('CommInitRank')
         self.ctx.call('mpt_comm_init', uid, self.world, self.rank)
+        self._phase('first barrier')
         self.barrier()
+        self._phase('communicator ready')
         if self.rank == 0 and self.world > 1:
             try:
                 os.remove(rendezvous_path())
@@ -216,9 +294,19 @@ class RcclFilm:
         self.ctx.call('mpt_set_stripes', int(width), self.rank, self.world)
         return stripe_columns(nx, self.world, self.rank, width)
 
+    def _phase(self, name):
+        if self.phases is not None:
+            self.phases.enter(name)
+
     def gather(self, id=0, root=0):
         if self.world > 1:
+            if self._gathers == 0:
+                self._phase('first gather')
             self.ctx.call('mpt_comm_gather_film', int(id), int(root))
+            if self._gathers == 0:
+                self.ctx.call('mpt_synchronize')          # (the first one only: so that "first gather" means the messages arrived)
+                self._phase('first gather done')
+            self._gathers += 1
 
     def barrier(self):
         self.ctx.call('mpt_comm_barrier')

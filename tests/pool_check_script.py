@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+'''Body of tests/test_parity_gpu.py::test_pooled_lds_kernel_gives_the_same_film_bit_for_bit, run as a program of its own because
+the pooled LDS kernel lives in an A/B build of the library (make -C ptina_amd/csrc pool -> libmiptina_pool.so, loaded through
+MIPTINA_LIB) and a process binds one library.  Prints POOL-OK.  usage: pool_check_script.py <repo root>'''
+import os
+import sys
+
+root = sys.argv[1]
+sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, 'tests'))
+import numpy as np  # noqa: E402
+from ptina_amd import scenes  # noqa: E402
+from helpers import setup_engine, FAST  # noqa: E402
+
+
+def _engine(fresh, *a, **kw):
+    return setup_engine(*a, **kw)
+
+
+def main():
+
+    from helpers import assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    lobes = list(scenes.scene_s34())
+    mats = list(lobes[2])
+    mats[3] = scenes.material(basecolor=(0.9, 0.95, 1.0), roughness=0.25, transmission=0.8, ior=1.5, specular=0.5)
+    mats[4] = scenes.material(basecolor=(0.7, 0.1, 0.1), roughness=0.5, clearcoat=1.0, clearcoatGloss=0.9, sheen=0.5, subsurface=0.3, metallic=0.2)
+    lobes[2] = mats
+    area = np.array([[1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 3.9], [0.0, -1.0, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    point = np.eye(4)
+    point[:3, 3] = (-1.2, 2.5, 1.0)
+    lights = [(area, np.array([12.0, 11.0, 9.0]), 0.7, 'AREA'), (point, np.array([20.0, 20.0, 24.0]), 0.3, 'POINT')]
+    for scene, lts, nx, ny, frames in ((scenes.scene_s978(), None, 52, 43, (8, 3)), (tuple(lobes), lts_ := lights, 70, 33, (5,)),
+                                        (scenes.scene_s978(), None, 256, 192, (16,))):
+        films = {}
+        for pool, shaders in ((0, 3), (1, 1), (1, 3), (1, 5)):
+            reset_all()
+            eng = _engine(None, scene, nx, ny, mode='fast', lights=lts)
+            c = ctx()
+            c.set_option('pool', pool)
+            c.set_option('pool_shaders', shaders)
+            c.set_option('batch', 16)
+            c.set_option('count', 1)
+            c.call('mpt_reset_counters')
+            for f in frames:
+                eng.render(f)
+            c.call('mpt_flush')
+            cnt = c.counters()
+            films[(pool, shaders)] = (FilmTable().get_raw().copy(), c.get_option('last_kernel'),
+                                      {k: cnt[k] for k in ('samples', 'rays', 'n_box', 'n_tri', 'n_shade', 'n_draws', 'bounces', 'n_node')}, cnt)
+        reset_all()
+        ref = films[(0, 3)]
+        assert ref[1] == 1 and np.all(ref[0].reshape(nx, ny, 4)[..., 3] == sum(frames))
+        for key, (film, kernel, work, cnt) in films.items():
+            if key[0]:
+                assert kernel == 3, key
+                # bit for bit (a NaN the reference's clearcoat / transmission arithmetic leaves in a pixel must be the same NaN)
+                diff = (film.view(np.uint32) != ref[0].view(np.uint32)).any(axis=1)
+                rel = np.abs(film[diff].astype(np.float64) - ref[0][diff]) / (np.abs(ref[0][diff]) + 1e-30)
+                worst = float(np.nanmax(rel)) if diff.any() else 0.0
+                print(f'pooled {key} {nx}x{ny}: {int(diff.sum())} of {len(diff)} pixels differ in some bit, max relative difference {worst:.2e}')
+                # Same source, but the bounce is compiled more than once (in the shader waves, in the tracer waves' fall-back,
+                # in the unpooled kernel) and -ffp-contract=fast may fuse a multiply-add in one copy and not in another: a
+                # few pixels differ in their last bits (measured: 5 of 2236 at 1.8e-7; 9 of 2310 at 2.4e-7 on the scene with
+                # every lobe).  Anything beyond rounding would be a path that went astray.
+                # On the scene with a glass material one of those last bits can flip a lobe choice (the reference's own f32 and
+                # f64 runs disagree on 5-11 % of such pixels): there the films are held to the FAST bounds.
+                # Since the unpooled kernel starts all the rays of a shading pass in one block, its copy of the bounce sits in other
+                # surroundings than the pooled kernel's copies and is fused differently in more places: 8 % of the pixels differ
+                # in last bits (1.7e-6; 9e-5 on the 256 x 192 film, where a path or two land on the other side of an edge).
+                assert diff.mean() <= 0.15, (key, int(diff.sum()))
+                if lts is None:
+                    assert worst <= 5e-4, (key, int(diff.sum()), worst)
+                else:
+                    spp_ = float(sum(frames))
+                    assert_parity(film.reshape(nx, ny, 4)[..., :3] / spp_, ref[0].reshape(nx, ny, 4)[..., :3] / spp_, *FAST, what=f'pooled {key} vs unpooled, lobes scene')
+                # (a ray whose direction differs in the last bit may visit a node more or less)
+                assert all(abs(work[k] - ref[2][k]) <= 1e-3 * ref[2][k] for k in work), (key, work, ref[2])
+                assert work['samples'] == ref[2]['samples']
+                assert cnt['pl_batch_lanes'] + cnt['pl_local'] == cnt['bounces'] and cnt['pl_taken'] >= cnt['samples']   # every bounce ran once: in a shader batch or in its tracer
+
+
+if __name__ == '__main__':
+    main()
+    print('POOL-OK')

@@ -5,6 +5,7 @@ bit-identical to the single-rank render.
 '''
 
 import os
+import time
 import socket
 import sys
 
@@ -271,11 +272,38 @@ def test_bench_n_gpu_line_carries_the_config3_leg(tmp_path):
     assert line['metric'].startswith('STUB') and 'STUB' in line['data']          # never mistaken for a measurement
     c3 = line['c3']
     assert c3['n_gpus'] == 2 and c3['steps'] == 2 and '2048x2048' in c3['workload']
+    assert c3['spp'] == 256 and '256 spp' in c3['workload'] and 'BASELINE configs[2]' in c3['workload']   # the stated config
     assert c3['msamples_s'] > 0 and c3['ms_per_step'] > 0
-    assert abs(c3['model_ms_per_step'] - (41.0 / 2 + 0.5)) < 1e-6 and 'a / N + b' in c3['model']
+    assert abs(c3['model_ms_per_step'] - (8 * 41.0 / 2 + 0.5)) < 1e-6 and 'a / N + b' in c3['model']
     assert abs(line['model_ms_per_step'] - (2.55 / 2 + 0.5)) < 1e-6
+    # the N > 1 line is not "unmeasured": a roofline block from rank 0's kernel time and the committed counters x its share
+    roof = line['roofline']
+    assert roof['frac'] is not None and roof['avg_kernel_ms'] > 0 and 'x 0.5000' in roof['counters_from']
+    assert 'NOT collected in this run' in roof['counters_from'] and line['hbm']['traffic_bytes'] > 0
     # one GPU: no c3 leg, no model keys
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--stub'],
                        env=env, capture_output=True, text=True, timeout=120)
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert r.returncode == 0 and line['n_gpus'] == 1 and 'c3' not in line and 'model_ms_per_step' not in line
+
+
+def test_bench_rank_that_never_returns_is_reported_with_every_ranks_phase():
+    '''a multi-rank run never hangs silently.  A stand-in rank (--stub) stops responding in a phase of the
+    protocol ("first gather": a collective one rank never joins blocks the others inside RCCL, where no exception reaches them);
+    its own watchdog thread ends it after MIPTINA_PHASE_TIMEOUT seconds with ONE line naming the phase every rank had reached,
+    the launcher stops the other ranks, and the exit code is not 0'''
+    import subprocess
+    env = dict(os.environ, MIPTINA_PHASE_TIMEOUT='2')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MIPTINA_RDZV_DIR'):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--stub',
+                        '--stub-hang', '1:first gather', '--c3-steps', '0'], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 60
+    assert "stuck in phase 'first gather'" in r.stderr, r.stderr
+    assert 'rank 0:' in r.stderr and 'rank 1: first gather' in r.stderr       # which phase EVERY rank reached
+    assert 'launch_ranks: rank' in r.stderr and 'phases:' in r.stderr         # the launcher's own line
+    # and a rank that fails (an exception: what a failed RCCL call raises) names its phase as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--stub',
+                        '--stub-hang', '0:CommInitRank:raise', '--c3-steps', '0'], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "failed in phase 'CommInitRank'" in r.stderr, r.stderr

@@ -354,6 +354,36 @@ def timeline(name='s978', spp=32, n=512):
     return res
 
 
+def fixedcost(name='s978', n=512, steps=12):
+    '''solo launches of B frames (each synchronised before the next): kernel ms against B.  The slope is the steady-state cost
+    of a frame of THIS film, the intercept what a launch costs beyond it (fill + drain)'''
+    res = {}
+    common.reset_all()
+    eng = setup_engine(scenes.get_scene(name), n, n, mode='fast')
+    c = ctx()
+    for kv in filter(None, os.environ.get('MIPTINA_OPTS', '').split(',')):
+        c.set_option(kv.split('=')[0], int(kv.split('=')[1]))
+    for B in (4, 8, 16, 32, 48, 64):
+        c.set_option('batch', B)
+        for _ in range(2):
+            eng.render(B)
+            c.call('mpt_synchronize')
+        c.kernel_time()
+        for _ in range(steps):
+            eng.render(B)
+            c.call('mpt_synchronize')
+        kms, nl = c.kernel_time()
+        res[B] = round(kms / max(nl, 1), 4)
+    bs = np.array(sorted(res), float)
+    ts = np.array([res[int(b)] for b in bs])
+    slope, icpt = np.polyfit(bs[2:], ts[2:], 1)
+    res['fit_ms_per_frame'] = round(float(slope), 5)
+    res['fit_intercept_ms'] = round(float(icpt), 4)
+    print('fixedcost', json.dumps(res), flush=True)
+    common.reset_all()
+    return res
+
+
 def c3(n=2048, spp=64):
     '''config 3's film on one GPU: S978 at 2048x2048 (needs max_filmsize = 2^22)'''
     common.reset_all()
@@ -583,6 +613,9 @@ if __name__ == '__main__':
         save()
     if 'blk' in what:
         out['blk'] = blk()
+        save()
+    if 'fixedcost' in what:
+        out['fixedcost'] = fixedcost()
         save()
     if 'timeline' in what:
         out['timeline'] = timeline()
