@@ -193,9 +193,11 @@ void  mpt_host_free(void *p);
 
 /* measurement */
 int mpt_get_counters(mpt_ctx *ctx, mpt_counters *out);
-/* Diagnostics (option "timeline" = 1): per wave of the last LDS-kernel launch, four 100 MHz timestamps
- * {start, scene copied to LDS, work queues found empty, exit}.  *nwaves = waves recorded. */
-int mpt_get_timeline(mpt_ctx *ctx, unsigned long long *out /* [cap_waves][4] */, int cap_waves, int *nwaves);
+/* Diagnostics (option "timeline" = 1): per wave of the last LDS-kernel launch, eight words: four 100 MHz timestamps
+ * {start, scene copied to LDS, work queues found empty, exit} and, in a -DMPT_X_TIMELINE2 build only (else 0), {time of the
+ * last work item pulled, items pulled, lanes in flight when the queues were found empty, shading passes after that}.
+ * *nwaves = waves recorded. */
+int mpt_get_timeline(mpt_ctx *ctx, unsigned long long *out /* [cap_waves][8] */, int cap_waves, int *nwaves);
 int mpt_reset_counters(mpt_ctx *ctx);
 /* Diagnostics: launch a one-workgroup kernel (`threads` lanes, `lds_bytes` of LDS) on a stream of its own
  * while the enqueued render launches keep running, and return the wall time until it has completed --

@@ -6,7 +6,7 @@ Tolerances (resolved image, per-pixel L2 over rgb; helpers.STRICT / helpers.FAST
 MI355X and against the oracle's own f32-vs-f64 spread
 (test_oracle_cpu.py::test_f32_oracle_agrees_with_f64_build):
   strict build : >= 99.9 % of pixels within 1e-4 * (1 + |ref|), relative RMSE <= 1e-4
-  fast build   : >= 99.5 % of pixels within 1e-3 * (1 + |ref|), relative RMSE <= 2e-3 (SURVEY 8d);
+  fast build   : >= 99.5 % of pixels within 1e-3 * (1 + |ref|), relative RMSE <= 1e-3 (SURVEY 8d);
                  one flipped discrete decision (lobe choice, edge hit) moves a pixel by O(sample/spp),
                  so cases with few samples per pixel or ill-conditioned materials state their own
                  calibrated bound, with the measurement it comes from.
@@ -500,7 +500,7 @@ def test_quantised_boxes_far_from_the_origin(fresh, oracle_mod):
         assert c.get_option('last_kernel') == 2 and np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
         got[quant] = FilmTable().get_image().copy()
         # f32 positions 500 units out carry 3e-5 of absolute error: pixels along silhouettes flip (measured below 0.3 %)
-        assert_parity(got[quant], want, FAST[0], 0.01, 1e-2, what=f'moved scene, 4-wide quant={quant} vs oracle')
+        assert_parity(got[quant], want, FAST[0], 0.0051, 2.7e-3, what=f'moved scene, 4-wide quant={quant} vs oracle')   # measured 0.39 % / 2.05e-3 (bounds = 1.3 x)
     reset_all()
     assert_parity(got[1], got[0], *FAST, what='moved scene, 8-bit boxes vs exact ones')
 
@@ -824,8 +824,8 @@ def test_scene_scale_dependence_is_the_references(fresh, oracle_mod, k):
         if k < 1:
             # a scene 500x smaller than the constants eps = 1e-6, inf = 1e6 were chosen for: many hits sit on the
             # |b| >= eps threshold of geometries.py:129 and flip with the last bit (measured: strict 0.12 % of the
-            # pixels / rel-RMSE 1.9e-3, fast 0.61 % / 2.9e-3)
-            b = (1e-4, 0.0025, 3.5e-3) if mode == 'strict' else (1e-3, 0.012, 5e-3)
+            # pixels / rel-RMSE 1.88e-3, fast 0.59 % / 3.15e-3; the bounds are 1.3 x that)
+            b = (1e-4, 0.0016, 2.45e-3) if mode == 'strict' else (1e-3, 0.0077, 4.1e-3)
         else:
             b = bounds(mode)
         assert_parity(FilmTable().get_image(), want, *b, what=f'scale {k} {mode}')
@@ -997,7 +997,7 @@ def test_full_size_properties_and_oracle_parity(fresh, oracle_mod, name):
     ref.render(spp)
     want = ref.get_image()[x0:x1]
     # rel-RMSE of the whole 262 144-pixel film: a handful of flipped 32-spp pixels put it at 9e-5 (measured)
-    assert_parity(imgs['strict'][x0:x1], want, STRICT[0], STRICT[1], 1.5e-4, what=f'full-size strict, columns [{x0},{x1})')
+    assert_parity(imgs['strict'][x0:x1], want, STRICT[0], STRICT[1], 1.2e-4, what=f'full-size strict, columns [{x0},{x1})')   # measured 9.07e-5 on s978 (9.1e-7 on s34): 1.3 x
     assert_parity(imgs['fast'][x0:x1], want, *FAST, what=f'full-size fast, columns [{x0},{x1})')
 
 
@@ -1223,7 +1223,7 @@ def test_large_scene_fast_vs_strict(fresh):
             assert np.isfinite(imgs[mode]).all() and np.all(imgs[mode][..., 3] == 1)
         # the 200k-triangle soup has nearly coincident triangles everywhere: the pixels whose closest hit differs
         # between the ordered and the reference traversal carry the RMSE (measured 0.15 % / 3.1e-3; c4: 0.07 % / 4e-4)
-        assert_parity(imgs['fast'], imgs['strict'], FAST[0], FAST[1], 1e-2 if tree == 0 else FAST[2], what=f'large scene tree={tree}')
+        assert_parity(imgs['fast'], imgs['strict'], FAST[0], FAST[1], 4.2e-3 if tree == 0 else 1.2e-3, what=f'large scene tree={tree}')   # measured 3.19e-3 (LBVH) / 9.03e-4 (SAH): 1.3 x
     reset_all()
 
 
@@ -1453,8 +1453,7 @@ def test_device_sah_pass_above_a_million_faces_and_its_host_fallback(fresh):
         films[key] = FilmTable().get_image().copy()
     reset_all()
     assert np.array_equal(films['fallback'], films['host'])
-    # (nearly coincident triangles of a soup: equal-depth ties flip pixels, as on C5; calibrated from the first run)
-    assert_parity(films['dev'], films['host'], FAST[0], 0.02, 5e-3, what='2.6 M triangles: device SAH tree vs host SAH tree')
+    assert_parity(films['dev'], films['host'], *FAST, what='2.6 M triangles: device SAH tree vs host SAH tree')   # measured: identical
 
 
 def test_config5_reference_build_fails_on_the_stated_scene(fresh, oracle_mod):
@@ -1496,7 +1495,7 @@ def test_config5_reference_build_fails_on_the_stated_scene(fresh, oracle_mod):
     strict = FilmTable().get_image()
     reset_all()
     from helpers import assert_parity
-    assert_parity(fast[x0:x1], strict[x0:x1], FAST[0], FAST[1], 3e-3, what='C5 (seed 12345) fast vs strict, 8 columns')   # measured 1.7e-3
+    assert_parity(fast[x0:x1], strict[x0:x1], FAST[0], FAST[1], 2.3e-3, what='C5 (seed 12345) fast vs strict, 8 columns')   # measured 1.74e-3 (bound = 1.3 x)
 
 
 def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
@@ -1536,7 +1535,7 @@ def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
     assert np.all(raw[..., 3] == spp) and np.isfinite(raw).all() and raw[..., :3].min() >= 0
     # 8192 pixels at 16 spp over a triangle soup: a handful of pixels whose closest hit flips between two
     # nearly coincident triangles carry the RMSE (measured: 0.10 % outliers, rel-RMSE 2.9e-3, max diff 0.14)
-    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 4.5e-3, what='C5 1M triangles fast, 8 columns x 16 spp')
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 3.8e-3, what='C5 1M triangles fast, 8 columns x 16 spp')   # measured 2.91e-3 (bound = 1.3 x)
     assert ctx().get_option('last_kernel') == 2           # gather kernel over the 4-wide collapse (465 k nodes, 8-bit child boxes)
     # the same with the exact child boxes (option wide_quant = 0: 128-B records)
     ctx().set_option('wide_quant', 0)
@@ -1545,7 +1544,7 @@ def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
     eng.render(spp)
     raw = FilmTable().get_raw().reshape(nx, ny, 4)
     assert ctx().get_option('last_kernel') == 2 and np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
-    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 4.5e-3, what='C5 1M triangles fast, exact 4-wide boxes, 8 columns x 16 spp')
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 3.8e-3, what='C5 1M triangles fast, exact 4-wide boxes, 8 columns x 16 spp')   # measured 2.91e-3
     # the same through the binary tree (option wide = 0)
     ctx().set_option('wide', 0)
     FilmTable().clear()
@@ -1553,13 +1552,13 @@ def test_config5_one_million_triangles_vs_oracle(fresh, oracle_mod):
     eng.render(spp)
     raw = FilmTable().get_raw().reshape(nx, ny, 4)
     assert ctx().get_option('last_kernel') == 0 and np.all(raw[..., 3] == spp) and np.isfinite(raw).all()
-    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 4.5e-3, what='C5 1M triangles fast over the binary tree, 8 columns x 16 spp')
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 3.8e-3, what='C5 1M triangles fast over the binary tree, 8 columns x 16 spp')   # measured 2.91e-3
     reset_all()
     eng = _engine(None, scene, nx, ny, mode='strict', slab=(x0, x1))
     eng.render(spp)
     # one pixel of the 8192 picks the other of two nearly coincident triangles (libm's last bit): 0.012 %
     # outliers, but its 0.03 difference alone puts the window's rel-RMSE at 3.4e-4 (measured)
-    assert_parity(FilmTable().get_image()[x0:x1], want, STRICT[0], STRICT[1], 5.5e-4, what='C5 1M triangles strict, 8 columns x 16 spp')
+    assert_parity(FilmTable().get_image()[x0:x1], want, STRICT[0], STRICT[1], 4.5e-4, what='C5 1M triangles strict, 8 columns x 16 spp')   # measured 3.42e-4 (bound = 1.3 x)
     reset_all()
 
 
@@ -1587,7 +1586,7 @@ def test_config4_full_scene_with_environment_vs_oracle(fresh, oracle_mod):
     raw = FilmTable().get_raw().reshape(nx, ny, 4)
     assert np.all(raw[..., 3] == spp) and np.isfinite(raw).all() and raw[..., :3].min() >= 0
     # one pixel next to the environment map's sun lobe differs by 0.79 at 8 spp: it alone is 1.4e-3 of rel-RMSE
-    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 2.5e-3, what='C4 99k triangles + env fast, 32 columns x 8 spp')
+    assert_parity(FilmTable().get_image()[x0:x1], want, FAST[0], FAST[1], 2.0e-3, what='C4 99k triangles + env fast, 32 columns x 8 spp')   # measured 1.51e-3 (bound = 1.3 x)
     reset_all()
     eng = _engine(None, scene, nx, ny, mode='strict', world=world, slab=(x0, x1))
     eng.render(spp)

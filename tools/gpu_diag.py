@@ -338,11 +338,20 @@ def timeline(name='s978', spp=32, n=512):
             eng.render(spp)
             c.call('mpt_synchronize')
         nw = C.c_int(0)
-        buf = (C.c_ulonglong * (4 * 4096))()
+        buf = (C.c_ulonglong * (8 * 4096))()
         c.call('mpt_get_timeline', buf, 4096, C.byref(nw))
-        t = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4)[:nw.value].astype(np.int64)
+        t = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)[:nw.value].astype(np.int64)
+        np.save(os.path.join(ROOT, 'gpurun_out', f'timeline_raw_{parts}.npy'), t)
         t0 = t[:, 0].min()
-        us = (t - t0) / 100.0
+        us = (t[:, :4] - t0) / 100.0
+        if t[:, 5].max() > 0:            # diagnostic build -DMPT_X_TIMELINE2: last pull, items, lanes in flight at empty, passes after
+            lastpull = (t[:, 4] - t0) / 100.0
+            extra = {'last_pull': [round(float(x), 1) for x in np.percentile(lastpull, [0, 10, 50, 90, 100])],
+                     'last_item_us': [round(float(x), 1) for x in np.percentile(us[:, 2] - lastpull, [0, 10, 50, 90, 100])],
+                     'items_per_wave': [int(x) for x in np.percentile(t[:, 5], [0, 10, 50, 90, 100])],
+                     'lanes_in_flight_at_empty': [int(x) for x in np.percentile(t[:, 6], [0, 10, 50, 90, 100])],
+                     'passes_after_empty': [int(x) for x in np.percentile(t[:, 7], [0, 10, 50, 90, 100])]}
+            print('timeline2', parts, json.dumps(extra), flush=True)
         wg_exit = us[:, 3].reshape(-1, 16).max(axis=1)
         q = lambda a: [round(float(x), 1) for x in np.percentile(a, [0, 10, 50, 90, 100])]
         res[str(parts)] = {'start': q(us[:, 0]), 'ready': q(us[:, 1]), 'queue_empty': q(us[:, 2]),

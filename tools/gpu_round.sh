@@ -30,6 +30,7 @@ for step in "$@"; do
     pipe)        run pipe 400 python tools/gpu_diag.py pipe ;;
     timeline)    run timeline 300 python tools/gpu_diag.py timeline ;;
     fixedcost)   run fixedcost 300 python tools/gpu_diag.py fixedcost ;;
+    timeline2)   MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_tl2.so run timeline2 300 python tools/gpu_diag.py timeline ;;   # needs tools/ab_build.sh tl2 "-DMPT_X_TIMELINE2=1"
     c3)          run c3 300 python tools/gpu_diag.py c3 ;;
     configs)     run configs 600 python tools/run_configs.py ;;
     big_ab)      MIPTINA_WIDE=0 run big_bin 400 python tools/run_configs.py C4 C5; MIPTINA_WIDE=1 run big_wide 400 python tools/run_configs.py C4 C5 ;;
