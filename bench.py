@@ -91,7 +91,7 @@ def is_counting_kernel(name):
 def render_kernel_name(mode, last_kernel):
     if mode != 'fast':
         return 'render_kernel_strict'
-    return ('render_kernel_fast', 'render_kernel_lds', 'render_kernel_wide', 'render_kernel_pool')[last_kernel]
+    return ('render_kernel_fast', 'render_kernel_lds', 'render_kernel_wide', 'render_kernel_pool', 'render_kernel_oct')[last_kernel]
 
 
 def collect_pmc(argv_tail, budget_s=150):
@@ -394,6 +394,8 @@ def _run_rank(args, rank, world, pmc, pmc_source, phases):
         film = FilmTable()
     if args.chunk >= 0:
         c.set_option('chunk', args.chunk)
+    for kv in filter(None, os.environ.get('MIPTINA_OPTS', '').split(',')):    # A/B switches (tools/gpu_round.sh), e.g. finalise=0
+        c.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     c.set_option('batch', SPP)
     if comm:
         comm.set_stripes(NX)                  # every world-th stripe of 16 columns: even load

@@ -102,6 +102,8 @@ void mpt_destroy(mpt_ctx *ctx);
  * adding zero or not is the same sum; 0 = traced like the reference does; -1 = on in the production build, off in the strict build: default), "pool" /
  * "pool_shaders" (the LDS kernel with its waves specialised into tracers and shaders and two path pools in LDS between them:
  * measured slower, default off),
+ * "finalise" (1, default: a render launch that finds no other launch in flight adds its frames to the film, resolves and
+ * writes out finished tiles itself while its last paths drain; 0: always the combine pass after the launch; same film bit for bit),
  * "timeline" (1 = record mpt_get_timeline data), "reserve_cus" (CUs every persistent render launch leaves
  * unclaimed, default 0; measured to be of no use to foreign kernels while launches overlap, kept for experiments).
  * read-only: "tree_depth", "fast_depth", "wide_nodes", "wide_depth", "wide_ratio_permille", "pending", "last_kernel" (0 = gather over
@@ -140,6 +142,11 @@ int mpt_get_tree(mpt_ctx *ctx, int32_t *child /*[n-1][2]*/, int32_t *leaf /*[n]*
  * child boxes, qnode [nw][4][4] with 8-bit boxes; any pointer may be NULL; *nw = wide nodes built (0: none) */
 int mpt_get_wide(mpt_ctx *ctx, float *wnode, float *qnode, int cap_nodes, int *nw);
 
+/* test/inspection: the 8-wide octant-ordered records the option "wide8" kernel walks (no reference counterpart; layout in
+ * ptina_amd/csrc/oct_build.cpp): onode [nw][5][4] f32, perm [n] = the leaf slot of the triangle at place t of that tree's leaf
+ * order; any pointer may be NULL; *nw = 8-wide nodes built (0: none) */
+int mpt_get_oct8(mpt_ctx *ctx, float *onode, int32_t *perm, int cap_nodes, int *nw);
+
 /* Pure sizing rule of the on-device SAH re-partition's workspace (no context, no GPU; the reference has no counterpart: its
  * tree is the LBVH of ptina/tree/lbvh.py:297-305).  For a model of n faces: out[0] = segments a level can hold, out[1] = words
  * of per-segment workspace the build allocates, out[2] = words a level of `nseg` segments writes, out[3] = bins per axis at
@@ -177,6 +184,13 @@ int mpt_synchronize(mpt_ctx *ctx);
 int mpt_clear(mpt_ctx *ctx, int pass);
 /* FilmTable.get_image, ptina/filmtable.py:47-63 : out [nx][ny][4] */
 int mpt_get_image(mpt_ctx *ctx, int pass, float *out);
+/* Advice, optional (the reference's get_image allocates its array inside the call, filmtable.py:48; this says beforehand where
+ * that array will be): the next mpt_get_image(pass, out) will be given THIS `out` (a buffer of mpt_host_alloc, [nx][ny][4]).
+ * A render launch that finalises its own tiles (option "finalise") then also writes the resolved image there while it drains,
+ * and that mpt_get_image only waits for the launch.  Results never depend on it: a different pointer, a film that has changed
+ * since, or no hint at all take the resolve pass.  `out` must stay allocated until mpt_get_image(pass, out) has returned or
+ * another hint (NULL = none) has replaced it; only pass 0 is used. */
+int mpt_hint_image(mpt_ctx *ctx, int pass, float *out);
 /* FilmTable.fast_export_image, ptina/filmtable.py:66-79 : out [ny*nx*3] */
 int mpt_fast_export_image(mpt_ctx *ctx, int pass, float *out);
 /* raw accumulators [nx*ny][4] (rgb sums, sample count) */

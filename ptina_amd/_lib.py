@@ -66,6 +66,7 @@ SIGNATURES = {
     'mpt_get_tree': (_i, [_vp, _ip, _ip, _fp, _fp, _ip, _ip]),
     'mpt_get_wide': (_i, [_vp, _fp, _fp, _i, C.POINTER(_i)]),
     'mpt_sah_workspace': (_i, [_i, C.c_int64, C.POINTER(C.c_int64)]),
+    'mpt_get_oct8': (_i, [_vp, _fp, _ip, _i, C.POINTER(_i)]),
     'mpt_set_camera': (_i, [_vp, _fp, _fp]),
     'mpt_clear_lights': (_i, [_vp]),
     'mpt_add_light': (_i, [_vp, _i, _fp, _fp, _fp, C.c_float, C.POINTER(_i)]),
@@ -80,6 +81,7 @@ SIGNATURES = {
     'mpt_synchronize': (_i, [_vp]),
     'mpt_clear': (_i, [_vp, _i]),
     'mpt_get_image': (_i, [_vp, _i, _fp]),
+    'mpt_hint_image': (_i, [_vp, _i, _fp]),
     'mpt_fast_export_image': (_i, [_vp, _i, _fp]),
     'mpt_get_film_raw': (_i, [_vp, _i, _fp]),
     'mpt_resolve': (_i, [_vp, _i]),

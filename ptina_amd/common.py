@@ -33,9 +33,9 @@ def register(cls):
 def reset_all():
     '''drop every singleton and the device context (tests; the reference has no equivalent
     because a Taichi program cannot be re-initialised)'''
+    _lib.drop_context()          # first: a launch in flight may still be writing into an array a singleton holds (FilmTable._next)
     for cls in _singletons:
         cls._instance = None
-    _lib.drop_context()
 
 
 def ctx():

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include "mpt_types.h"
 #include "tri_records.h"
+#include "film_ops.h"
 
 // SobolSampler.update, sampling/sobol.py:99-105, for `count` consecutive frames in one launch:
 // thread j owns dimension j, keeps X[j] in a register, and emits P[f][j] for every frame.
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void combine_kernel(MptVec4 *__restrict__ film
     MptVec4 a = film[pix];
     for (int c = 0; c < nframes; c++) {
         MptVec4 b = partial[(size_t)c * stride + t];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        film_add_sample(a, b.x, b.y, b.z);             // (b.w is the launch's slab tag: 1, or the ready flag of the tail finalisation)
     }
     film[pix] = a;
 }
@@ -76,14 +77,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const MptVec4 *__restrict_
                                                       size_t npix) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= npix) return;
-    MptVec4 v = film[t];
-    if (v.w != 0.0f) {
-        v.x /= v.w; v.y /= v.w; v.z /= v.w;
-        v.w = 1.0f;
-    } else {
-        v.x = 0.9f; v.y = 0.4f; v.z = 0.9f; v.w = 0.0f;
-    }
-    out[t] = v;
+    out[t] = film_resolve(film[t]);
 }
 
 // FilmTable.fast_export_image, filmtable.py:66-79 : flat RGB at (y * nx + x) * 3.
@@ -197,5 +191,25 @@ __global__ __launch_bounds__(256) void derive_tfast_kernel(const MptVec4 *__rest
 MPT_KERNEL_API hipError_t mpt_launch_derive_tfast(const MptVec4 *tgeo, MptVec4 *tfast, int n, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(derive_tfast_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tgeo, tfast, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- triangle records in the 8-wide tree's leaf order
+// tfast8[t] = tfast[perm[t]] (48 B), tshade8[t] = tshade[perm[t]] (64 B): the leaf children of an 8-wide node name their
+// triangles by one base index (oct_build.cpp)
+__global__ __launch_bounds__(256) void permute_tris_kernel(const MptVec4 *__restrict__ tfast, const MptVec4 *__restrict__ tshade,
+                                                           const int32_t *__restrict__ perm, MptVec4 *__restrict__ tfast8,
+                                                           MptVec4 *__restrict__ tshade8, int n) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const size_t s = (size_t)perm[t];
+    for (int k = 0; k < 3; k++) tfast8[(size_t)t * 3 + k] = tfast[s * 3 + k];
+    for (int k = 0; k < 4; k++) tshade8[(size_t)t * 4 + k] = tshade[s * 4 + k];
+}
+
+MPT_KERNEL_API hipError_t mpt_launch_permute_tris(const MptVec4 *tfast, const MptVec4 *tshade, const int32_t *perm, MptVec4 *tfast8,
+                                              MptVec4 *tshade8, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(permute_tris_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tfast, tshade, perm, tfast8, tshade8, n);
     return hipGetLastError();
 }

@@ -133,6 +133,7 @@ extern "C" int mpt_comm_gather_film(mpt_ctx *c, int pass, int root) {
                         c->x0, c->x1, c->rank, lo, hi, R);
     }
     if (R == 1) return 0;
+    c->film_version++;                          // the root's film is about to change under any image written early (mpt_hint_image)
     // ---- the piece table of this rank's side of the gather, rebuilt when the split changes
     //   sender: its ranges film -> packed;  root: every peer's ranges packed -> film
     const bool is_root = c->rank == root;

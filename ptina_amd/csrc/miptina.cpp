@@ -140,6 +140,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     }
     if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) return bail("aux stream");
     if (hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess) return bail("event");
+    if (hipEventCreateWithFlags(&c->ev_film, hipEventDisableTiming) != hipSuccess) return bail("event");
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -190,6 +191,8 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
         hipFree(c->partial2[k]); hipFree(c->sP2[k]); hipFree(c->d_work2[k]);
     }
     if (c->ev_main) hipEventDestroy(c->ev_main);
+    if (c->ev_film) hipEventDestroy(c->ev_film);
+    hipFree(c->onode); hipFree(c->tfast8); hipFree(c->tshade8); hipFree(c->d_perm8);
     for (auto &pr : c->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto &ev : c->event_pool) hipEventDestroy(ev);
     for (int p = 0; p < 3; p++) hipFree(c->film[p]);
@@ -288,6 +291,12 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
     } else if (k == "skip_dark") {
         if (value < -1 || value > 1) return fail("skip_dark must be -1 (auto), 0 or 1");
         c->skip_dark = value;
+    } else if (k == "wide8") {
+        if (value != 0 && value != 1) return fail("wide8 must be 0 or 1");
+        if (value != c->use_wide8) { c->use_wide8 = value; c->tree_valid = false; }    // (built by the next mpt_build_tree)
+    } else if (k == "finalise") {
+        if (value < 0 || value > 2) return fail("finalise must be 0 (combine pass), 1 (tail finalisation) or 2 (the same without the early image: A/B)");
+        c->finalise = value;
     } else if (k == "pool") {
 #if !MPT_WITH_POOL
         if (value) return fail("this library is built without the pooled LDS kernel (an A/B build: make -C ptina_amd/csrc pool)");
@@ -358,6 +367,11 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "lds") *value = c->use_lds;
     else if (k == "lds_block") *value = c->lds_block;
     else if (k == "zero_copy") *value = c->zero_copy;
+    else if (k == "wide8") *value = c->use_wide8;
+    else if (k == "oct_nodes") *value = c->oct_nodes;
+    else if (k == "oct_depth") *value = c->oct_depth;
+    else if (k == "finalise") *value = c->finalise;
+    else if (k == "last_finalised") *value = c->last_finalised;
     else if (k == "pool") *value = c->use_pool;
     else if (k == "skip_dark") *value = c->skip_dark;
     else if (k == "pool_shaders") *value = c->pool_shaders;
@@ -409,6 +423,7 @@ extern "C" int mpt_set_size(mpt_ctx *c, int nx, int ny) {
     // the reference keeps one flat buffer and only changes `res` (filmtable.py:41-42): stale sums
     // of another resolution are the caller's to clear(); same here.
     c->nx = nx; c->ny = ny; c->x0 = 0; c->x1 = nx; c->stripe_w = 0; c->stripe_idx = 0; c->stripe_mod = 1;
+    c->film_version++;
     return 0;
 }
 
@@ -643,7 +658,7 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     p.ntiles = p.tiles_x * p.tiles_y;
     memcpy(p.world_fac, c->world_fac, sizeof p.world_fac);
     memcpy(p.v2w, c->v2w, sizeof p.v2w);
-    p.wnode = c->wnode; p.qnode = c->qnode; p.stack_spill = nullptr;
+    p.wnode = c->wnode; p.qnode = c->qnode; p.onode = nullptr; p.stack_spill = nullptr;
     p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade; p.tfast = c->tfast;
     p.default_mtl = c->caps.max_materials;
     p.skip_dark = c->skip_dark >= 0 ? c->skip_dark : (c->mode == MPT_MODE_FAST ? 1 : 0);
@@ -782,11 +797,14 @@ extern "C" int mpt_flush(mpt_ctx *c) {
                 hipFree(c->partial2[q]); c->partial2[q] = nullptr; c->partial2_cap[q] = 0;
                 if (dev_alloc(&c->partial2[q], need)) return 1;
                 c->partial2_cap[q] = need;
+                // the w of a slab entry is its ready flag for the tail finalisation (the launch's tag): fresh memory must not
+                // hold one by accident
+                HIP_TRY(hipMemset(c->partial2[q], 0, need * sizeof(MptVec4)));
             }
         p.partial = c->partial2[k];
         p.work_counter = c->d_work2[k];
         if (!use_spec) {
-            HIP_TRY(hipMemsetAsync(c->d_work2[k], 0, 8 * sizeof(unsigned int), ss));
+            HIP_TRY(hipMemsetAsync(c->d_work2[k], 0, 16 * sizeof(unsigned int), ss));   // 8 queue heads + the finalisation's tile counter
             HIP_TRY(hipEventRecord(c->ev_sobol2[k], ss));
         }
         HIP_TRY(hipStreamWaitEvent(rs, c->ev_sobol2[k], 0));
@@ -806,15 +824,15 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     // read-back (bench.py's `value`, an interactive frame) is one launch at a time -- so it takes every CU; 1/G of
     // them would only make it G times longer.  Launches issued while others are still in flight take 1/G each.
     int launch_div = std::max(c->cur_div, 1);
-    if (fast && launch_div > 1 && c->grid_div <= 0) {
-        bool ring_idle = true;
+    bool ring_idle = fast;
+    if (fast && ((launch_div > 1 && c->grid_div <= 0) || c->finalise)) {
         for (int q = 0; q < c->cur_depth && ring_idle; q++) {
             hipError_t st = hipEventQuery(c->ev_render[q]);
             if (st == hipErrorNotReady) ring_idle = false;
             else if (st != hipSuccess) HIP_TRY(st);
         }
-        if (ring_idle) launch_div = 1;
     }
+    if (fast && launch_div > 1 && c->grid_div <= 0 && ring_idle) launch_div = 1;
     c->last_div = launch_div;
     const int launch_cus = std::max(usable_cus / launch_div, 1);   // G launches never claim more than usable_cus
     // scenes that do not fit LDS walk the 4-wide nodes (option "wide"; built by mpt_build_tree unless too deep)
@@ -822,10 +840,14 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     // half the dependent fetches; with the planes picked by direction sign it wins on both big configurations
     // (MI355X: C4 963 -> 1135 Msamples/s, C5 494 -> 520), so it is the default wherever the collapse was built.
     const bool wide_pays = c->use_wide != 0;
-    const bool wide_kernel = fast && !lds_kernel && wide_pays && c->wide_nodes > 0;
+    // ... or the 8-wide octant-ordered nodes (option "wide8", oct_build.cpp) with the triangle records in that tree's leaf order
+    const bool oct_kernel = fast && !lds_kernel && c->use_wide8 && c->oct_nodes > 0;
+    const bool wide_kernel = oct_kernel || (fast && !lds_kernel && wide_pays && c->wide_nodes > 0);
     int wide_blocks = 0;
+    if (oct_kernel) { p.onode = c->onode; p.tfast = c->tfast8; p.tshade = c->tshade8; }
     if (wide_kernel) {
-        HIP_TRY(mpt_wide_blocks(launch_cus, c->count, c->use_quant, &wide_blocks));
+        if (oct_kernel) HIP_TRY(mpt_oct_blocks(launch_cus, c->count, &wide_blocks));
+        else HIP_TRY(mpt_wide_blocks(launch_cus, c->count, c->use_quant, &wide_blocks));
         const size_t need_spill = (size_t)wide_blocks * MPT_BLOCK * 128;   // >= SpillStack::SPILL entries per lane (128 - LDS levels)
         // every slot of the ring at once (an allocation synchronises the device), and one strip PER SLOT: the launches of
         // different slots overlap, and a strip is indexed by block and lane only
@@ -874,6 +896,33 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         }
         p.timeline = c->d_timeline;
     }
+    // Tail finalisation: a launch that has the chip to itself -- a step that ends with a read-back, an interactive frame -- adds
+    // its frames to the film, resolves and writes the image out by itself, in the shadow of its own drain (finalise_tiles).  A
+    // launch issued while another is in flight keeps the combine pass on the main stream: two launches must not add to the same
+    // film pixels at the same time, and the main stream is what orders them.
+    const bool fin = fast && c->finalise && ring_idle && !pool_kernel && p.nitems > 0;
+    c->launch_seq++;
+    p.fin_counter = nullptr; p.image_out = nullptr; p.slab_tag = 1.0f;
+    c->film_version++;                           // this batch changes pass 0, whoever adds it
+    if (fin) {
+        if (c->launch_seq % 4194304u == 0u)      // the tags come round again: no entry of any slab may still carry the old one
+            for (int q = 0; q < MPT_MAX_PIPE; q++)
+                if (c->partial2[q]) HIP_TRY(hipMemsetAsync(c->partial2[q], 0, c->partial2_cap[q] * sizeof(MptVec4), rs));
+        p.fin_counter = c->d_work2[k] + 8;
+        p.slab_tag = 2.0f + (float)(c->launch_seq % 4194304u);               // exact in f32; never 0 (fresh memory) or 1 (a combine-pass launch)
+        // everything the main stream still has to do to the film (an earlier batch's combine, a clear, a gather) comes first
+        HIP_TRY(hipEventRecord(c->ev_film, c->stream));
+        HIP_TRY(hipStreamWaitEvent(rs, c->ev_film, 0));
+        // the resolved image as well, if the caller has said where get_image() will want it and this share is the whole film
+        const size_t img_bytes = (size_t)c->nx * c->ny * sizeof(MptVec4);
+        void *mapped = nullptr;
+        if (c->hint_image && c->finalise == 1 && c->zero_copy && c->x0 == 0 && c->x1 == c->nx && c->stripe_w == 0 && is_locked_range(c->hint_image, img_bytes) &&
+            hipHostGetDevicePointer(&mapped, c->hint_image, 0) == hipSuccess && mapped) {
+            p.image_out = (MptVec4 *)mapped;
+            c->early_ptr = c->hint_image; c->early_version = c->film_version; c->early_stream = rs;
+        }
+    }
+    c->last_finalised = fin ? 1 : 0;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(hipEventRecord(e0, rs));
     if (!fast) HIP_TRY(mpt_launch_render_strict(&p, p.ntiles, stack, c->count, rs));
@@ -881,9 +930,10 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     else if (pool_kernel) HIP_TRY(mpt_launch_render_pool(&p, launch_cus, 1024, pool_bytes, c->count, rs));
 #endif
     else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, launch_cus, lds_block_used, lds_bytes, c->count, rs));
+    else if (oct_kernel) HIP_TRY(mpt_launch_render_oct(&p, wide_blocks, c->count, rs));
     else if (wide_kernel) HIP_TRY(mpt_launch_render_wide(&p, wide_blocks, c->count, c->use_quant, rs));
     else HIP_TRY(mpt_launch_render_fast(&p, launch_cus, stack, c->count, rs));
-    c->last_kernel = pool_kernel ? 3 : lds_kernel ? 1 : wide_kernel ? 2 : 0;
+    c->last_kernel = pool_kernel ? 3 : lds_kernel ? 1 : oct_kernel ? 4 : wide_kernel ? 2 : 0;
     HIP_TRY(hipEventRecord(e1, rs));
     c->events.push_back({ e0, e1 });
     if (c->events.size() > 4096) {
@@ -897,9 +947,10 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         // ordered after this render; the next batch, on the other stream, is not
         HIP_TRY(hipEventRecord(c->ev_render[k], rs));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_render[k], 0));
-        HIP_TRY(mpt_launch_combine(c->film[0], c->partial2[k], c->ny, c->x0, c->x1, p.stripe_w, p.stripe_pitch,
-                                   p.partial_stride / std::max(c->ny, 1), B, c->stream));
-        HIP_TRY(hipEventRecord(c->ev_free[k], c->stream));
+        if (!fin)
+            HIP_TRY(mpt_launch_combine(c->film[0], c->partial2[k], c->ny, c->x0, c->x1, p.stripe_w, p.stripe_pitch,
+                                       p.partial_stride / std::max(c->ny, 1), B, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_free[k], c->stream));      // (a finalising launch has consumed its slab itself)
         // Ahead of time, on the aux stream: the Sobol points and zeroed queue heads of the NEXT batch, assuming it
         // has as many frames as this one and uses the next ring slot (the sampler's future is deterministic; its
         // state X moves only when that batch is really launched).  Takes 25 us of Sobol kernel + memset off the
@@ -908,7 +959,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         if (k2 != k) {
             HIP_TRY(hipStreamWaitEvent(ss, c->ev_render[k2], 0));   // the batch that last read sP2[k2] / d_work2[k2]
             HIP_TRY(mpt_launch_sobol_update(c->sX, c->sV, c->sP2[k2], c->sdim, c->srows, c->stime, B, B, 0, ss));
-            HIP_TRY(hipMemsetAsync(c->d_work2[k2], 0, 8 * sizeof(unsigned int), ss));
+            HIP_TRY(hipMemsetAsync(c->d_work2[k2], 0, 16 * sizeof(unsigned int), ss));
             HIP_TRY(hipEventRecord(c->ev_sobol2[k2], ss));
             c->spec_valid = true; c->spec_slot = k2; c->spec_B = B; c->spec_time = c->stime;
         }
@@ -976,6 +1027,7 @@ extern "C" int mpt_clear(mpt_ctx *c, int pass) {                               /
     size_t npix = (size_t)c->nx * c->ny;
     for (int p = 0; p < 3; p++)
         if (c->film[p]) HIP_TRY(hipMemsetAsync(c->film[p], 0, npix * sizeof(MptVec4), c->stream));
+    c->film_version++;
     return 0;
 }
 
@@ -993,10 +1045,38 @@ extern "C" int mpt_resolve(mpt_ctx *c, int pass) {
     return 0;
 }
 
+extern "C" int mpt_hint_image(mpt_ctx *c, int pass, float *out) {
+    if (use_ro(c)) return 1;
+    if (pass != 0) return 0;                   // only the path pass is finalised inside the render launch
+    if (c->hint_image == out) return 0;
+    // the old array may be the one a launch in flight is writing its image into: the caller is free to let go of it after this call
+    if (c->early_ptr && c->early_ptr == c->hint_image) HIP_TRY(hipStreamSynchronize(c->stream));
+    c->hint_image = out;
+    c->early_ptr = nullptr;
+    return 0;
+}
+
 extern "C" int mpt_get_image(mpt_ctx *c, int pass, float *out) {               // filmtable.py:47-63
     if (use_ro(c)) return 1;                   // validates the handle and makes the context's device current (round-3 ADVICE)
     const size_t bytes = (size_t)c->nx * c->ny * sizeof(MptVec4);
     void *mapped = nullptr;
+    if (pass == 0) {
+        // The launch that rendered the frames may have written this very image already (tail finalisation, mpt_hint_image): then
+        // there is nothing left to do but wait for it.  The hint is spent either way: the array is the caller's from here on.
+        if (mpt_flush(c)) return 1;
+        const bool early = out && c->early_ptr == out && c->early_version == c->film_version;
+        if (c->hint_image == out || c->early_ptr == out) {
+            if (!early && c->early_ptr == out) HIP_TRY(hipStreamSynchronize(c->stream));    // (a stale image still being written)
+            c->hint_image = nullptr; c->early_ptr = nullptr;
+        }
+        if (early) {
+            if (check_pass(c, pass)) return 1;
+            // the launch's own stream: one completion signal (the main stream, which waits for the same launch before anything else
+            // it is given, would add a cross-stream hop in front of the host's wake-up)
+            HIP_TRY(hipStreamSynchronize(c->early_stream));
+            return check_watchdog(c);
+        }
+    }
     if (c->zero_copy && is_locked_range(out, bytes) && hipHostGetDevicePointer(&mapped, out, 0) == hipSuccess && mapped) {
         // the caller's array is page-locked memory of ours: the resolve pass writes the image straight into it over PCIe,
         // instead of into a device buffer that a DMA then copies (one dependent hop and the copy engine's start-up less)

@@ -64,6 +64,10 @@ MPT_KERNEL_API hipError_t mpt_wide_scan_bytes(int ni, size_t *bytes);
 MPT_KERNEL_API hipError_t mpt_wide_build(const MptVec4 *fnode, int n, MptVec4 *wnode, MptVec4 *qnode, int *bin_of, int *ncount,
                                      int *offset, void *scan_tmp, size_t scan_bytes, double *d_area, int *nwide, int *depth,
                                      double area[2], hipStream_t stream);
+MPT_KERNEL_API hipError_t mpt_launch_permute_tris(const MptVec4 *tfast, const MptVec4 *tshade, const int32_t *perm, MptVec4 *tfast8,
+                                              MptVec4 *tshade8, int n, hipStream_t stream);
+MPT_KERNEL_API hipError_t mpt_oct_blocks(int grid, int count, int *blocks);
+MPT_KERNEL_API hipError_t mpt_launch_render_oct(const MptRenderParams *p, int blocks, int count, hipStream_t stream);
 MPT_KERNEL_API hipError_t mpt_lbvh_sort_bytes(int n, size_t *bytes);
 MPT_KERNEL_API hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t stream);
 
@@ -73,6 +77,8 @@ MPT_KERNEL_API hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t st
 #endif
 #define MPT_INTERNAL __attribute__((visibility("hidden")))   // shared between the .cpp files, not exported
 MPT_INTERNAL int fail(const char *fmt, ...);
+struct mpt_ctx;
+MPT_INTERNAL int make_oct8(mpt_ctx *c);          // oct_build.cpp
 
 #define HIP_TRY(expr)                                                                     \
     do {                                                                                  \
@@ -190,6 +196,19 @@ struct mpt_ctx {
     int reserve_cus = 0;                              // CUs no persistent workgroup claims (experiments: see mpt_flush)
     int grid_div = 0;                                 // each launch takes 1/grid_div of the CUs; 0 = auto
     int cur_depth = 2, cur_div = 1;                   // what the last launch used
+    hipEvent_t ev_film = nullptr;                     // main-stream work on the film (combine, clear, gather) a finalising launch must see
+    // tail finalisation (render_kernel.hip finalise_tiles): option "finalise" (1 = launches that find the ring idle sum, resolve and
+    // write out their tiles themselves; 0 = always the combine pass); launch_seq numbers the launches (slab tags);
+    // film_version counts the changes of pass 0; hint_image = where the next mpt_get_image(0) wants the image (mpt_hint_image);
+    // early_* = the image a finalising launch has written (or is writing) and the film version it shows
+    int finalise = 1;
+    unsigned launch_seq = 0;
+    unsigned long long film_version = 0;
+    float *hint_image = nullptr;
+    float *early_ptr = nullptr;
+    hipStream_t early_stream = nullptr;               // the stream of the launch that writes early_ptr
+    unsigned long long early_version = 0;
+    int last_finalised = 0;                           // the last launch finalised its tiles itself (diagnostics, option "last_finalised")
     hipEvent_t ev_main = nullptr;                     // main-stream work a render must see (uploads, resets, ...)
     bool main_dirty = true;
     int flip = 0;
@@ -202,6 +221,13 @@ struct mpt_ctx {
     size_t partial2_cap[MPT_MAX_PIPE] = {};           // float4 elements per buffer
     float *sP2[MPT_MAX_PIPE] = {};
     unsigned int *d_work2[MPT_MAX_PIPE] = {};
+
+    // 8-wide octant-ordered tree (oct_build.cpp, render_kernel_oct): option "wide8" = 1 builds and walks it for scenes that do
+    // not fit LDS; onode [oct_nodes][5], the triangle records in its leaf order (tfast8 / tshade8), d_perm8 [n]: t8 -> leaf slot
+    int use_wide8 = 0;
+    MptVec4 *onode = nullptr; size_t onode_cap = 0;
+    MptVec4 *tfast8 = nullptr, *tshade8 = nullptr; int32_t *d_perm8 = nullptr; size_t tri8_cap = 0;
+    int oct_nodes = 0, oct_depth = 0;
 
     // measurement
     int timeline = 0;                    // 1: the LDS kernel records per-wave timestamps of its last launch

@@ -111,6 +111,7 @@ struct MptRenderParams {
     const MptVec4 *fnode;
     const MptVec4 *wnode;                    // 4-wide traversal nodes (scenes that do not fit LDS), or null
     const MptVec4 *qnode;                    // the same nodes with the child boxes quantised to 8 bits (64-B records), or null
+    const MptVec4 *onode;                    // 8-wide octant-ordered nodes (80-B records, oct_build.cpp), or null; tfast / tshade then hold the records in ITS leaf order
     const MptVec4 *tgeo;
     const MptVec4 *tshade;
     const MptVec4 *tfast;                    // production build: 48-byte triangle records {n, v0.x}{a, v0.y}{c, v0.z} derived from tgeo
@@ -127,6 +128,15 @@ struct MptRenderParams {
     unsigned int *work_counter;              // persistent kernels: 8 per-range item counters
     int *stack_spill;                        // wide kernel: the overflow stack entries (128 - the LDS levels) of every lane of the grid
     unsigned int *watchdog;                  // host-pinned flag a persistent wave raises when it gives up
+    // Tail finalisation (fast build): a wave that has run out of work sums, resolves and writes out the tiles
+    // whose samples are all in the slab, while other waves still drain their last paths.  fin_counter: the next tile to
+    // finalise (zeroed with the queue heads), null = the combine pass does it after the launch; slab_tag: the w every sample
+    // of THIS launch is stored with (the ready flag of its 16-byte slab entry; 1 when fin_counter is null); image_out: where the
+    // resolved pixel goes as well (FilmTable.get_image's array, device-visible), or null
+    unsigned int *fin_counter;
+    MptVec4 *image_out;
+    float slab_tag;
+    int32_t pad3;
     unsigned long long *timeline;            // diagnostics: per wave {start, scene ready, queue empty, exit} in
                                              // 100 MHz ticks, or null
 };

@@ -260,7 +260,7 @@ struct Stack {
 // scene records served from HBM/L2 through the vector L1 (any scene size)
 struct GlobalScene {
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
-    static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false;
+    static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
     const MptVec4 *fnode, *tgeo;
     int soa_n;                 // node count, for the layout A/B build below
     DEV void node(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &d) const {
@@ -285,7 +285,7 @@ struct GlobalScene {
 // bought 3-7 %)
 struct WideScene {
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
-    static constexpr bool WIDE = true, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false;
+    static constexpr bool WIDE = true, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
     const MptVec4 *wnode, *tgeo;
     // entry (n*) and exit (f*) planes of the four children, picked by the ray's direction signs: o* is 0 for a ray
     // going up the axis and 16 (bytes: the next float4) for one going down -- still seven dwordx4 gathers
@@ -335,7 +335,7 @@ struct WideScene {
 // at 34-43 % issue utilisation.
 struct QuantScene {
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
-    static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false;
+    static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
     const MptVec4 *qnode, *tgeo;
     DEV void node4q(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &id) const {
         const char *base = (const char *)qnode;
@@ -390,6 +390,57 @@ struct SpillStack {
     DEV int peek(int) const { return 0; }
 };
 
+// 8-wide nodes with octant-ordered child slots and 8-bit boxes (oct_build.cpp): 80-byte records, FIVE 16-B gathers per step for
+// eight box tests; the order the children are met in is slot XOR the ray's direction octant -- no sort -- and a node leaves at most
+// two stack entries behind (its other internal hits, its other leaf hits), each a (base | mask, slots to go) pair
+struct OctScene {
+    static constexpr int SHADE_MIN = 0;
+    static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false, OCT = true;
+    const MptVec4 *onode, *tgeo;                       // tgeo: tfast8, the 48-byte records in the 8-wide tree's leaf order
+    DEV void node8(int i, MptVec4 &h0, MptVec4 &h1, MptVec4 &px, MptVec4 &py, MptVec4 &pz) const {
+        const char *base = (const char *)onode;
+        const unsigned o = (unsigned)i * 80u;            // (the host keeps the array below 2 GiB)
+        h0 = *(const MptVec4 *)(base + o); h1 = *(const MptVec4 *)(base + 16 + o);
+        px = *(const MptVec4 *)(base + 32 + o); py = *(const MptVec4 *)(base + 48 + o); pz = *(const MptVec4 *)(base + 64 + o);
+    }
+    DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2) const {
+        const MptVec4 *g = tgeo + (size_t)slot * 3;
+        g0 = g[0]; g1 = g[1]; g2 = g[2];
+    }
+};
+
+// LIFO of the 8-wide traversal: entries are PAIRS (a, b) -- a = first child or triangle | mask of the node's slots of that kind
+// << 24, b = the slots still to visit (internal: in met-order positions; leaves: bit 31 set) -- two words per level in LDS,
+// [level][lane] each, the (rare) levels beyond CAP in a per-lane strip of global memory like SpillStack's
+struct OctStack {
+    static constexpr int SENTINEL = 0x40000000;        // the b word of the bottom entry: traversal over
+    static constexpr int PLANE_OFF = 0;
+    static constexpr bool PEEK = false;
+#ifndef MPT_OCT_CAP
+#define MPT_OCT_CAP 14
+#endif
+    static constexpr int CAP = MPT_OCT_CAP, SPILL = 64 - CAP;   // 2 x 14 levels x 256 lanes x 4 B = 28 KiB of LDS: five workgroups per CU
+    int *base;                 // &lds[threadIdx.x]
+    int *spill;
+    unsigned lane_off;         // this lane's first word in the strips (2 x SPILL words per lane)
+    int sp;
+    DEV void put(int at, int a, int b) {
+        if (at < CAP) { base[at * MPT_BLOCK] = a; base[(CAP + at) * MPT_BLOCK] = b; }
+        else { spill[lane_off + 2u * (unsigned)(at - CAP)] = a; spill[lane_off + 2u * (unsigned)(at - CAP) + 1u] = b; }
+    }
+    DEV void get(int at, int &a, int &b) const {
+        if (at < CAP) { a = base[at * MPT_BLOCK]; b = base[(CAP + at) * MPT_BLOCK]; }
+        else { a = spill[lane_off + 2u * (unsigned)(at - CAP)]; b = spill[lane_off + 2u * (unsigned)(at - CAP) + 1u]; }
+    }
+    DEV void setb(int at, int b) {
+        if (at < CAP) base[(CAP + at) * MPT_BLOCK] = b;
+        else spill[lane_off + 2u * (unsigned)(at - CAP) + 1u] = b;
+    }
+    DEV void push(int v) { put(sp, 0, v); sp++; }      // (lane_start_ray: the sentinel)
+    DEV int pop() { sp--; return 0; }
+    DEV int peek(int) const { return 0; }
+};
+
 // scene records resident in the CU's LDS (small scenes): ds_read_b128 instead of divergent
 // global gathers -- one copy per CU, shared by the 16 waves of a 1024-lane workgroup
 typedef float mpt_f4 __attribute__((ext_vector_type(4)));
@@ -410,7 +461,7 @@ struct LdsScene {
 #define MPT_SHADE_MIN_LDS 24
 #endif
     static constexpr int SHADE_MIN = MPT_SHADE_MIN_LDS; // SHADE waits until this many lanes want it (render_kernel.hip trace_stream)
-    static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = true, LDS_MATS = true;
+    static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = true, LDS_MATS = true, OCT = false;
     LdsVec4Ptr fnode, tgeo;
     // The material records (parameters + derived terms, 96 B each, the default material last) and one byte per
     // leaf slot naming the record: SHADE reads its material out of LDS while the shading record of the triangle is

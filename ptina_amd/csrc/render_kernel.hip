@@ -24,6 +24,7 @@
 //   one 16x16 tile per workgroup, blockIdx remapped so an XCD's blocks cover a contiguous run of tiles.
 
 #include "pt_device.h"
+#include "film_ops.h"
 #include <atomic>
 
 #ifndef MPT_SPEC_POP
@@ -292,6 +293,36 @@ DEV void lane_draws(const MptRenderParams &p, LaneState &L, float *out) {
     }
 }
 
+// One sample's radiance into the launch's slab, path.py:93 (the combine pass or the tail finalisation adds the frames in order).
+// The entry's w is the launch's tag: with the tail finalisation on, the 16 bytes are stored write-through (sc1: they leave this
+// XCD's L2 at once, where a finishing wave of any other XCD can see them) and the tag says that they have arrived -- the data is
+// the flag, one store, nothing to order (MI355X_MICROARCH.md, visibility: R2 granules; 16-B sc1 stores observed untorn).
+// Inline asm, because the builtin that takes cache bits wants a buffer descriptor (four more scalar registers held through the
+// traversal loop); the compiler does not count this store in its vmcnt bookkeeping, which only makes its own waits stricter.
+// (Every launch stores that way, finalising or not: a 16-byte sc1 store costs what a plain one does, and a wave-uniform choice
+//  between the two in the shading pass cost the whole kernel 4 % -- the pass is short of scalar registers.)
+#ifndef MPT_SC1_STORES
+#define MPT_SC1_STORES 1      // 0: plain stores (A/B; the tail finalisation must then stay off)
+#endif
+DEV void store_sample(const MptRenderParams &p, int frame, int pix, V3 radiance) {
+    MptVec4 *dst = p.partial + ((size_t)frame * (size_t)p.partial_stride + pix);
+#if MPT_SC1_STORES == 1
+    mpt_f4 v = { radiance.x, radiance.y, radiance.z, p.slab_tag };
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+#elif MPT_SC1_STORES == 2     // (A/B: the round-4 first attempt, a wave-uniform choice)
+    if (p.fin_counter) {
+        mpt_f4 v = { radiance.x, radiance.y, radiance.z, p.slab_tag };
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+        return;
+    }
+    MptVec4 o; o.x = radiance.x; o.y = radiance.y; o.z = radiance.z; o.w = p.slab_tag;
+    *dst = o;
+#else
+    MptVec4 o; o.x = radiance.x; o.y = radiance.y; o.z = radiance.z; o.w = p.slab_tag;
+    *dst = o;
+#endif
+}
+
 // the bottom entry of every ray's LIFO is a sentinel, so "pop" never needs an emptiness test:
 // popping the sentinel means the traversal is over
 template <class STACK>
@@ -330,8 +361,7 @@ DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, STACK &stk, V3
         // lbvh.py:218,319: with fewer than two faces the root box is never written: no hit
         if (p.n < 2) L.st = ST_DONE;
     } else {
-        MptVec4 o; o.x = L.result.x; o.y = L.result.y; o.z = L.result.z; o.w = 1.0f;
-        p.partial[(size_t)L.frame * (size_t)p.partial_stride + L.pix] = o;   // path.py:93, summed by combine
+        store_sample(p, L.frame, L.pix, L.result);                          // path.py:93, summed by combine
         L.st = ST_NEW;
     }
 }
@@ -339,8 +369,7 @@ DEV void lane_next_bounce(const MptRenderParams &p, LaneState &L, STACK &stk, V3
 // The loop head alone (path.py:25): a lane about to bounce whose path is over stores its sample and waits for a new one
 DEV bool path_continues(const LaneState &L) { return L.depth < 5 && any_gt0(L.throughput) && any_ne0(L.prd); }
 DEV void lane_store_sample(const MptRenderParams &p, LaneState &L) {
-    MptVec4 o; o.x = L.result.x; o.y = L.result.y; o.z = L.result.z; o.w = 1.0f;
-    p.partial[(size_t)L.frame * (size_t)p.partial_stride + L.pix] = o;       // path.py:93, summed by combine
+    store_sample(p, L.frame, L.pix, L.result);                              // path.py:93, summed by combine
     L.st = ST_NEW;
 }
 // The one place of a shading pass where rays start (MPT_ONE_START): the lanes whose shadow ray just ended, the lanes that
@@ -506,6 +535,128 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     }
     L.curr = next;
     L.st = classify<STACK>(next);
+}
+
+// ---- the 8-wide, octant-ordered tree (OctScene / OctStack; oct_build.cpp)
+// The ray's direction octant: bit a set = the ray goes DOWN axis a.  A child slot's bit a set = the child lies on the high side of
+// the node's centre along a, so slot ^ octant, ascending, is the order the ray meets the children in (nearest first).
+DEV unsigned ray_octant(const LaneState &L) {
+    return ((unsigned)__float_as_int(L.inv.x) >> 31) | (((unsigned)__float_as_int(L.inv.y) >> 31) << 1) | (((unsigned)__float_as_int(L.inv.z) >> 31) << 2);
+}
+// bit i of an 8-bit mask to bit i ^ r: three conditional delta swaps
+DEV unsigned oct_permute(unsigned m, unsigned r) {
+    const unsigned m1 = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+    m = (r & 1u) ? m1 : m;
+    const unsigned m2 = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+    m = (r & 2u) ? m2 : m;
+    const unsigned m4 = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    return (r & 4u) ? m4 : m;
+}
+// the next thing to do is on top of the stack: a leaf group (b < 0: the lowest slot left names the next triangle), a group of
+// internal children (the lowest MET-ORDER position left names the next node) or the sentinel
+template <class STACK>
+DEV void oct_next(STACK &stk, LaneState &L, unsigned r) {
+    int a, b;
+    const int top = L.sp - 1;
+    stk.get(top, a, b);
+    if (b & STACK::SENTINEL) { L.st = ST_DONE; return; }
+    const bool leaf = b < 0;
+    const unsigned bits = (unsigned)b & 0xffu;
+    const int pos = __builtin_ctz(bits | 0x100u);
+    const unsigned slot = leaf ? (unsigned)pos : ((unsigned)pos ^ r);
+    const int idx = (a & 0xffffff) + __builtin_popcount(((unsigned)a >> 24) & ((1u << slot) - 1u));
+    const unsigned rest = bits & (bits - 1u);
+    if (rest) stk.setb(top, (int)(((unsigned)b & 0x80000000u) | rest));
+    else L.sp = top;
+    L.curr = leaf ? ~idx : idx;
+    L.st = leaf ? ST_LEAF : ST_NODE;
+}
+
+template <bool COUNT, class SCENE, class STACK>
+DEV void stage_node8(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
+    if (COUNT) { cnt.n_node++; cnt.n_box += 8; }
+    MptVec4 h0, h1, px, py, pz;
+    sc.node8(L.curr, h0, h1, px, py, pz);
+    // plane = origin + byte * scale: its distance along the ray is byte * (scale * inv) + (origin * inv - o * inv)
+    const float sx = h0.w * L.inv.x, sy = h1.x * L.inv.y, sz = h1.y * L.inv.z;
+    const float bx = __builtin_fmaf(h0.x, L.inv.x, -L.oinv.x), by = __builtin_fmaf(h0.y, L.inv.y, -L.oinv.y),
+                bz = __builtin_fmaf(h0.z, L.inv.z, -L.oinv.z);
+    const int a_node = __float_as_int(h1.z), a_tri = __float_as_int(h1.w);
+    const unsigned imask = (unsigned)a_node >> 24, lmask = (unsigned)a_tri >> 24;
+    const unsigned r = ray_octant(L);
+    const bool dnx = (r & 1u) != 0, dny = (r & 2u) != 0, dnz = (r & 4u) != 0;
+    // entry planes: the low ones for a ray going up the axis, the high ones for one going down ({lo[0..3], lo[4..7], hi[0..3], hi[4..7]})
+    const unsigned lx0 = (unsigned)__float_as_int(px.x), lx1 = (unsigned)__float_as_int(px.y), hx0 = (unsigned)__float_as_int(px.z), hx1 = (unsigned)__float_as_int(px.w);
+    const unsigned ly0 = (unsigned)__float_as_int(py.x), ly1 = (unsigned)__float_as_int(py.y), hy0 = (unsigned)__float_as_int(py.z), hy1 = (unsigned)__float_as_int(py.w);
+    const unsigned lz0 = (unsigned)__float_as_int(pz.x), lz1 = (unsigned)__float_as_int(pz.y), hz0 = (unsigned)__float_as_int(pz.z), hz1 = (unsigned)__float_as_int(pz.w);
+    const unsigned nx0 = dnx ? hx0 : lx0, nx1 = dnx ? hx1 : lx1, fx0 = dnx ? lx0 : hx0, fx1 = dnx ? lx1 : hx1;
+    const unsigned ny0 = dny ? hy0 : ly0, ny1 = dny ? hy1 : ly1, fy0 = dny ? ly0 : hy0, fy1 = dny ? ly1 : hy1;
+    const unsigned nz0 = dnz ? hz0 : lz0, nz1 = dnz ? hz1 : lz1, fz0 = dnz ? lz0 : hz0, fz1 = dnz ? lz1 : hz1;
+    unsigned hits = 0u;
+#define MPT_UB(w, c) ((float)(((w) >> (8 * (c))) & 0xffu))
+#define MPT_OSLAB(c, nxw, nyw, nzw, fxw, fyw, fzw, bit)                                                                \
+    {                                                                                                                  \
+        const float tn = fmaxf(fmaxf(__builtin_fmaf(MPT_UB(nxw, c), sx, bx), __builtin_fmaf(MPT_UB(nyw, c), sy, by)),  \
+                               fmaxf(__builtin_fmaf(MPT_UB(nzw, c), sz, bz), 0.0f));                                   \
+        const float tf = fminf(fminf(__builtin_fmaf(MPT_UB(fxw, c), sx, bx), __builtin_fmaf(MPT_UB(fyw, c), sy, by)),  \
+                               fminf(__builtin_fmaf(MPT_UB(fzw, c), sz, bz), L.tbest));                                \
+        hits |= tn <= tf ? (1u << (bit)) : 0u;                                                                         \
+    }
+    MPT_OSLAB(0, nx0, ny0, nz0, fx0, fy0, fz0, 0) MPT_OSLAB(1, nx0, ny0, nz0, fx0, fy0, fz0, 1)
+    MPT_OSLAB(2, nx0, ny0, nz0, fx0, fy0, fz0, 2) MPT_OSLAB(3, nx0, ny0, nz0, fx0, fy0, fz0, 3)
+    MPT_OSLAB(0, nx1, ny1, nz1, fx1, fy1, fz1, 4) MPT_OSLAB(1, nx1, ny1, nz1, fx1, fy1, fz1, 5)
+    MPT_OSLAB(2, nx1, ny1, nz1, fx1, fy1, fz1, 6) MPT_OSLAB(3, nx1, ny1, nz1, fx1, fy1, fz1, 7)
+#undef MPT_OSLAB
+#undef MPT_UB
+    // (an empty slot's box is inverted -- lo 255, hi 0 -- and never hit)
+    const unsigned lh = hits & lmask;                          // leaf hits, by slot: their order does not matter much, all are tested
+    const unsigned pih = oct_permute(hits & imask, r);         // internal hits, by the position the ray meets them in
+    // leaves first (they can only shorten the ray), then the nearest internal child; what is left of either kind goes to the stack
+    const bool take_leaf = lh != 0u;
+    const unsigned sel = take_leaf ? lh : pih;
+    const int pos = __builtin_ctz(sel | 0x100u);
+    const unsigned rest = sel & (sel - 1u);
+    const unsigned slot = take_leaf ? (unsigned)pos : ((unsigned)pos ^ r);
+    const int a_sel = take_leaf ? a_tri : a_node;
+    const int idx = (a_sel & 0xffffff) + __builtin_popcount(((unsigned)a_sel >> 24) & ((1u << slot) - 1u));
+    int sp = L.sp;
+    if (__ballot(sp > STACK::CAP - 2) == 0ull) {
+        // nobody near the end of the LDS part: plain stores at a running index (a store that is not wanted lands on the level the
+        // next one overwrites, or on the free level above the top)
+        stk.base[sp * MPT_BLOCK] = a_node; stk.base[(STACK::CAP + sp) * MPT_BLOCK] = (int)pih;
+        sp += (take_leaf && pih != 0u) ? 1 : 0;
+        stk.base[sp * MPT_BLOCK] = a_sel; stk.base[(STACK::CAP + sp) * MPT_BLOCK] = (int)(rest | (take_leaf ? 0x80000000u : 0u));
+        sp += rest != 0u ? 1 : 0;
+    } else {
+        if (take_leaf && pih != 0u) { stk.put(sp, a_node, (int)pih); sp++; }
+        if (rest != 0u) { stk.put(sp, a_sel, (int)(rest | (take_leaf ? 0x80000000u : 0u))); sp++; }
+    }
+    L.sp = sp;
+    if (sel != 0u) {
+        L.curr = take_leaf ? ~idx : idx;
+        L.st = take_leaf ? ST_LEAF : ST_NODE;
+    } else oct_next(stk, L, r);
+}
+
+template <bool COUNT, class SCENE, class STACK>
+DEV void stage_leaf8(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
+    const int slot = ~L.curr;                                  // (a t8 index: the triangle's place in the 8-wide tree's leaf order)
+    bool stop = false;
+    if (COUNT) cnt.n_tri++;
+    if (L.curr != L.navoid) {                                  // the triangle the ray left from is never tested (lbvh.py:329)
+        MptVec4 g0, g1, g2;
+        sc.tri(slot, g0, g1, g2);
+        float dd, su, sv;
+        if (tri_test_fast(g0, g1, g2, L.to, L.td, &dd, &su, &sv)) {
+            if (L.shadow) {
+                if (dd <= L.tbest) { L.hidx = slot; stop = true; }              // path.py:51: any occluder within li.dis
+            } else if (dd < L.tbest) {                                          // lbvh.py:331
+                L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv;
+            }
+        }
+    }
+    if (stop) L.st = ST_DONE;
+    else oct_next(stk, L, ray_octant(L));
 }
 
 template <bool COUNT, class SCENE, class STACK>
@@ -700,6 +851,13 @@ DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(by
 #define MPT_STAMP_BEGIN
 #define MPT_STAMP_END(acc)
 #endif
+// A/B (MPT_X_TAIL_PRIO / MPT_X_WAVE_PRIO): user priority by the wave's age within its SIMD (the instruction takes a literal)
+DEV void set_prio_by_age() {
+    const int age = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) & 3;
+    if (age == 1) __builtin_amdgcn_s_setprio(1);
+    else if (age == 2) __builtin_amdgcn_s_setprio(2);
+    else if (age == 3) __builtin_amdgcn_s_setprio(3);
+}
 DEV int wave_count(bool pred) { return (int)__builtin_popcountll(__ballot(pred)); }
 DEV int wave_count32(bool pred) {            // the same in two 32-bit halves: stays on the scalar unit when compared
     unsigned long long m = __ballot(pred);
@@ -751,6 +909,12 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     unsigned long long acc_node = 0, acc_leaf = 0, acc_sdone = 0, acc_shade = 0, acc_new = 0;
     const unsigned long long stamp_start = __builtin_amdgcn_s_memtime();
 #endif
+#if MPT_X_WAVE_PRIO
+    set_prio_by_age();     // A/B: the same for the whole launch
+#endif
+#if MPT_X_FIN_PRIO
+    __builtin_amdgcn_s_setprio(MPT_X_FIN_PRIO);
+#endif
     LaneState L;
     L.st = ST_NEW;
     L.sp = 0; L.curr = 0; L.shadow = 0;
@@ -784,7 +948,8 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             if (cn * MPT_PREF_NODE >= cl * MPT_PREF_LEAF) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
                 if (L.st == ST_NODE) {
-                    if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
+                    if constexpr (SCENE::OCT) stage_node8<COUNT>(sc, stk, L, cnt);
+                    else if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
                     else stage_node<COUNT>(sc, stk, L, cnt);
                 }
 #if MPT_NODE_REP
@@ -812,13 +977,19 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 MPT_STAMP_END(acc_node)
             } else {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
-                if (L.st == ST_LEAF) stage_leaf<COUNT>(sc, stk, L, cnt);
+                if (L.st == ST_LEAF) {
+                    if constexpr (SCENE::OCT) stage_leaf8<COUNT>(sc, stk, L, cnt);
+                    else stage_leaf<COUNT>(sc, stk, L, cnt);
+                }
 #if MPT_LEAF_REP
 #pragma unroll
                 for (int rep = 0; rep < MPT_LEAF_REP; rep++) {
                     if (__ballot(L.st == ST_LEAF) == 0ull) break;
                     if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
-                    if (L.st == ST_LEAF) stage_leaf<COUNT>(sc, stk, L, cnt);
+                    if (L.st == ST_LEAF) {
+                        if constexpr (SCENE::OCT) stage_leaf8<COUNT>(sc, stk, L, cnt);
+                        else stage_leaf<COUNT>(sc, stk, L, cnt);
+                    }
                 }
 #endif
                 MPT_STAMP_END(acc_leaf)
@@ -882,6 +1053,12 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 int item = wq.pull();               // while the other lanes are still busy (no per-item tail)
                 if (item < 0) {
                     more = false;
+#if MPT_X_TAIL_PRIO
+                    // A/B: the hardware issues the oldest wave of a SIMD first (waves 0-3 of a 1024-lane workgroup trace 39 items
+                    // per launch, waves 12-15 23: profiles/r04_timeline2.json); once the queues are dry the younger waves, which are
+                    // the last to finish, get the higher user priority
+                    set_prio_by_age();
+#endif
                     if (tl && (threadIdx.x & 63) == 0) {
                         tl[2] = wall_clock64();
 #if MPT_X_TIMELINE2
@@ -968,6 +1145,148 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     }
 #endif
 }
+
+// ---------------------------------------------------------------- tail finalisation
+// A launch ends with a drain: the queues are dry, waves finish their last paths and leave one by one (a third of a millisecond
+// on the benchmark film), and only then could the combine pass, the resolve pass and the read-back start -- 0.14 ms more per
+// step.  With p.fin_counter set, a wave that has nothing left to trace turns to the film instead: it takes the next tile of the
+// share (tiles finish in the order their items were issued, so all but the last few are complete), waits until every sample of
+// it carries this launch's tag, adds the frames to the film in frame order (film_ops.h: the combine pass's arithmetic), and writes
+// the resolved pixels to the caller's image as well when the host knows where get_image() will want them.  The slab entries were
+// stored write-through (store_sample) and are read here with sc1 loads (L1 bypassed, re-read every pass: R2 of the guide).
+// Nothing waits for a finishing wave, and what IT waits for is in the hands of waves that are running (every item has been pulled
+// before the first wave gets here), so the loop ends; a bounded spin raises the watchdog instead of hanging if it ever does not.
+typedef unsigned int mpt_u4 __attribute__((ext_vector_type(4)));
+DEV mpt_u4 slab_load_sc1(const MptVec4 *frame_base, unsigned frame_bytes, unsigned byte_off) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)frame_base, (short)0, (int)frame_bytes, 0x00020000);
+#ifndef MPT_FIN_AUX
+#define MPT_FIN_AUX 16       // cache bits of the slab loads: 16 = sc1 (A/B: 18 = sc1 nt)
+#endif
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, MPT_FIN_AUX);      // aux 16 = sc1
+}
+
+#ifndef MPT_FIN_SLEEP
+#define MPT_FIN_SLEEP 32     // units of 64 cycles between two looks at a tile that is not complete yet
+#endif
+#ifndef MPT_FIN_GROUP_LDS
+#define MPT_FIN_GROUP_LDS 8       // slab loads in flight per lane: the LDS-resident kernel has 128 VGPRs to lend ...
+#define MPT_FIN_GROUP_GATHER 6    // ... the gather kernels 96 (with eight the function needs 102 and they would lose their fifth wave per SIMD)
+#endif
+#ifndef MPT_FIN_INLINE
+// 0: out of line.  Inlined into the render kernels the finalisation moved their register allocation and the traversal loop ran
+// 3 % slower (MI355X, same box: 3.21 against 3.13 ms per launch, profiles/r04_ab_experiments.json); as a function of its own it
+// leaves them alone, at the price of its registers counting for every kernel that calls it (MPT_FIN_GROUP_*).
+#define MPT_FIN_INLINE 0
+#endif
+// what finalise_tiles reads of the launch parameters.  Out of line, its arguments arrive in vector registers: the ones a buffer
+// descriptor is made of are made scalar again (readfirstlane; they are wave-uniform)
+struct FinArgs {
+    MptVec4 *partial, *film0, *image_out;
+    unsigned int *fin_counter, *watchdog;
+    int tile_w_shift, tile_h_shift, ny, nitems, nchunks, nframes, partial_stride, stripe_w, stripe_pitch, x0, x1;
+    float slab_tag;
+};
+DEV int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> DEV T *uniform_p(T *ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+// (individual parameters, not a struct by value: that one would travel through scratch memory)
+template <int GROUP>
+#if MPT_FIN_INLINE
+DEV int finalise_tiles_impl(
+#else
+__device__ __attribute__((noinline)) int finalise_tiles_impl(
+#endif
+        MptVec4 *a_partial, MptVec4 *a_film0, MptVec4 *a_image_out, unsigned int *a_fin_counter, unsigned int *a_watchdog,
+        int a_tws, int a_ths, int a_ny, int a_nitems, int a_nchunks, int a_nframes, int a_partial_stride, int a_stripe_w,
+        int a_stripe_pitch, int a_x0, int a_x1, float a_slab_tag) {
+    FinArgs p;
+    p.partial = a_partial; p.film0 = a_film0; p.image_out = a_image_out; p.fin_counter = a_fin_counter; p.watchdog = a_watchdog;
+    p.tile_w_shift = a_tws; p.tile_h_shift = a_ths; p.ny = a_ny; p.nitems = a_nitems; p.nchunks = a_nchunks; p.nframes = a_nframes;
+    p.partial_stride = a_partial_stride; p.stripe_w = a_stripe_w; p.stripe_pitch = a_stripe_pitch; p.x0 = a_x0; p.x1 = a_x1;
+    p.slab_tag = a_slab_tag;
+#if !MPT_FIN_INLINE
+    p.partial = uniform_p(p.partial); p.partial_stride = uniform_i(p.partial_stride); p.nframes = uniform_i(p.nframes);
+    p.tile_w_shift = uniform_i(p.tile_w_shift); p.tile_h_shift = uniform_i(p.tile_h_shift);
+#endif
+    const int lane = threadIdx.x & 63;
+    const int tws = p.tile_w_shift, ths = p.tile_h_shift, tps = tws + ths;
+    const int t8y = (p.ny + (1 << ths) - 1) >> ths;
+    const int ntile = p.nitems / p.nchunks;                 // items are tile-major: nchunks per tile
+    const int B = p.nframes;
+    const unsigned frame_bytes = (unsigned)p.partial_stride * 16u;      // (a frame of the slab is far below 4 GiB: the film's cap is 2^26 pixels)
+    const unsigned tag = (unsigned)__float_as_int(p.slab_tag);
+    const unsigned long long t_begin = wall_clock64();
+    int done = 0;
+    for (;; done++) {
+        int t = 0;
+        if (lane == 0) t = (int)atomicAdd(p.fin_counter, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= ntile) break;
+        const int tx = t / t8y, ty = t - tx * t8y;
+        const int tps_x = p.stripe_w >> tws, st = tx / tps_x;            // stripe of this tile column (as in trace_stream)
+        const int ti = p.x0 + st * p.stripe_pitch + ((tx - st * tps_x) << tws), tj = ty << ths;
+        for (int q0 = 0; q0 < (1 << tps); q0 += 64) {                    // (wave-uniform trip count)
+            const int q = q0 + lane;
+            const int i = ti + (q >> ths), j = tj + (q & ((1 << ths) - 1));
+            const bool inside = q < (1 << tps) && i < p.x1 && j < p.ny;  // (pixels of the tile past the film's edge get no samples)
+            const unsigned off = (unsigned)(((tx << tws) + (q >> ths)) * p.ny + (tj + (q & ((1 << ths) - 1)))) * 16u;
+            const size_t pix = (size_t)i * p.ny + j;
+            MptVec4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+            if (inside) acc = p.film0[pix];
+            for (int f0 = 0; f0 < B; f0 += GROUP) {
+                mpt_u4 v[GROUP];
+                for (;;) {
+                    bool ready = true;
+#pragma unroll
+                    for (int k = 0; k < GROUP; k++) {
+                        v[k] = mpt_u4{ 0u, 0u, 0u, tag };
+                        if (f0 + k < B && inside) v[k] = slab_load_sc1(p.partial + (size_t)(f0 + k) * (size_t)p.partial_stride, frame_bytes, off);
+                        ready = ready && v[k].w == tag;
+                    }
+                    if (__ballot(!ready) == 0ull) break;
+                    if (wall_clock64() - t_begin > 400000000ull) {       // 4 s at 100 MHz: some sample never came
+                        if (lane == 0) __hip_atomic_store(p.watchdog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        return done;
+                    }
+                    __builtin_amdgcn_s_sleep(MPT_FIN_SLEEP);
+                }
+#pragma unroll
+                for (int k = 0; k < GROUP; k++)
+                    if (f0 + k < B) film_add_sample(acc, __uint_as_float(v[k].x), __uint_as_float(v[k].y), __uint_as_float(v[k].z));
+            }
+            if (inside) {
+                p.film0[pix] = acc;
+                if (p.image_out) p.image_out[pix] = film_resolve(acc);
+            }
+        }
+    }
+    return done;
+}
+
+// GROUP = slab loads in flight per lane: what the calling kernel's register budget allows (see MPT_FIN_INLINE)
+template <int GROUP>
+DEV int finalise_tiles(const MptRenderParams &p) {
+#if MPT_FIN_INLINE >= 0          // (-1: A/B build without the call: the render kernels as they were before the tail finalisation)
+#if MPT_X_FIN_PRIO
+    __builtin_amdgcn_s_setprio(0);       // A/B: the waves still tracing (priority MPT_X_FIN_PRIO, set in trace_stream) issue first
+#endif
+    // In a workgroup of three or four waves per SIMD only the younger two finalise.  The hardware issues the oldest wave of a
+    // SIMD first, so the old waves finish tracing first -- and, finalising, stayed in front of the waves still tracing behind
+    // them: with all four at it the launch took 3.15 ms, with the younger two 3.12 (the combine pass after the launch: 3.10 + 0.1;
+    // MI355X, same box, profiles/r04_ab_experiments.json).  Every tile is still taken by somebody: the loop runs until none is left.
+#ifndef MPT_FIN_YOUNG
+#define MPT_FIN_YOUNG 2
+#endif
+    if ((blockDim.x >> 8) >= 3 && (int)((threadIdx.x >> 8) & 3) < MPT_FIN_YOUNG) return 0;
+    if (p.fin_counter)
+        return finalise_tiles_impl<GROUP>(p.partial, p.film0, p.image_out, p.fin_counter, p.watchdog, p.tile_w_shift, p.tile_h_shift, p.ny,
+                                          p.nitems, p.nchunks, p.nframes, p.partial_stride, p.stripe_w, p.stripe_pitch, p.x0, p.x1, p.slab_tag);
+#endif
+    return 0;
+}
 #endif
 
 // ---------------------------------------------------------------- gather kernel: 16x16 tile x chunk per workgroup
@@ -1002,6 +1321,7 @@ __global__ MPT_RENDER_BOUNDS void MPT_SUFFIX(render_kernel)(const MptRenderParam
     // persistent workgroups pulling (8x8 tile, chunk) items; see WorkQueue
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
     trace_stream<COUNT>(p, tr.sc, tr.st, wq, cnt);
+    finalise_tiles<MPT_FIN_GROUP_GATHER>(p);
 #endif
     flush_counters<COUNT>(p, cnt);
 }
@@ -1031,6 +1351,24 @@ __global__ __launch_bounds__(MPT_BLOCK, MPT_WIDE_WAVES) void render_kernel_wide(
         WideScene sc; sc.wnode = p.wnode; sc.tgeo = p.tfast;
         trace_stream<COUNT>(p, sc, stk, wq, cnt);
     }
+    finalise_tiles<MPT_FIN_GROUP_GATHER>(p);
+    flush_counters<COUNT>(p, cnt);
+}
+
+// ---------------------------------------------------------------- gather kernel over 8-wide octant-ordered nodes (option "wide8")
+template <bool COUNT>
+__global__ __launch_bounds__(MPT_BLOCK, MPT_WIDE_WAVES) void render_kernel_oct(const MptRenderParams p) {
+    __shared__ int s_stack[2 * OctStack::CAP * MPT_BLOCK];
+    OctStack stk;
+    stk.base = s_stack + threadIdx.x;
+    stk.spill = p.stack_spill;
+    stk.lane_off = (blockIdx.x * MPT_BLOCK + threadIdx.x) * (unsigned)(2 * OctStack::SPILL);
+    stk.sp = 0;
+    Cnt cnt = {};
+    WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
+    OctScene sc; sc.onode = p.onode; sc.tgeo = p.tfast;
+    trace_stream<COUNT>(p, sc, stk, wq, cnt);
+    finalise_tiles<MPT_FIN_GROUP_GATHER>(p);
     flush_counters<COUNT>(p, cnt);
 }
 
@@ -1079,6 +1417,10 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
     trace_stream<COUNT>(p, sc, stk, wq, cnt, tl);
     if (tl && (threadIdx.x & 63) == 0) tl[3] = wall_clock64();
+    const int fin_tiles = finalise_tiles<MPT_FIN_GROUP_LDS>(p);
+#if !MPT_X_TIMELINE2
+    if (tl && (threadIdx.x & 63) == 0) { tl[4] = wall_clock64(); tl[5] = (unsigned long long)fin_tiles; }   // left the finalisation; tiles it did
+#endif
     flush_counters<COUNT>(p, cnt);
 }
 #endif
@@ -1225,6 +1567,25 @@ MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int quant, int *b
     }
     *blocks = grid * occ;
     return hipSuccess;
+}
+
+MPT_KERNEL_API hipError_t mpt_oct_blocks(int grid, int count, int *blocks) {
+    static std::atomic<int> occ_cache[MPT_MAX_DEVICES][2];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MPT_MAX_DEVICES) return hipErrorInvalidDevice;
+    int occ = occ_cache[dev][count ? 1 : 0].load(std::memory_order_relaxed);
+    if (!occ) {
+        occ = count ? blocks_per_cu(render_kernel_oct<true>) : blocks_per_cu(render_kernel_oct<false>);
+        occ_cache[dev][count ? 1 : 0].store(occ, std::memory_order_relaxed);
+    }
+    *blocks = grid * occ;
+    return hipSuccess;
+}
+
+MPT_KERNEL_API hipError_t mpt_launch_render_oct(const MptRenderParams *p, int blocks, int count, hipStream_t stream) {
+    if (count) hipLaunchKernelGGL((render_kernel_oct<true>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
+    else hipLaunchKernelGGL((render_kernel_oct<false>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
+    return hipGetLastError();
 }
 
 MPT_KERNEL_API hipError_t mpt_launch_render_wide(const MptRenderParams *p, int blocks, int count, int quant, hipStream_t stream) {

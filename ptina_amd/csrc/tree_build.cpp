@@ -759,7 +759,10 @@ extern "C" int mpt_build_tree(mpt_ctx *c) {
     }
     HIP_TRY(mpt_launch_derive_tfast(c->tgeo, c->tfast, c->nfaces, c->stream));
     HIP_TRY(hipMemsetAsync(c->tfast + (size_t)c->nfaces * 3, 0xff, 3 * sizeof(MptVec4), c->stream));   // 0xffffffff: a NaN
-    return make_wide(c);
+    if (make_wide(c)) return 1;
+    c->oct_nodes = 0; c->oct_depth = 0;
+    if (c->use_wide8 && c->tree_kind == 1) return make_oct8(c);     // option "wide8": the same tree 8-wide, octant-ordered (oct_build.cpp)
+    return 0;
 }
 
 static int download_tree(mpt_ctx *c) {

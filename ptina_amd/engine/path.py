@@ -18,4 +18,6 @@ class PathEngine(metaclass=Singleton):
     def render(self, nframes=1):
         '''reference path.py:75-77: one Sobol update + one sample per pixel, asynchronously.
         Consecutive calls are fused into one launch at the next read-back.'''
+        from ..filmtable import FilmTable
+        FilmTable()._hint()               # (where get_image() will want the image: a launch may write it while it drains)
         ctx().call('mpt_render', int(nframes))

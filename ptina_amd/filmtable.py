@@ -14,6 +14,7 @@ class FilmTable(metaclass=Singleton):
     def __init__(self, size=2**21, count=3):
         self.size = size
         self.count = count
+        self._next = None             # the array the next get_image(0) will return, already known to the library (_hint)
 
     def _res(self):
         nx, ny = C.c_int(0), C.c_int(0)
@@ -35,10 +36,28 @@ class FilmTable(metaclass=Singleton):
         '''zeroes every pass whatever `id` says, as the reference does (filmtable.py:44-45)'''
         ctx().call('mpt_clear', int(id))
 
+    def _hint(self):
+        '''called by PathEngine.render() before it enqueues frames: allocate the array the next get_image(0) will return and tell
+        the library (mpt_hint_image), so that a render launch can write the resolved image while it drains.  The reference
+        allocates that array inside get_image (filmtable.py:48); it is the same fresh array, made a little earlier'''
+        shape = self._res() + (4,)
+        if self._next is None or self._next.shape != shape:
+            if self._next is not None:
+                ctx().call('mpt_hint_image', 0, None)       # (waits for a launch that may be writing into the old one)
+            self._next = host_array(shape)
+            ctx().call('mpt_hint_image', 0, fptr(self._next))
+
     def get_image(self, id=0):
         '''reference filmtable.py:47-63: [nx, ny, 4] f32, rgb / w, w -> 1; empty -> (.9,.4,.9,0)'''
         nx, ny = self._res()
-        arr = host_array((nx, ny, 4))          # a fresh array, as in the reference; page-locked -> one DMA
+        arr = None
+        if int(id) == 0 and self._next is not None:
+            arr, self._next = self._next, None               # (the hint is spent by the call below)
+            if arr.shape != (nx, ny, 4):
+                ctx().call('mpt_hint_image', 0, None)
+                arr = None
+        if arr is None:
+            arr = host_array((nx, ny, 4))      # a fresh array, as in the reference; page-locked -> one DMA
         ctx().call('mpt_get_image', int(id), fptr(arr))
         return arr
 

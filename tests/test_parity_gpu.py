@@ -196,6 +196,133 @@ def test_work_item_shape_does_not_change_the_film(fresh):
         assert np.array_equal(film, ref), key
 
 
+def test_tail_finalisation_gives_the_combine_pass_film_and_image(fresh):
+    '''option "finalise" (default 1): a render launch that has the chip to itself adds its frames to the film, resolves and writes
+    out finished tiles itself while its last paths drain (render_kernel.hip finalise_tiles: write-through slab entries whose w
+    is the launch's tag, sc1 re-reads until the tag is there); 0 = the combine pass after the launch.  Same raw film and same
+    get_image() bits, every time: for the three production kernels (LDS-resident, 4-wide gather, binary gather), ragged films,
+    several tile shapes and frames per work item, several batches in a row, a film that already holds sums, column slabs
+    and stripes, the counting build, and the whole 512 x 512 x 32 benchmark film five times over (a hand-off that loses a
+    sample once in a million would show there)'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+
+    def run(fin, nx, ny, frames, opts=(), slab=None, stripes=None, scene=None, count=0):
+        reset_all()
+        eng = _engine(None, scene or scenes.scene_s978(), nx, ny, mode='fast', slab=slab, max_filmsize=max(nx * ny, 1 << 18))
+        c = ctx()
+        c.set_option('finalise', fin)
+        c.set_option('batch', 8)
+        c.set_option('count', count)
+        for k, v in opts:
+            c.set_option(k, v)
+        if stripes:
+            c.call('mpt_set_stripes', *stripes)
+        flags = []
+        imgs = []
+        for f in frames:
+            eng.render(f)
+            imgs.append(FilmTable().get_image().copy())          # (a read-back after every batch: each launch finds the ring idle)
+            flags.append(c.get_option('last_finalised'))
+        return FilmTable().get_raw().copy(), imgs, flags, c.get_option('last_kernel')
+
+    cases = [dict(nx=52, ny=43, frames=(8, 3, 8)), dict(nx=52, ny=43, frames=(5,), opts=(('lds', 0),)),
+             dict(nx=52, ny=43, frames=(8, 2), opts=(('lds', 0), ('wide', 0))),
+             dict(nx=52, ny=43, frames=(8, 3), opts=(('tile_w_shift', 3), ('tile_h_shift', 2))),
+             dict(nx=52, ny=43, frames=(8,), opts=(('tile_w_shift', 2), ('tile_h_shift', 2), ('chunk', 3))),
+             dict(nx=52, ny=43, frames=(4,), opts=(('tile_w_shift', 1), ('tile_h_shift', 0))),       # two pixels per tile: 62 lanes of a finishing wave idle
+             dict(nx=64, ny=40, frames=(8, 8), slab=(16, 40)), dict(nx=96, ny=40, frames=(8, 1), stripes=(16, 1, 3)),
+             dict(nx=40, ny=24, frames=(4,), scene=scenes.scene_s34(), count=1)]
+    for case in cases:
+        ref = run(0, **case)
+        got = run(1, **case)
+        assert all(f == 0 for f in ref[2]) and all(f == 1 for f in got[2]), (case, ref[2], got[2])
+        assert ref[3] == got[3]
+        assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), case
+        for a, b in zip(got[1], ref[1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), case
+    # the benchmark film, repeatedly, and pipelined launches in between (render(64) = two launches back to back: the second finds
+    # the first in flight and keeps the combine pass; both orders of addition are the frame order)
+    films = {}
+    for fin in (0, 1):
+        reset_all()
+        eng = _engine(None, scenes.scene_s978(), 512, 512, mode='fast')
+        c = ctx()
+        c.set_option('finalise', fin)
+        c.set_option('batch', 32)
+        out = []
+        for rep in range(5):
+            eng.render(32)
+            out.append(FilmTable().get_image().copy())
+            assert c.get_option('last_finalised') == fin
+        eng.render(64)
+        out.append(FilmTable().get_image().copy())
+        assert c.get_option('last_finalised') == 0          # (the second launch of the pair)
+        out.append(FilmTable().get_raw().copy())
+        films[fin] = out
+    reset_all()
+    for a, b in zip(films[1], films[0]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.all(films[1][-1][:, 3] == 5 * 32 + 64)
+
+
+def test_image_hint_is_advice_only(fresh):
+    '''mpt_hint_image says where the next get_image(0) will want its array, so that a finalising launch can write the resolved
+    image while it drains (FilmTable does this for every PathEngine.render()).  It is advice: the image is right when the hint
+    is used, when the film changes between the render and the read-back (clear, another batch, a resize), when get_image is
+    given another array, when there is no hint at all, and when the hinted array is dropped unused'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx
+    from ptina_amd._lib import fptr, host_array
+    nx, ny = 72, 40
+    eng = _engine(fresh, scenes.scene_s978(), nx, ny, mode='fast')
+    c = ctx()
+    film = FilmTable()
+    c.set_option('batch', 4)
+
+    def want():
+        raw = film.get_raw().reshape(nx, ny, 4)
+        img = np.empty_like(raw)
+        img[..., :3] = raw[..., :3] / raw[..., 3:4]
+        img[..., 3] = 1.0
+        return img
+
+    eng.render(4)                                    # hint -> launch writes the image -> get_image only waits
+    assert c.get_option('last_finalised') == 1
+    a = film.get_image()
+    assert np.array_equal(a, want())
+    eng.render(4)
+    b = film.get_image()
+    assert b is not a and np.array_equal(b, want()) and not np.array_equal(a, b)     # a fresh array every time; the old one untouched
+    a_copy = a.copy()
+    eng.render(4)
+    eng.render(4)                                    # a second batch after the one that wrote the image: the early image is stale
+    d = film.get_image()
+    assert np.array_equal(d, want()) and np.array_equal(a, a_copy)
+    eng.render(4)
+    film.clear()                                     # the film changed under the early image
+    e = film.get_image()
+    assert np.allclose(e, [0.9, 0.4, 0.9, 0.0])
+    eng.render(4)
+    other = host_array((nx, ny, 4))                  # get_image into another array than the hinted one
+    c.call('mpt_get_image', 0, fptr(other))
+    assert np.array_equal(other, want())
+    f = film.get_image()                             # (no launch since: the resolve pass)
+    assert np.array_equal(f, other)
+    eng.render(4)
+    film._next = None                                # the hinted array dropped unused: FilmTable makes another one ...
+    c.call('mpt_hint_image', 0, None)                # ... after telling the library (which waits for the launch writing into it)
+    g = film.get_image()
+    assert np.array_equal(g, want())
+    eng.render(2)
+    film.set_size(40, 24)                            # resize between render and read-back: the hinted array has the wrong shape
+    film.clear()
+    eng.render(4)
+    h = film.get_image()
+    raw = film.get_raw().reshape(40, 24, 4)
+    assert h.shape == (40, 24, 4) and np.array_equal(h[..., :3], raw[..., :3] / raw[..., 3:4])
+
+
 def test_workgroup_size_does_not_change_the_film(fresh):
     '''the LDS-resident kernel picks its persistent workgroup by the launch's size (768 lanes below six samples per lane,
     1024 above: miptina.cpp); whatever is picked or forced -- 256, 512, 768, 1024 lanes, i.e. 1 to 4 waves per SIMD sharing
@@ -619,17 +746,20 @@ def test_random_scenes_parity(fresh, oracle_mod, seed):
     ref.render(spp)
     want = ref.get_image()
     assert np.isfinite(want).all()
-    for mode, opts in (('strict', {}), ('fast', {}), ('fast', {'lds': 0, 'wide': 0}), ('fast', {'lds': 0})):
+    for mode, opts in (('strict', {}), ('fast', {}), ('fast', {'lds': 0, 'wide': 0}), ('fast', {'lds': 0}), ('fast', {'lds': 0, 'wide8': 1})):
         reset_all()
         eng = _engine(None, scene, nx, ny, mode=mode, lights=lights, world=world)
         for key, val in opts.items():
             ctx().set_option(key, val)
+        if 'wide8' in opts:
+            from ptina_amd.things import BVHTree
+            BVHTree().build()                      # (the 8-wide records are made by the build that follows the option)
         eng.render(spp)
         raw = FilmTable().get_raw().reshape(nx, ny, 4)
         assert np.all(raw[..., 3] == spp)
         kernel = ctx().get_option('last_kernel')
         if mode == 'fast':
-            assert kernel == (1 if not opts else 0 if 'wide' in opts else 2), (opts, kernel)
+            assert kernel == (1 if not opts else 4 if 'wide8' in opts else 0 if 'wide' in opts else 2), (opts, kernel)
         assert_parity(FilmTable().get_image(), want, *bounds(mode), what=f'random scene {seed} ({k} triangles) {mode} {opts}')
     reset_all()
 
@@ -1079,6 +1209,94 @@ def test_device_wide_collapse_equals_the_host_pass(fresh, name, kw):
         assert np.array_equal(np.sort(ids[ids > 0]), np.arange(1, nw))             # every wide node but the root has one parent
         leaves = ~ids[(ids < 0) & (ids != ~n)]
         assert np.array_equal(np.sort(leaves), np.arange(n))                       # every triangle in exactly one slot
+
+
+def test_octant_ordered_8wide_tree_and_kernel(fresh, oracle_mod):
+    '''option "wide8" (VERDICT r03 next #3): the fast tree collapsed 8-wide with octant-ordered child slots and 8-bit boxes
+    (oct_build.cpp), walked without a sort by render_kernel_oct.  Structure: every 8-wide node but the root is the child of
+    exactly one slot, internal children and leaf triangles are numbered consecutively in slot order, every triangle sits in
+    exactly one leaf slot (the permutation is one), every child's quantised box holds the boxes of everything below it (checked
+    from the leaves up), empty slots are inverted boxes.  Films: 60 000 random triangles and the benchmark scene forced off LDS,
+    against the 4-wide kernel (the same hits; equal-depth ties may be met in another order) and against the oracle'''
+    import ctypes as C
+    from helpers import assert_parity, setup_oracle
+    from ptina_amd.things import FilmTable, BVHTree
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd._lib import fptr, iptr
+    for name, kw, nx, ny, spp in (('c5', {'n': 60000}, 160, 128, 4), ('s978', {}, 96, 80, 8)):
+        scene = scenes.get_scene(name, **kw)
+        n = scene[1].shape[0]
+        films = {}
+        for w8 in (1, 0):
+            reset_all()
+            eng = _engine(None, scene, nx, ny, mode='fast', max_faces=max(n + 1, 1 << 21))
+            c = ctx()
+            c.set_option('lds', 0)
+            c.set_option('wide8', w8)
+            BVHTree().build()
+            c.set_option('count', 1)
+            c.call('mpt_reset_counters')
+            eng.render(spp)
+            cnt = c.counters()
+            assert c.get_option('last_kernel') == (4 if w8 else 2)
+            films[w8] = (FilmTable().get_image().copy(), cnt['n_node'] / cnt['rays'], cnt['n_tri'] / cnt['rays'])
+            raw = FilmTable().get_raw().reshape(nx, ny, 4)
+            assert np.all(raw[..., 3] == spp)
+            if w8:
+                nw = c.get_option('oct_nodes')
+                assert nw > 0 and 1 <= c.get_option('oct_depth') <= 40
+                rec = np.zeros((nw, 5, 4), np.float32)
+                perm = np.zeros(n, np.int32)
+                got = C.c_int(0)
+                c.call('mpt_get_oct8', fptr(rec), iptr(perm), nw, C.byref(got))
+                assert got.value == nw and np.array_equal(np.sort(perm), np.arange(n))
+                words = rec.view(np.uint32)
+                a_node, a_tri = words[:, 1, 2], words[:, 1, 3]
+                imask, lmask = a_node >> 24, a_tri >> 24
+                assert np.all(imask & lmask == 0)
+                nint = np.array([bin(int(m)).count('1') for m in imask]); nleaf = np.array([bin(int(m)).count('1') for m in lmask])
+                assert np.all(nint + nleaf >= 2) and np.all(nint + nleaf <= 8)
+                # breadth-first numbering: children of node w start where those of node w - 1 end, triangles likewise
+                assert np.array_equal(a_node & 0xffffff, 1 + np.concatenate([[0], np.cumsum(nint)[:-1]]))
+                assert np.array_equal(a_tri & 0xffffff, np.concatenate([[0], np.cumsum(nleaf)[:-1]]))
+                assert 1 + nint.sum() == nw and nleaf.sum() == n
+                # quantised child boxes, decoded as the kernel does: they hold everything below them
+                planes = words[:, 2:5, :].reshape(nw, 3, 4).copy()                   # [node][axis]{lo0-3, lo4-7, hi0-3, hi4-7}
+                by = planes.view(np.uint8).reshape(nw, 3, 4, 4)
+                lo_q = by[:, :, 0:2, :].reshape(nw, 3, 8).astype(np.float32); hi_q = by[:, :, 2:4, :].reshape(nw, 3, 8).astype(np.float32)
+                origin = rec[:, 0, :3]; scale = np.stack([rec[:, 0, 3], rec[:, 1, 0], rec[:, 1, 1]], axis=1)
+                lo = origin[:, :, None] + lo_q * scale[:, :, None]; hi = origin[:, :, None] + hi_q * scale[:, :, None]   # [node][axis][slot]
+                used = ((imask | lmask)[:, None] >> np.arange(8)[None, :]) & 1
+                assert np.all((lo_q[:, 0, :] == 255) & (hi_q[:, 0, :] == 0) | (used == 1))      # empty slots: inverted
+                verts = scene[0].reshape(-1, 3, 8)[:, :, :3]
+                # true boxes bottom-up: a node's box = union of its children's true boxes; leaves from the triangles (via perm -> slot -> face)
+                tree = BVHTree().to_numpy()
+                face_of_slot = tree['leaf']                                             # leaf slot -> face (lbvh.py leaf array)
+                tlo = np.zeros((nw, 3)); thi = np.zeros((nw, 3))
+                eps = 1e-4
+                for w in range(nw - 1, -1, -1):
+                    blo = np.full(3, np.inf); bhi = np.full(3, -np.inf)
+                    ci = int(a_node[w] & 0xffffff); ti = int(a_tri[w] & 0xffffff)
+                    for s_ in range(8):
+                        if (int(imask[w]) >> s_) & 1:
+                            clo, chi = tlo[ci], thi[ci]; ci += 1
+                        elif (int(lmask[w]) >> s_) & 1:
+                            tri = verts[face_of_slot[perm[ti]]]; ti += 1
+                            clo, chi = tri.min(axis=0), tri.max(axis=0)
+                        else:
+                            continue
+                        span = np.maximum(np.abs(clo), np.abs(chi)) * 1e-5 + eps * scale[w]
+                        assert np.all(lo[w, :, s_] <= clo + span) and np.all(hi[w, :, s_] >= chi - span), (name, w, s_)
+                        blo = np.minimum(blo, clo); bhi = np.maximum(bhi, chi)
+                    tlo[w], thi[w] = blo, bhi
+        reset_all()
+        print(f'{name}: node visits per ray 8-wide {films[1][1]:.2f} / 4-wide {films[0][1]:.2f}, triangle tests {films[1][2]:.2f} / {films[0][2]:.2f}')
+        assert films[1][1] < 0.8 * films[0][1]                       # fewer, wider steps
+        assert_parity(films[1][0], films[0][0], *FAST, what=f'{name}: 8-wide octant-ordered vs 4-wide')
+        if name == 's978':
+            ref = setup_oracle(oracle_mod, scene, nx, ny)
+            ref.render(spp)
+            assert_parity(films[1][0], ref.get_image(), *FAST, what='s978 through the 8-wide kernel vs oracle')
 
 
 def test_device_sah_pass_builds_a_tree_as_good_as_the_host_pass(fresh, oracle_mod):

@@ -6,7 +6,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../ptina_amd/csrc"
 mkdir -p _obj_ab_$name
-for f in render_strict unit_fast unit_strict aux_kernels lbvh_build miptina tree_build comm; do
+for f in render_strict unit_fast unit_strict aux_kernels lbvh_build sah_build wide_build miptina tree_build oct_build comm; do
   [ -f _obj/$f.o ] && cp -p _obj/$f.o _obj_ab_$name/ || true
 done
 make -s OBJ=_obj_ab_$name OUT=../libmiptina_$name.so FASTFLAGS="-fno-slp-vectorize $*" 2>&1 | grep -E "error|Error" -A5 || true

@@ -344,7 +344,15 @@ def timeline(name='s978', spp=32, n=512):
         np.save(os.path.join(ROOT, 'gpurun_out', f'timeline_raw_{parts}.npy'), t)
         t0 = t[:, 0].min()
         us = (t[:, :4] - t0) / 100.0
-        if t[:, 5].max() > 0:            # diagnostic build -DMPT_X_TIMELINE2: last pull, items, lanes in flight at empty, passes after
+        if t[:, 6].max() == 0 and t[:, 4].max() > 0:     # product build with the tail finalisation: when each wave left it, tiles it did
+            fin_end = (t[:, 4] - t0) / 100.0
+            extra = {'fin_end': [round(float(x), 1) for x in np.percentile(fin_end, [0, 10, 50, 90, 100])],
+                     'fin_us_per_wave': [round(float(x), 1) for x in np.percentile(fin_end - us[:, 3], [0, 10, 50, 90, 100])],
+                     'tiles_per_wave': [int(x) for x in np.percentile(t[:, 5], [0, 10, 50, 90, 100])],
+                     'waves_that_finalised': int((t[:, 5] > 0).sum()), 'tiles': int(t[:, 5].sum()),
+                     'last_trace_exit': round(float(us[:, 3].max()), 1), 'last_fin_exit': round(float(fin_end.max()), 1)}
+            print('timeline_fin', parts, json.dumps(extra), flush=True)
+        elif t[:, 5].max() > 0:            # diagnostic build -DMPT_X_TIMELINE2: last pull, items, lanes in flight at empty, passes after
             lastpull = (t[:, 4] - t0) / 100.0
             extra = {'last_pull': [round(float(x), 1) for x in np.percentile(lastpull, [0, 10, 50, 90, 100])],
                      'last_item_us': [round(float(x), 1) for x in np.percentile(us[:, 2] - lastpull, [0, 10, 50, 90, 100])],

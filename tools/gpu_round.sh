@@ -44,10 +44,16 @@ for step in "$@"; do
     ubench)      run ubench 200 tools/microbench/valu_microbench --json ;;
     ubench_pmc)  run ubench_pmc 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/ubench_pmc -- tools/microbench/valu_microbench ;;
     bench_quick) run bench_quick 300 python bench.py --no-pmc --no-cpu-baseline ;;
-    ablibs)      for L in $ABLIBS; do MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_$L.so run ab_$L 300 python bench.py --no-pmc --no-cpu-baseline; done ;;
+    bench_nofin) MIPTINA_OPTS=finalise=0 run bench_nofin 300 python bench.py --no-pmc --no-cpu-baseline ;;
+    tests_fin)   run tests_fin 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'finalisation or hint or film_api or batching or full_size or smoke or pipelin' ;;
+    ablibs)      n=0; for L in $ABLIBS; do n=$((n+1)); O=$MIPTINA_OPTS; case $L in base*|nofin*|*nofin) O=finalise=0 ;; *noimg) O=finalise=2 ;; esac;   # (builds without the in-kernel finalisation need the combine pass)
+                   F=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_$L.so; [ "$L" = main ] && F=$GRAFT_REPO_ROOT/ptina_amd/libmiptina.so;
+                   MIPTINA_OPTS=$O MIPTINA_LIB=$F run ab${n}_$L 300 python bench.py --no-pmc --no-cpu-baseline; done ;;
     tests_fast)  run tests_fast 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'fast_build or strict_build or full_size or batching or pipelining or lds_and_gather or lobes or ordered or idle or work_item or quantised' ;;
     tests_big)   run tests_big 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'config5 or config4 or mid_size or large_scene or lds_and_gather or where_the_tree' ;;
     big_wide)    MIPTINA_WIDE=1 run big_wide 400 python tools/run_configs.py C4 C5 ;;
+    big_oct)     MIPTINA_OPTS=wide8=1 CONFIGS_OUT=configs_oct.json run big_oct 500 python tools/run_configs.py C4 C5 ;;
+    tests_oct)   run tests_oct 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'octant or random_scenes' ;;
     big_ablibs)  for L in $ABLIBS; do MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_$L.so run big_$L 400 python tools/run_configs.py C4 C5; done ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
     tests_all)   run tests_all 900 python -m pytest tests -m gpu -q ;;
