@@ -32,7 +32,7 @@ __device__ __forceinline__ float construct_float(int i) {
     return ret;
 }
 
-__global__ __launch_bounds__(256) void sobol_update_kernel(int *__restrict__ X, const int *__restrict__ V,
+__global__ __launch_bounds__(256) void sobol_update_kernel(const int *X, int *Xout, const int *__restrict__ V,
                                                            float *__restrict__ P, int dim, int rows, int time0,
                                                            int count, int pstride_frames, int write_x) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,8 +45,9 @@ __global__ __launch_bounds__(256) void sobol_update_kernel(int *__restrict__ X, 
         // (reset's skipped updates never read P)
         if (f >= count - pstride_frames) P[(size_t)(f - (count - pstride_frames)) * dim + j] = construct_float(x);
     }
-    // write_x = 0: the points of the NEXT batch computed ahead of time; the state moves when that batch is launched
-    if (write_x) X[j] = x;
+    // Xout = X: the sampler's state moves.  Xout = a second buffer: the points of the NEXT batch computed ahead of time, and the
+    // state that batch will leave behind with them -- the host swaps the two buffers when that batch is launched
+    if (write_x) Xout[j] = x;
 }
 
 // film[pix] += sample[0][pix], then sample[1][pix], ... : the reference's frame-by-frame
@@ -125,10 +126,10 @@ MPT_KERNEL_API hipError_t mpt_launch_probe(double *out, int threads, size_t lds_
     return hipGetLastError();
 }
 
-MPT_KERNEL_API hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0,
+MPT_KERNEL_API hipError_t mpt_launch_sobol_update(const int *X, int *Xout, const int *V, float *P, int dim, int rows, int time0,
                                               int count, int keep, int write_x, hipStream_t stream) {
     int grid = (dim + 255) / 256;
-    hipLaunchKernelGGL(sobol_update_kernel, dim3(grid), dim3(256), 0, stream, X, V, P, dim, rows, time0, count, keep, write_x);
+    hipLaunchKernelGGL(sobol_update_kernel, dim3(grid), dim3(256), 0, stream, X, Xout, V, P, dim, rows, time0, count, keep, write_x);
     return hipGetLastError();
 }
 

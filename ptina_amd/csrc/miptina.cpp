@@ -6,6 +6,7 @@
 // gather in comm.cpp.  No PyTorch, no Python: plain HIP runtime calls.
 
 #include "miptina_ctx.h"
+#include <chrono>
 
 // Up to MPT_MAX_PIPE render streams, the main stream and the aux stream carry work at the same time.
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told
@@ -130,13 +131,13 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (dev_alloc(&c->lights, MPT_MAX_LIGHTS)) return bail("lights");
     if (dev_alloc(&c->d_counters, 20)) return bail("counters");
     if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
-    if (dev_alloc(&c->d_work, 16)) return bail("work counters");   // 8 queue heads
+    if (dev_alloc(&c->d_work, MPT_QUEUE_WORDS)) return bail("work counters");   // 8 queue heads, a cache line each
     for (int k = 0; k < MPT_MAX_PIPE; k++) {
         if (hipEventCreateWithFlags(&c->ev_sobol2[k], hipEventDisableTiming) != hipSuccess) return bail("event");
         if (hipEventCreateWithFlags(&c->ev_render[k], hipEventDisableTiming) != hipSuccess) return bail("event");
         if (hipEventCreateWithFlags(&c->ev_free[k], hipEventDisableTiming) != hipSuccess) return bail("event");
-        if (dev_alloc(&c->d_work2[k], 16)) return bail("work counters");
-        hipMemsetAsync(c->d_work2[k], 0, 16 * sizeof(unsigned int), c->stream);
+        if (dev_alloc(&c->d_work2[k], MPT_QUEUE_WORDS)) return bail("work counters");
+        hipMemsetAsync(c->d_work2[k], 0, MPT_QUEUE_WORDS * sizeof(unsigned int), c->stream);
     }
     if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) return bail("aux stream");
     if (hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess) return bail("event");
@@ -157,7 +158,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
         c->d_watchdog = (unsigned int *)dp;
     }
     hipMemsetAsync(c->d_counters, 0, 20 * sizeof(unsigned long long), c->stream);
-    hipMemsetAsync(c->d_work, 0, 16 * sizeof(unsigned int), c->stream);
+    hipMemsetAsync(c->d_work, 0, MPT_QUEUE_WORDS * sizeof(unsigned int), c->stream);
     {   // unset materials: factor 0 (field-zero, mtllib.py:12-13), texture -1 (deviation Q6)
         std::vector<MptMaterial> z((size_t)c->caps.max_materials + 1);
         for (auto &m : z) { memset(&m, 0, sizeof m); for (int k = 0; k < 12; k++) m.tex[k] = -1; }
@@ -200,7 +201,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     hipFree(c->snode); hipFree(c->fnode); hipFree(c->tgeo); hipFree(c->tshade); hipFree(c->wnode); hipFree(c->qnode); hipFree(c->tfast); hipFree(c->fnode_soa);
     for (int k = 0; k < MPT_MAX_PIPE; k++) hipFree(c->stack_spill2[k]);
     hipFree(c->mats); hipFree(c->images); hipFree(c->texels); hipFree(c->lights);
-    hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
+    hipFree(c->sV); hipFree(c->sX); hipFree(c->sX_spec); hipFree(c->sP);
     hipFree(c->gather_buf); hipFree(c->d_pieces); hipFree(c->sah_ws);
     hipFree(c->wb_bin_of); hipFree(c->wb_ncount); hipFree(c->wb_offset); hipFree(c->wb_scan); hipFree(c->wb_area);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
@@ -294,6 +295,9 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
     } else if (k == "wide8") {
         if (value != 0 && value != 1) return fail("wide8 must be 0 or 1");
         if (value != c->use_wide8) { c->use_wide8 = value; c->tree_valid = false; }    // (built by the next mpt_build_tree)
+    } else if (k == "spin_us") {
+        if (value < 0) return fail("spin_us must be >= 0");
+        c->spin_us = value;
     } else if (k == "finalise") {
         if (value < 0 || value > 2) return fail("finalise must be 0 (combine pass), 1 (tail finalisation) or 2 (the same without the early image: A/B)");
         c->finalise = value;
@@ -370,6 +374,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "wide8") *value = c->use_wide8;
     else if (k == "oct_nodes") *value = c->oct_nodes;
     else if (k == "oct_depth") *value = c->oct_depth;
+    else if (k == "spin_us") *value = c->spin_us;
     else if (k == "finalise") *value = c->finalise;
     else if (k == "last_finalised") *value = c->last_finalised;
     else if (k == "pool") *value = c->use_pool;
@@ -580,11 +585,11 @@ extern "C" int mpt_sobol_init(mpt_ctx *c, const int32_t *V, int rows, int dim) {
     if (use(c)) return 1;
     if (rows < 2 || dim < 1 || !V) return fail("bad sobol grid %dx%d", rows, dim);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    hipFree(c->sV); hipFree(c->sX); hipFree(c->sP);
-    c->sV = c->sX = nullptr; c->sP = nullptr;
+    hipFree(c->sV); hipFree(c->sX); hipFree(c->sX_spec); hipFree(c->sP);
+    c->sV = c->sX = c->sX_spec = nullptr; c->sP = nullptr;
     HIP_TRY(hipStreamSynchronize(c->aux));
     for (int k = 0; k < MPT_MAX_PIPE; k++) { HIP_TRY(hipStreamSynchronize(c->rstream[k])); hipFree(c->sP2[k]); c->sP2[k] = nullptr; }
-    if (dev_alloc(&c->sV, (size_t)rows * dim) || dev_alloc(&c->sX, (size_t)dim) ||
+    if (dev_alloc(&c->sV, (size_t)rows * dim) || dev_alloc(&c->sX, (size_t)dim) || dev_alloc(&c->sX_spec, (size_t)dim) ||
         dev_alloc(&c->sP, (size_t)MPT_MAX_BATCH * dim)) return 1;
     for (int k = 0; k < MPT_MAX_PIPE; k++)
         if (dev_alloc(&c->sP2[k], (size_t)MPT_MAX_BATCH * dim)) return 1;
@@ -602,7 +607,7 @@ static int sobol_advance(mpt_ctx *c, int count, int keep, hipStream_t stream = n
     while (count > 0) {
         int step = count;
         int k = std::min(keep, step);
-        HIP_TRY(mpt_launch_sobol_update(c->sX, c->sV, P, c->sdim, c->srows, c->stime, step, k, 1, stream));
+        HIP_TRY(mpt_launch_sobol_update(c->sX, c->sX, c->sV, P, c->sdim, c->srows, c->stime, step, k, 1, stream));
         c->stime = (int32_t)((uint32_t)c->stime + (uint32_t)step);
         count -= step;
     }
@@ -734,7 +739,13 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         if (fast) { HIP_TRY(hipEventRecord(c->ev_sobol2[k], ss)); HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sobol2[k], 0)); }
         return 0;
     }
-    if (sobol_advance(c, B, use_spec ? 0 : B, ss, fast ? c->sP2[k] : nullptr)) return 1;   // ahead of time: X only
+    if (use_spec) {
+        // the points AND the state this batch leaves behind were computed when the previous batch was launched: the sampler moves by
+        // a swap of two pointers -- no kernel at launch time (round 3 ran an X-only update here, whose 83 small workgroups took
+        // CUs just when the persistent render workgroups wanted them: half the workgroups of a 1/8-share launch started 35 us late)
+        std::swap(c->sX, c->sX_spec);
+        c->stime = (int32_t)((uint32_t)c->stime + (uint32_t)B);
+    } else if (sobol_advance(c, B, B, ss, fast ? c->sP2[k] : nullptr)) return 1;
 
     const int stack = ((c->mode == MPT_MODE_STRICT ? c->tree_depth : c->fast_depth) + 2 <= 32) ? 32 : 64;
     // LDS-resident kernel: node (64 B, MPT_LDS_NODE_STRIDE apart) + triangle (48 B) records + a 16-bit stack of (depth+1) levels x 1024
@@ -804,7 +815,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         p.partial = c->partial2[k];
         p.work_counter = c->d_work2[k];
         if (!use_spec) {
-            HIP_TRY(hipMemsetAsync(c->d_work2[k], 0, 16 * sizeof(unsigned int), ss));   // 8 queue heads + the finalisation's tile counter
+            HIP_TRY(hipMemsetAsync(c->d_work2[k], 0, MPT_QUEUE_WORDS * sizeof(unsigned int), ss));   // 8 queue heads + the finalisation's tile counter
             HIP_TRY(hipEventRecord(c->ev_sobol2[k], ss));
         }
         HIP_TRY(hipStreamWaitEvent(rs, c->ev_sobol2[k], 0));
@@ -908,11 +919,16 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         if (c->launch_seq % 4194304u == 0u)      // the tags come round again: no entry of any slab may still carry the old one
             for (int q = 0; q < MPT_MAX_PIPE; q++)
                 if (c->partial2[q]) HIP_TRY(hipMemsetAsync(c->partial2[q], 0, c->partial2_cap[q] * sizeof(MptVec4), rs));
-        p.fin_counter = c->d_work2[k] + 8;
+        p.fin_counter = c->d_work2[k] + 8 * MPT_QUEUE_STRIDE;
         p.slab_tag = 2.0f + (float)(c->launch_seq % 4194304u);               // exact in f32; never 0 (fresh memory) or 1 (a combine-pass launch)
-        // everything the main stream still has to do to the film (an earlier batch's combine, a clear, a gather) comes first
-        HIP_TRY(hipEventRecord(c->ev_film, c->stream));
-        HIP_TRY(hipStreamWaitEvent(rs, c->ev_film, 0));
+        // everything the main stream still has to do to the film (an earlier batch's combine, a clear, a gather) comes first --
+        // nothing, when the stream is idle (a step that ended with a read-back): then the event pair (8 us of API calls in front of
+        // the launch, HIP trace of bench.py) is left out
+        const hipError_t main_busy = hipStreamQuery(c->stream);
+        if (main_busy == hipErrorNotReady) {
+            HIP_TRY(hipEventRecord(c->ev_film, c->stream));
+            HIP_TRY(hipStreamWaitEvent(rs, c->ev_film, 0));
+        } else if (main_busy != hipSuccess) HIP_TRY(main_busy);
         // the resolved image as well, if the caller has said where get_image() will want it and this share is the whole film
         const size_t img_bytes = (size_t)c->nx * c->ny * sizeof(MptVec4);
         void *mapped = nullptr;
@@ -958,8 +974,8 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         const int k2 = c->flip % c->cur_depth;
         if (k2 != k) {
             HIP_TRY(hipStreamWaitEvent(ss, c->ev_render[k2], 0));   // the batch that last read sP2[k2] / d_work2[k2]
-            HIP_TRY(mpt_launch_sobol_update(c->sX, c->sV, c->sP2[k2], c->sdim, c->srows, c->stime, B, B, 0, ss));
-            HIP_TRY(hipMemsetAsync(c->d_work2[k2], 0, 16 * sizeof(unsigned int), ss));
+            HIP_TRY(mpt_launch_sobol_update(c->sX, c->sX_spec, c->sV, c->sP2[k2], c->sdim, c->srows, c->stime, B, B, 1, ss));
+            HIP_TRY(hipMemsetAsync(c->d_work2[k2], 0, MPT_QUEUE_WORDS * sizeof(unsigned int), ss));
             HIP_TRY(hipEventRecord(c->ev_sobol2[k2], ss));
             c->spec_valid = true; c->spec_slot = k2; c->spec_B = B; c->spec_time = c->stime;
         }
@@ -1073,6 +1089,18 @@ extern "C" int mpt_get_image(mpt_ctx *c, int pass, float *out) {               /
             if (check_pass(c, pass)) return 1;
             // the launch's own stream: one completion signal (the main stream, which waits for the same launch before anything else
             // it is given, would add a cross-stream hop in front of the host's wake-up)
+            // ... and polled, for a while, instead of slept on: the runtime's blocking wait returned 18 us after the kernel's end
+            // (HIP trace), a query loop sees the completion signal within a few; a launch that runs longer than the poll window
+            // falls back to the blocking wait (option "spin_us", 0 = always block)
+            if (c->spin_us > 0) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (;;) {
+                    const hipError_t q = hipStreamQuery(c->early_stream);
+                    if (q == hipSuccess) return check_watchdog(c);
+                    if (q != hipErrorNotReady) HIP_TRY(q);
+                    if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > (double)c->spin_us) break;
+                }
+            }
             HIP_TRY(hipStreamSynchronize(c->early_stream));
             return check_watchdog(c);
         }

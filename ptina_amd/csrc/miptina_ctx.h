@@ -30,8 +30,8 @@ MPT_KERNEL_API hipError_t mpt_launch_render_pool(const MptRenderParams *, int gr
 MPT_KERNEL_API size_t mpt_pool_lds_overhead(void);
 MPT_KERNEL_API hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_preview_strict(const MptRenderParams *, int grid, int stack, hipStream_t);
-MPT_KERNEL_API hipError_t mpt_launch_sobol_update(int *X, const int *V, float *P, int dim, int rows, int time0, int count,
-                                              int keep, int write_x, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_sobol_update(const int *X, int *Xout, const int *V, float *P, int dim, int rows, int time0,
+                                              int count, int keep, int write_x, hipStream_t stream);
 MPT_KERNEL_API hipError_t mpt_launch_combine(MptVec4 *film, const MptVec4 *partial, int ny, int x0, int x1,
                                          int stripe_w, int stripe_pitch, int ccols, int nframes, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_resolve(const MptVec4 *film, MptVec4 *out, size_t npix, hipStream_t);
@@ -179,6 +179,7 @@ struct mpt_ctx {
     int sdim = 0, srows = 0;
     int32_t stime = 0;
     int *sV = nullptr, *sX = nullptr;
+    int *sX_spec = nullptr;              // the state the batch whose points were computed ahead of time will leave behind (swapped with sX when it is launched)
     float *sP = nullptr;                 // [MPT_MAX_BATCH][sdim]
 
     // command batching
@@ -202,6 +203,7 @@ struct mpt_ctx {
     // film_version counts the changes of pass 0; hint_image = where the next mpt_get_image(0) wants the image (mpt_hint_image);
     // early_* = the image a finalising launch has written (or is writing) and the film version it shows
     int finalise = 1;
+    int spin_us = 20000;                              // mpt_get_image polls a finalising launch for this long before it blocks
     unsigned launch_seq = 0;
     unsigned long long film_version = 0;
     float *hint_image = nullptr;

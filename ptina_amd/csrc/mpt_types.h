@@ -34,6 +34,14 @@
 #define MPT_BLOCK 256          // 4 waves of 64; one 16x16 pixel tile, an 8x8 sub-tile per wave
 #define MPT_TILE 16
 #define MPT_MAX_BATCH 64       // frames per launch
+// The eight per-XCD queue heads of a persistent launch sit MPT_QUEUE_STRIDE words apart -- each on a cache line of its own: device-
+// scope atomics on words of ONE line are served one after the other (a single head saturates near 88 pulls per microsecond; the
+// benchmark launch makes 52), so eight heads in one 32-byte block were still one queue to the memory system.  The tail
+// finalisation's tile counter follows them on its own line.  MPT_QUEUE_WORDS = what a launch's block holds (zeroed per launch).
+#ifndef MPT_QUEUE_STRIDE
+#define MPT_QUEUE_STRIDE 32
+#endif
+#define MPT_QUEUE_WORDS (10 * MPT_QUEUE_STRIDE)
 #define MPT_TIMELINE_WORDS 8    // diagnostics: 64-bit words per wave of the launch timeline (option "timeline")
 #define MPT_MAX_LIGHTS 64
 #define MPT_MAX_DEVICES 64     // device ids a process may hold contexts on (per-device launch caches)

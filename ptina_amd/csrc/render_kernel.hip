@@ -877,12 +877,34 @@ struct WorkQueue {
             int q = (q0 + qoff) & 7;
             int lo = (int)(((long long)nitems * q) >> 3), hi = (int)(((long long)nitems * (q + 1)) >> 3);
             int k = 0;
-            if (lane == 0) k = (int)atomicAdd(ctr + q, 1u);
+            if (lane == 0) k = (int)atomicAdd(ctr + q * MPT_QUEUE_STRIDE, 1u);
             k = __builtin_amdgcn_readfirstlane(k);
             if (lo + k < hi) return lo + k;
             qoff++;
         }
         return -1;
+    }
+    // Items nobody has pulled yet, over all eight ranges -- on the SCALAR unit only (one s_load_dwordx8 past the scalar cache, a
+    // dozen SALU instructions): the shading pass has no vector register to spare (a first version with a vector load and wave
+    // shuffles spilled four of its live values to scratch and the whole launch took 2.7 x as long).  A relaxed look: the counters
+    // move on meanwhile.
+    DEV int remaining() const {
+        unsigned c0, c1, c2, c3, c4, c5, c6, c7;
+        asm volatile("s_load_dword %0, %8, %9 glc\n\ts_load_dword %1, %8, %10 glc\n\ts_load_dword %2, %8, %11 glc\n\ts_load_dword %3, %8, %12 glc\n\t"
+                     "s_load_dword %4, %8, %13 glc\n\ts_load_dword %5, %8, %14 glc\n\ts_load_dword %6, %8, %15 glc\n\ts_load_dword %7, %8, %16 glc\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3), "=&s"(c4), "=&s"(c5), "=&s"(c6), "=&s"(c7)
+                     : "s"(ctr), "i"(0), "i"(4 * MPT_QUEUE_STRIDE), "i"(8 * MPT_QUEUE_STRIDE), "i"(12 * MPT_QUEUE_STRIDE), "i"(16 * MPT_QUEUE_STRIDE),
+                       "i"(20 * MPT_QUEUE_STRIDE), "i"(24 * MPT_QUEUE_STRIDE), "i"(28 * MPT_QUEUE_STRIDE)
+                     : "memory");
+        const unsigned c[8] = { c0, c1, c2, c3, c4, c5, c6, c7 };
+        int pulled = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int size = (int)(((long long)nitems * (q + 1)) >> 3) - (int)(((long long)nitems * q) >> 3);
+            pulled += min((int)c[q], size);
+        }
+        return nitems - pulled;
     }
 };
 
@@ -1050,7 +1072,23 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
         unsigned long long m_new = __ballot(L.st == ST_NEW);
         if (m_new != 0ull) {
             if (next >= S && more) {                // pool drained: fetch the next work item right away,
-                int item = wq.pull();               // while the other lanes are still busy (no per-item tail)
+                int item = -1;                      // while the other lanes are still busy (no per-item tail)
+#if MPT_TAPER
+                // The end of a launch is one path latency per wave, and a path runs 2-3 x faster in a wave that has its SIMD to
+                // itself.  So the launch tapers: the youngest wave of each SIMD stops pulling when fewer than 3 x MPT_TAPER x (waves of
+                // one age) items are left, the next at 2 x, the next at 1 x; the oldest -- which the hardware issues first anyway --
+                // take the last items alone.  (Workgroups of at least three waves per SIMD; the others pull to the end.)
+                const int taper_age = (blockDim.x >> 8) >= 3 ? (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) & 3) : 0;
+#if MPT_X_TAPER_DBG == 1     // bisecting: the look at the counters stays, the answer is always "pull"
+                if (taper_age == 0 || wq.remaining() >= -0x7fffffff) item = wq.pull();
+#elif MPT_X_TAPER_DBG == 2   // bisecting: no look at the counters
+                if (taper_age == 0 || p.nitems >= taper_age) item = wq.pull();
+#else
+                if (taper_age == 0 || wq.remaining() >= taper_age * MPT_TAPER * (int)(gridDim.x * 4)) item = wq.pull();
+#endif
+#else
+                item = wq.pull();
+#endif
                 if (item < 0) {
                     more = false;
 #if MPT_X_TAIL_PRIO

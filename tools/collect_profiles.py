@@ -81,6 +81,28 @@ if big:
     with open(os.path.join(dst, f'{tag}_pmc_big_summary.json'), 'w') as fh:
         json.dump(big, fh, indent=1, sort_keys=True)
     print('big-scene pmc summary ->', f'{tag}_pmc_big_summary.json')
+# the same scenes through the 8-wide octant-ordered kernel (option wide8: `tools/gpu_round.sh pmcoct1 pmcoct3 pmcoct4`), same dispatch pattern
+octs = {}
+for d in ('pmcoct1', 'pmcoct3', 'pmcoct4'):
+    f = newest(f'{d}/*/*counter_collection.csv')
+    if not f:
+        continue
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        if 'render_kernel_oct<false' in r['Kernel_Name']:
+            per[r['Counter_Name']][int(r['Dispatch_Id'])] += float(r['Counter_Value'])
+    for cn, byd in per.items():
+        vals = [byd[k] for k in sorted(byd)]
+        if len(vals) != 11:
+            continue
+        for name, sl in (('C4 99k tris, 32 frames x 1024x1024 per launch', vals[1:7]),
+                         ('C5 1M tris, 16 frames x 1024x1024 per launch', vals[8:11])):
+            sl = sorted(sl)
+            octs.setdefault(name, {})[cn] = sl[len(sl) // 2]
+if octs:
+    with open(os.path.join(dst, f'{tag}_pmc_oct_summary.json'), 'w') as fh:
+        json.dump(octs, fh, indent=1, sort_keys=True)
+    print('8-wide kernel pmc summary ->', f'{tag}_pmc_oct_summary.json')
 for name in ('bench.log', 'diag.json'):
     src = os.path.join(ROOT, 'gpurun_out', name)
     if os.path.exists(src):

@@ -61,6 +61,8 @@ for step in "$@"; do
     prof)        (cd /tmp; run_dir=$GRAFT_REPO_ROOT/gpurun_out/prof; rm -rf $run_dir; mkdir -p $run_dir;
                   cd $GRAFT_REPO_ROOT;
                   run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pmc) ;;
+    hiptrace)    (run_dir=$GRAFT_REPO_ROOT/gpurun_out/hiptrace; rm -rf $run_dir; mkdir -p $run_dir;
+                  run hiptrace 400 rocprofv3 --hip-trace --kernel-trace --output-format csv -d gpurun_out/hiptrace -- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-pmc) ;;
     slabtrace)   (run_dir=$GRAFT_REPO_ROOT/gpurun_out/slabtrace; rm -rf $run_dir; mkdir -p $run_dir;
                   STRIPE=16 run slabtrace 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/slabtrace -- python3 tools/slab_trace.py 8 3 40) ;;
     counters)    rocprofv3 -L > gpurun_out/counters_list.txt 2>&1; echo "counters listed" ;;
@@ -72,6 +74,9 @@ for step in "$@"; do
     pmcbig2)     run pmcbig2 500 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmcbig2 -- python3 tools/run_configs.py C4 C5 ;;
     pmcbig3)     run pmcbig3 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcbig3 -- python3 tools/run_configs.py C4 C5 ;;
     pmcbig4)     run pmcbig4 500 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM --output-format csv -d gpurun_out/pmcbig4 -- python3 tools/run_configs.py C4 C5 ;;
+    pmcoct3)     MIPTINA_OPTS=wide8=1 run pmcoct3 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcoct3 -- python3 tools/run_configs.py C4 C5 ;;
+    pmcoct4)     MIPTINA_OPTS=wide8=1 run pmcoct4 500 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM --output-format csv -d gpurun_out/pmcoct4 -- python3 tools/run_configs.py C4 C5 ;;
+    pmcoct1)     MIPTINA_OPTS=wide8=1 run pmcoct1 500 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcoct1 -- python3 tools/run_configs.py C4 C5 ;;
     # (TA_* / TCP_* counter passes over run_configs.py hung rocprofv3 on this pool -- 7 minutes without output -- and are not offered)
     torchrun1)   run torchrun1 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --force-comm --no-cpu-baseline --no-pmc ;;
     *) echo "unknown step $step" ;;
