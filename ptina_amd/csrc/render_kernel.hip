@@ -868,6 +868,11 @@ DEV int wave_count32(bool pred) {            // the same in two 32-bit halves: s
 // one counter each.  A wave starts on the range of its XCD (blocks b, b+8, ... share an XCD) and
 // moves on to the next range when one runs dry, so neighbouring tiles are traced by CUs behind the
 // same L2 for as long as there is local work; every wave leaves when all eight ranges are exhausted.
+// (Round 4, measured and taken out again -- profiles/r04_ab_experiments.json: a tapered end of launch, the younger waves of a SIMD
+//  leaving the last items to the older.  Told by a look at the eight heads it made the launch 2.1-2.7 x slower -- which is how the
+//  heads' shared cache line was found, mpt_types.h MPT_QUEUE_STRIDE -- and told by the pull's own result, free of any memory
+//  access, 1-2 % slower: the end of a launch wants every wave it can get.  Also: the pull's atomic issued 8 / 16 / 32 samples ahead
+//  of need: 2.89 / 2.89 / 2.92 against 2.88 ms -- its round trip is already hidden behind the wave's other lanes.)
 struct WorkQueue {
     unsigned int *ctr;
     int nitems, q0, qoff;
@@ -883,28 +888,6 @@ struct WorkQueue {
             qoff++;
         }
         return -1;
-    }
-    // Items nobody has pulled yet, over all eight ranges -- on the SCALAR unit only (one s_load_dwordx8 past the scalar cache, a
-    // dozen SALU instructions): the shading pass has no vector register to spare (a first version with a vector load and wave
-    // shuffles spilled four of its live values to scratch and the whole launch took 2.7 x as long).  A relaxed look: the counters
-    // move on meanwhile.
-    DEV int remaining() const {
-        unsigned c0, c1, c2, c3, c4, c5, c6, c7;
-        asm volatile("s_load_dword %0, %8, %9 glc\n\ts_load_dword %1, %8, %10 glc\n\ts_load_dword %2, %8, %11 glc\n\ts_load_dword %3, %8, %12 glc\n\t"
-                     "s_load_dword %4, %8, %13 glc\n\ts_load_dword %5, %8, %14 glc\n\ts_load_dword %6, %8, %15 glc\n\ts_load_dword %7, %8, %16 glc\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3), "=&s"(c4), "=&s"(c5), "=&s"(c6), "=&s"(c7)
-                     : "s"(ctr), "i"(0), "i"(4 * MPT_QUEUE_STRIDE), "i"(8 * MPT_QUEUE_STRIDE), "i"(12 * MPT_QUEUE_STRIDE), "i"(16 * MPT_QUEUE_STRIDE),
-                       "i"(20 * MPT_QUEUE_STRIDE), "i"(24 * MPT_QUEUE_STRIDE), "i"(28 * MPT_QUEUE_STRIDE)
-                     : "memory");
-        const unsigned c[8] = { c0, c1, c2, c3, c4, c5, c6, c7 };
-        int pulled = 0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int size = (int)(((long long)nitems * (q + 1)) >> 3) - (int)(((long long)nitems * q) >> 3);
-            pulled += min((int)c[q], size);
-        }
-        return nitems - pulled;
     }
 };
 
@@ -1072,23 +1055,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
         unsigned long long m_new = __ballot(L.st == ST_NEW);
         if (m_new != 0ull) {
             if (next >= S && more) {                // pool drained: fetch the next work item right away,
-                int item = -1;                      // while the other lanes are still busy (no per-item tail)
-#if MPT_TAPER
-                // The end of a launch is one path latency per wave, and a path runs 2-3 x faster in a wave that has its SIMD to
-                // itself.  So the launch tapers: the youngest wave of each SIMD stops pulling when fewer than 3 x MPT_TAPER x (waves of
-                // one age) items are left, the next at 2 x, the next at 1 x; the oldest -- which the hardware issues first anyway --
-                // take the last items alone.  (Workgroups of at least three waves per SIMD; the others pull to the end.)
-                const int taper_age = (blockDim.x >> 8) >= 3 ? (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) & 3) : 0;
-#if MPT_X_TAPER_DBG == 1     // bisecting: the look at the counters stays, the answer is always "pull"
-                if (taper_age == 0 || wq.remaining() >= -0x7fffffff) item = wq.pull();
-#elif MPT_X_TAPER_DBG == 2   // bisecting: no look at the counters
-                if (taper_age == 0 || p.nitems >= taper_age) item = wq.pull();
-#else
-                if (taper_age == 0 || wq.remaining() >= taper_age * MPT_TAPER * (int)(gridDim.x * 4)) item = wq.pull();
-#endif
-#else
-                item = wq.pull();
-#endif
+                int item = wq.pull();               // while the other lanes are still busy (no per-item tail)
                 if (item < 0) {
                     more = false;
 #if MPT_X_TAIL_PRIO
