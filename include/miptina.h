@@ -92,7 +92,7 @@ void mpt_destroy(mpt_ctx *ctx);
  * gathers per step, default; 0 = 128-byte records with the exact boxes: seven), "wide_build" (1 = that collapse runs on the
  * device, default; 0 = host pass over downloaded records: same bytes), "sah_build" (where the SAH
  * re-partition runs: 1 = on the device, binned above 32 triangles and exact below; 0 = host pass, exact up to 8192; -1 = auto: the
- * device above 32768 faces, default), "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
+ * device above 131072 faces, default), "gpu_build" (1 = LBVH built on the device, default), "sah_max" (faces above which the fast build
  * walks the LBVH itself; default 2^22), "grid_div" (each launch takes 1/G of the CUs so that G launches are resident
  * in different phases; 0 = choose by samples per lane, and the whole chip for a launch that finds nothing else in flight: default), "pipe_depth" (batches in flight,
  * 2..6; 0 = auto), "lds_block" (lanes per persistent workgroup of the LDS kernel, diagnostics),

@@ -148,7 +148,7 @@ struct mpt_ctx {
     int sah_inject_fail = 0;                          // test door: treat the device SAH pass as failed after it ran
     int sah_fallback = 0;                             // last build: the device SAH pass gave up (1: error, 2: depth) and the host pass ran
     int sah_build = -1;                               // SAH re-partition: 1 on the device (sah_build.hip), 0 host pass, -1 auto
-                                                      // (device above 32768 faces: the host's exact sweep is the better tree
+                                                      // (device above 131072 faces: the host's exact sweep is the better tree
                                                       // for small scenes and costs them milliseconds)
     void *sah_ws = nullptr; size_t sah_ws_bytes = 0;  // one allocation, carved up in build_sah_device
     int wide_build = 1;                               // 1: the 4-wide collapse runs on the device (wide_build.hip), 0: host pass

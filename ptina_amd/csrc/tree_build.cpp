@@ -537,7 +537,10 @@ static int build_tree_gpu(mpt_ctx *c) {
     c->tree_depth = depth;
     c->fast_depth = depth;
     c->host_tree_valid = false;
-    const bool sah_on_device = c->sah_build == 1 || (c->sah_build < 0 && n > 32768);
+    // auto: the host pass up to 131072 faces (its exact sweep of every range up to 8192 leaves is the better tree where ranges of
+    // 33 ... 8192 triangles matter -- BASELINE config 4: 9.44 against 9.63 node fetches per ray -- and costs 44 ms there), the device
+    // pass above (38 ms at a million faces against 220)
+    const bool sah_on_device = c->sah_build == 1 || (c->sah_build < 0 && n > 131072);
     c->sah_fallback = 0;
     if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max) {
         // SAH re-partition of the leaves: on the device (sah_build.hip: nothing comes back but the depth), or the host pass --
