@@ -15,6 +15,10 @@
 //     and identical for any slab split across GPUs.
 //   render_kernel_fast (any scene size): 256-lane workgroups, 4 waves per SIMD, scene records gathered
 //     from HBM / L2 / Infinity Cache, per-lane int32 traversal stack in LDS, [level][lane].
+//   After the loop a wave that has run out of work finalises finished tiles of the film -- sum of the frames, resolve, the image's
+//     write-out -- while the others drain (finalise_tiles): a launch that has the GPU to itself needs no combine pass.
+//   render_kernel_wide: 4-wide nodes with 8-bit child boxes (the product path for scenes that do not fit LDS); render_kernel_oct:
+//     8-wide octant-ordered nodes (option wide8; an A/B that lost 17-19 %, kept with its tests).
 //   render_kernel_lds (scenes whose node + triangle records fit the CU's 160 KiB LDS): measured on
 //     MI355X the gather version spends its time in the vector L1 -- a wave's node fetch touches up to 64
 //     different cache lines per load instruction, four instructions per node -- so one persistent
