@@ -755,7 +755,8 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     const size_t lds_bytes = ((((size_t)(c->nfaces - 1) * MPT_LDS_NODE_STRIDE + 15) >> 4) + (size_t)c->nfaces * 3 + (size_t)(c->caps.max_materials + 1) * 6) * sizeof(MptVec4) +
                              (((size_t)c->nfaces + 15) & ~(size_t)15) + (size_t)lds_stack * 1024 * sizeof(short);
     const bool lds_kernel = fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && c->caps.max_materials < 256 &&
-                            lds_bytes <= 160 * 1024;
+                            lds_bytes <= 160 * 1024 &&
+                            (size_t)(c->nfaces - 1) * (MPT_LDS_NODE_STRIDE / 8) < 32768;   // (the LDS copy's node ids are byte offsets / 8 in an int16 stack)
     // the same scene with the waves of the workgroup specialised and two path pools in LDS (render_pool.h): only the material
     // records the model uses, stacks for the tracer waves only, node records 72 bytes apart where that fits and 64 where not
     size_t pool_bytes = 0;

@@ -456,10 +456,15 @@ typedef __attribute__((address_space(3))) const char *LdsBytePtr;
 typedef __attribute__((address_space(3))) const unsigned char *LdsU8Ptr;
 #define MPT_LDS_MAT_VEC4 6      // float4 of a material record kept in LDS: p[0..15] and the derived terms d[0..7]
 
-struct LdsScene {
+// PRESCALED: the internal-node ids of the LDS copy (in the records and therefore on the stack) are the node's byte offset / 8, so
+// a NODE step forms its record address with one shift instead of a 32-bit integer multiply (quarter rate: four issue slots of the
+// ~50 a step has).  render_kernel_lds scales the ids while it copies the records (stride 72 -> id x 9 <= 32767: scenes that fit LDS do).
+template <bool PRESCALED>
+struct LdsSceneT {
 #ifndef MPT_SHADE_MIN_LDS
 #define MPT_SHADE_MIN_LDS 24
 #endif
+    static constexpr bool PRESCALED_IDS = PRESCALED;
     static constexpr int SHADE_MIN = MPT_SHADE_MIN_LDS; // SHADE waits until this many lanes want it (render_kernel.hip trace_stream)
     static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = true, LDS_MATS = true, OCT = false;
     LdsVec4Ptr fnode, tgeo;
@@ -478,7 +483,7 @@ struct LdsScene {
     // and 12 v_min / v_max fewer per step.
     DEV void node_planes(int i, int ox, int oy, int oz, mpt_f2 &nx, mpt_f2 &fx, mpt_f2 &ny, mpt_f2 &fy,
                          mpt_f2 &nz, mpt_f2 &fz, mpt_f2 &ids) const {
-        LdsBytePtr nd = (LdsBytePtr)fnode + i * nstride;
+        LdsBytePtr nd = (LdsBytePtr)fnode + (PRESCALED ? (i << 3) : i * nstride);
         LdsBytePtr ax = nd + ox, ay = nd + oy, az = nd + oz;
         nx = *(LdsVec2Ptr)ax;        fx = *(LdsVec2Ptr)(nd + (ox ^ 8));
         ny = *(LdsVec2Ptr)(ay + 16); fy = *(LdsVec2Ptr)(nd + 16 + (oy ^ 8));
@@ -494,6 +499,12 @@ struct LdsScene {
         g0 = lds_ld(g); g1 = lds_ld(g + 1); g2 = lds_ld(g + 2);
     }
 };
+
+typedef LdsSceneT<false> LdsScene;       // (the pooled A/B kernel: a run-time stride)
+#ifndef MPT_LDS_PRESCALED
+#define MPT_LDS_PRESCALED 1
+#endif
+typedef LdsSceneT<MPT_LDS_PRESCALED != 0> LdsSceneP;
 
 // 16-bit LIFO for the LDS-resident kernel (node ids fit in int16 there), [level][lane of 1024]
 #define MPT_LDS_BLOCK 1024

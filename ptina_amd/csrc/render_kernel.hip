@@ -1394,7 +1394,12 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
     if (tl && (threadIdx.x & 63) == 0) tl[0] = wall_clock64();
     {   // one copy of the scene per CU: coalesced 16-B loads, ds_write_b128
         for (int k = threadIdx.x; k < (p.n - 1) * 4; k += blockDim.x) {          // 8-byte stores: the records are 8-byte aligned
-            const MptVec4 v = p.fnode[k];
+            MptVec4 v = p.fnode[k];
+            if (LdsSceneP::PRESCALED_IDS && (k & 3) == 3) {                        // {id0, id1, -, -}: internal ids become byte offset / 8
+                const int i0 = __float_as_int(v.x), i1 = __float_as_int(v.y);
+                v.x = __int_as_float(i0 >= 0 ? i0 * (MPT_LDS_NODE_STRIDE / 8) : i0);
+                v.y = __int_as_float(i1 >= 0 ? i1 * (MPT_LDS_NODE_STRIDE / 8) : i1);
+            }
             float *d = (float *)((char *)smem + (k >> 2) * MPT_LDS_NODE_STRIDE + (k & 3) * 16);
             *(float2 *)d = make_float2(v.x, v.y); *(float2 *)(d + 2) = make_float2(v.z, v.w);
         }
@@ -1412,7 +1417,7 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
     __syncthreads();
     if (tl && (threadIdx.x & 63) == 0) tl[1] = wall_clock64();
 
-    LdsScene sc;
+    LdsSceneP sc;
     sc.fnode = (LdsVec4Ptr)(void *)smem;
     sc.tgeo = (LdsVec4Ptr)(void *)(smem + nnode4);
     sc.mats = (LdsVec4Ptr)(void *)(smem + nnode4 + ntri4);
