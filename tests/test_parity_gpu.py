@@ -1813,14 +1813,15 @@ def test_config4_full_scene_with_environment_vs_oracle(fresh, oracle_mod):
 
 
 def test_config3_eight_stripe_shares_reassemble_bit_identically(fresh):
-    '''BASELINE configs[2]'s film split as bench.py --gpus 8 splits it: 2048x2048, 32 spp, stripes of 16
-    columns dealt to 8 ranks (mpt_set_stripes(16, r, 8)); all eight shares rendered one after the other on
-    this GPU must reassemble into exactly the single-GPU film'''
+    '''BASELINE configs[2] AS STATED -- 2048x2048 at 256 spp (the tests ran it at 2 and 32) -- split as
+    bench.py --gpus 8 splits it: stripes of 16 columns dealt to 8 ranks (mpt_set_stripes(16, r, 8)); render(256) is eight
+    pipelined launches of 32 frames (the first finalises its own tiles, the others keep the combine pass); all eight shares
+    rendered one after the other on this GPU must reassemble into exactly the single-GPU film, every pixel counted 256 times'''
     from ptina_amd.things import FilmTable
     from ptina_amd.common import ctx, reset_all
     from ptina_amd.dist import stripe_columns
     from ptina_amd import _lib
-    n, spp, R = 2048, 32, 8
+    n, spp, R = 2048, 256, 8
     scene = scenes.scene_s978()
     eng = _engine(None, scene, n, n, mode='fast', max_filmsize=n * n)
     eng.render(spp)
