@@ -237,17 +237,22 @@ extern "C" int mpt_comm_selftest(mpt_ctx *c, int as_rank, int nranks, int root, 
     do {
         if (dev_alloc(&d_in, npix) || dev_alloc(&d_out, npix) || dev_alloc(&d_msg, (size_t)at) || dev_alloc(&d_msg2, (size_t)at) ||
             dev_alloc(&d_tab, (size_t)std::max(np, 1) * 2)) break;
-        if (hipMemcpy(d_in, film_in, npix * sizeof(MptVec4), hipMemcpyHostToDevice) != hipSuccess) { fail("selftest upload"); break; }
-        if (hipMemcpy(d_out, film_out, npix * sizeof(MptVec4), hipMemcpyHostToDevice) != hipSuccess) { fail("selftest upload"); break; }
+        // every copy on the context's own stream, the one the pack / scatter kernels run on: ordered by the stream itself and
+        // not by what a blocking copy on the null stream happens to have finished when it returns
+        if (hipMemcpyAsync(d_in, film_in, npix * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream) != hipSuccess) { fail("selftest upload"); break; }
+        if (hipMemcpyAsync(d_out, film_out, npix * sizeof(MptVec4), hipMemcpyHostToDevice, c->stream) != hipSuccess) { fail("selftest upload"); break; }
         if (np > 0) {
-            hipMemcpy(d_tab, pack.data(), (size_t)np * sizeof(MptPiece), hipMemcpyHostToDevice);
-            hipMemcpy(d_tab + np, scatter.data(), (size_t)np * sizeof(MptPiece), hipMemcpyHostToDevice);
+            if (hipMemcpyAsync(d_tab, pack.data(), (size_t)np * sizeof(MptPiece), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipMemcpyAsync(d_tab + np, scatter.data(), (size_t)np * sizeof(MptPiece), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                fail("selftest upload"); break;
+            }
             if (mpt_launch_copy_pieces(d_in, d_msg, d_tab, np, max_count, c->stream) != hipSuccess) { fail("selftest pack"); break; }
             hipMemcpyAsync(d_msg2, d_msg, (size_t)at * sizeof(MptVec4), hipMemcpyDeviceToDevice, c->stream);   // the "message"
             if (mpt_launch_copy_pieces(d_msg2, d_out, d_tab + np, np, max_count, c->stream) != hipSuccess) { fail("selftest scatter"); break; }
         }
         if (hipStreamSynchronize(c->stream) != hipSuccess) { fail("selftest sync"); break; }
-        if (hipMemcpy(film_out, d_out, npix * sizeof(MptVec4), hipMemcpyDeviceToHost) != hipSuccess) { fail("selftest download"); break; }
+        if (hipMemcpyAsync(film_out, d_out, npix * sizeof(MptVec4), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { fail("selftest download"); break; }
         rc = 0;
     } while (0);
     hipFree(d_in); hipFree(d_out); hipFree(d_msg); hipFree(d_msg2); hipFree(d_tab);

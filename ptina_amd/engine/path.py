@@ -14,10 +14,13 @@ from ..sampling.sobol import SobolSampler
 class PathEngine(metaclass=Singleton):
     def __init__(self):
         SobolSampler()
+        self._film_cls = None
 
     def render(self, nframes=1):
         '''reference path.py:75-77: one Sobol update + one sample per pixel, asynchronously.
         Consecutive calls are fused into one launch at the next read-back.'''
-        from ..filmtable import FilmTable
-        FilmTable()._hint()               # (where get_image() will want the image: a launch may write it while it drains)
+        if self._film_cls is None:
+            from ..filmtable import FilmTable
+            self._film_cls = FilmTable
+        self._film_cls()._hint()          # (where get_image() will want the image: a launch may write it while it drains)
         ctx().call('mpt_render', int(nframes))

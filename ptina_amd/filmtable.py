@@ -15,11 +15,15 @@ class FilmTable(metaclass=Singleton):
         self.size = size
         self.count = count
         self._next = None             # the array the next get_image(0) will return, already known to the library (_hint)
+        self._size = None
 
     def _res(self):
-        nx, ny = C.c_int(0), C.c_int(0)
-        ctx().call('mpt_get_size', C.byref(nx), C.byref(ny))
-        return nx.value, ny.value
+        # (the size only changes through set_size below: remembered, so that render() / get_image() do not ask the library twice a step)
+        if self._size is None:
+            nx, ny = C.c_int(0), C.c_int(0)
+            ctx().call('mpt_get_size', C.byref(nx), C.byref(ny))
+            self._size = (nx.value, ny.value)
+        return self._size
 
     @property
     def nx(self):
@@ -31,6 +35,7 @@ class FilmTable(metaclass=Singleton):
 
     def set_size(self, nx, ny):
         ctx().call('mpt_set_size', int(nx), int(ny))
+        self._size = (int(nx), int(ny))
 
     def clear(self, id=0):
         '''zeroes every pass whatever `id` says, as the reference does (filmtable.py:44-45)'''

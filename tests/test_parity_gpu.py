@@ -1812,6 +1812,16 @@ def test_config4_full_scene_with_environment_vs_oracle(fresh, oracle_mod):
     reset_all()
 
 
+def _same_film(a, b, what):
+    '''bit equality of two films (columns, rows, 4), saying where they differ when they do'''
+    d = (np.ascontiguousarray(a).view(np.uint32) != np.ascontiguousarray(b).view(np.uint32)).any(axis=-1)
+    if not d.any():
+        return True
+    cx, cy = np.nonzero(d)
+    pytest.fail('%s differs in %d pixels: columns %d..%d, rows %d..%d, first (%d, %d) %s vs %s' % (
+        what, len(cx), cx.min(), cx.max(), cy.min(), cy.max(), cx[0], cy[0], a[cx[0], cy[0]], b[cx[0], cy[0]]))
+
+
 def test_config3_eight_stripe_shares_reassemble_bit_identically(fresh):
     '''BASELINE configs[2] AS STATED -- 2048x2048 at 256 spp (the tests ran it at 2 and 32) -- split as
     bench.py --gpus 8 splits it: stripes of 16 columns dealt to 8 ranks (mpt_set_stripes(16, r, 8)); render(256) is eight
@@ -1836,6 +1846,7 @@ def test_config3_eight_stripe_shares_reassemble_bit_identically(fresh):
         part = FilmTable().get_raw().reshape(n, n, 4)
         cols = stripe_columns(n, R, r)
         assert np.all(part[np.setdiff1d(np.arange(n), cols)] == 0)
+        assert _same_film(part[cols], full[cols], 'share %d as rendered' % r)
         if r == 0:
             tiled[cols] = part[cols]                      # the root's own share is already in its film
         else:
@@ -1845,7 +1856,7 @@ def test_config3_eight_stripe_shares_reassemble_bit_identically(fresh):
             ctx().call('mpt_comm_selftest', r, R, 0, _lib.fptr(np.ascontiguousarray(part.reshape(-1, 4))), _lib.fptr(flat))
             tiled = flat.reshape(n, n, 4)
     reset_all()
-    assert np.array_equal(tiled, full)
+    assert _same_film(tiled, full, 'the reassembled film')
 
 
 @pytest.mark.parametrize('world', [2, 3, 8])
