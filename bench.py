@@ -91,7 +91,7 @@ def is_counting_kernel(name):
 def render_kernel_name(mode, last_kernel):
     if mode != 'fast':
         return 'render_kernel_strict'
-    return ('render_kernel_fast', 'render_kernel_lds', 'render_kernel_wide', 'render_kernel_pool', 'render_kernel_oct')[last_kernel]
+    return ('render_kernel_fast', 'render_kernel_lds', 'render_kernel_wide', 'render_kernel_pool', 'render_kernel_oct', 'render_kernel_lds4')[last_kernel]
 
 
 def collect_pmc(argv_tail, budget_s=150):

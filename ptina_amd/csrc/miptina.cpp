@@ -287,6 +287,9 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->count = value ? 1 : 0;
     } else if (k == "lds") {
         c->use_lds = value ? 1 : 0;
+    } else if (k == "lds_wide") {
+        if (value != 0 && value != 1) return fail("lds_wide must be 0 or 1");
+        c->lds_wide = value;
     } else if (k == "zero_copy") {
         c->zero_copy = value ? 1 : 0;
     } else if (k == "skip_dark") {
@@ -369,6 +372,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "gpu_build") *value = c->gpu_build;
     else if (k == "pending") *value = c->pending;
     else if (k == "lds") *value = c->use_lds;
+    else if (k == "lds_wide") *value = c->lds_wide;
     else if (k == "lds_block") *value = c->lds_block;
     else if (k == "zero_copy") *value = c->zero_copy;
     else if (k == "wide8") *value = c->use_wide8;
@@ -394,6 +398,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "sah_build") *value = c->sah_build;
     else if (k == "sah_fallback") *value = c->sah_fallback;
     else if (k == "wide_nodes") *value = c->wide_nodes;
+    else if (k == "wide_stack") *value = c->wide_stack;
     else if (k == "wide_ratio_permille") *value = (int)(c->wide_ratio * 1000.f + 0.5f);
     else if (k == "wide_depth") *value = c->wide_depth;
     else if (k == "nranks") *value = c->nranks;
@@ -663,7 +668,7 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     p.ntiles = p.tiles_x * p.tiles_y;
     memcpy(p.world_fac, c->world_fac, sizeof p.world_fac);
     memcpy(p.v2w, c->v2w, sizeof p.v2w);
-    p.wnode = c->wnode; p.qnode = c->qnode; p.onode = nullptr; p.stack_spill = nullptr;
+    p.wnode = c->wnode; p.qnode = c->qnode; p.nwide = c->wide_nodes; p.onode = nullptr; p.stack_spill = nullptr;
     p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade; p.tfast = c->tfast;
     p.default_mtl = c->caps.max_materials;
     p.skip_dark = c->skip_dark >= 0 ? c->skip_dark : (c->mode == MPT_MODE_FAST ? 1 : 0);
@@ -754,9 +759,19 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     // + the material records (96 B each, the default one last) and one byte per triangle naming its record
     const size_t lds_bytes = ((((size_t)(c->nfaces - 1) * MPT_LDS_NODE_STRIDE + 15) >> 4) + (size_t)c->nfaces * 3 + (size_t)(c->caps.max_materials + 1) * 6) * sizeof(MptVec4) +
                              (((size_t)c->nfaces + 15) & ~(size_t)15) + (size_t)lds_stack * 1024 * sizeof(short);
-    const bool lds_kernel = fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && c->caps.max_materials < 256 &&
-                            lds_bytes <= 160 * 1024 &&
-                            (size_t)(c->nfaces - 1) * (MPT_LDS_NODE_STRIDE / 8) < 32768;   // (the LDS copy's node ids are byte offsets / 8 in an int16 stack)
+    // ... or the 4-wide nodes with exact boxes (option "lds_wide"): seven float4 of a wnode record MPT_LDS4_NODE_STRIDE apart, one
+    // triangle record more (the unused slots' leaf), only the material records the model uses (+ the default one), and every
+    // stack level the tree can ask for (a step leaves up to three entries behind)
+    const int lds4_nmats = c->max_mtlid + 1;
+    const size_t lds4_bytes = ((size_t)c->wide_nodes * (MPT_LDS4_NODE_STRIDE / 16) + ((size_t)c->nfaces + 1) * 3 + (size_t)(lds4_nmats + 1) * 6) * sizeof(MptVec4) +
+                              (((size_t)c->nfaces + 15) & ~(size_t)15) + (size_t)c->wide_stack * 1024 * sizeof(short);
+    const bool lds4_kernel = fast && c->use_lds && c->lds_wide && c->use_wide && !c->use_pool && c->wide_nodes > 0 && c->wide_stack > 0 && c->wnode &&
+                             c->nfaces >= 2 && c->nfaces < 32767 && lds4_nmats < 255 && lds4_bytes <= 160 * 1024 &&
+                             (size_t)c->wide_nodes * (MPT_LDS4_NODE_STRIDE / 8) < 32768;
+    const bool lds_kernel = lds4_kernel ||
+                            (fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && c->caps.max_materials < 256 &&
+                             lds_bytes <= 160 * 1024 &&
+                             (size_t)(c->nfaces - 1) * (MPT_LDS_NODE_STRIDE / 8) < 32768);   // (the LDS copy's node ids are byte offsets / 8 in an int16 stack)
     // the same scene with the waves of the workgroup specialised and two path pools in LDS (render_pool.h): only the material
     // records the model uses, stacks for the tracer waves only, node records 72 bytes apart where that fits and 64 where not
     size_t pool_bytes = 0;
@@ -803,6 +818,7 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         size_t need = (size_t)B * (size_t)ccols * c->ny;
         // every slot of the ring at once: an allocation synchronises the device, so it must not
         // happen again on the second, third, ... batch of a run
+        bool zeroed = false;
         for (int q = 0; q < c->cur_depth; q++)
             if (need > c->partial2_cap[q]) {
                 HIP_TRY(hipDeviceSynchronize());
@@ -810,9 +826,15 @@ extern "C" int mpt_flush(mpt_ctx *c) {
                 if (dev_alloc(&c->partial2[q], need)) return 1;
                 c->partial2_cap[q] = need;
                 // the w of a slab entry is its ready flag for the tail finalisation (the launch's tag): fresh memory must not
-                // hold one by accident
-                HIP_TRY(hipMemset(c->partial2[q], 0, need * sizeof(MptVec4)));
+                // hold one by accident -- and it does: the allocator hands back the slab of an earlier context, whose first
+                // finalising launch used the very tag this context's first one will use
+                HIP_TRY(hipMemsetAsync(c->partial2[q], 0, need * sizeof(MptVec4), c->stream));
+                zeroed = true;
             }
+        // ... and the zeros must be there before any launch of the ring writes or reads the slab: the render streams are not
+        // ordered behind the stream that zeroes, and a memset may return before it is done.  (Seen in the full GPU test run as a
+        // 2048 x 2048 film with single samples of an earlier test's render in it: its 2 GiB slabs take a millisecond to zero.)
+        if (zeroed) HIP_TRY(hipStreamSynchronize(c->stream));
         p.partial = c->partial2[k];
         p.work_counter = c->d_work2[k];
         if (!use_spec) {
@@ -903,7 +925,8 @@ extern "C" int mpt_flush(mpt_ctx *c) {
             HIP_TRY(hipDeviceSynchronize());
             hipFree(c->d_timeline); c->d_timeline = nullptr;
             if (dev_alloc(&c->d_timeline, (size_t)waves * MPT_TIMELINE_WORDS)) return 1;
-            HIP_TRY(hipMemset(c->d_timeline, 0, (size_t)waves * MPT_TIMELINE_WORDS * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(c->d_timeline, 0, (size_t)waves * MPT_TIMELINE_WORDS * sizeof(unsigned long long), c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
             c->timeline_waves = waves;
         }
         p.timeline = c->d_timeline;
@@ -946,11 +969,12 @@ extern "C" int mpt_flush(mpt_ctx *c) {
 #if MPT_WITH_POOL
     else if (pool_kernel) HIP_TRY(mpt_launch_render_pool(&p, launch_cus, 1024, pool_bytes, c->count, rs));
 #endif
+    else if (lds4_kernel) HIP_TRY(mpt_launch_render_lds4(&p, launch_cus, lds_block_used, lds4_bytes, c->count, rs));
     else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, launch_cus, lds_block_used, lds_bytes, c->count, rs));
     else if (oct_kernel) HIP_TRY(mpt_launch_render_oct(&p, wide_blocks, c->count, rs));
     else if (wide_kernel) HIP_TRY(mpt_launch_render_wide(&p, wide_blocks, c->count, c->use_quant, rs));
     else HIP_TRY(mpt_launch_render_fast(&p, launch_cus, stack, c->count, rs));
-    c->last_kernel = pool_kernel ? 3 : lds_kernel ? 1 : oct_kernel ? 4 : wide_kernel ? 2 : 0;
+    c->last_kernel = pool_kernel ? 3 : lds4_kernel ? 5 : lds_kernel ? 1 : oct_kernel ? 4 : wide_kernel ? 2 : 0;
     HIP_TRY(hipEventRecord(e1, rs));
     c->events.push_back({ e0, e1 });
     if (c->events.size() > 4096) {

@@ -26,6 +26,7 @@ MPT_KERNEL_API hipError_t mpt_launch_derive_tfast(const MptVec4 *tgeo, MptVec4 *
 MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int quant, int *blocks);
 MPT_KERNEL_API hipError_t mpt_launch_render_wide(const MptRenderParams *, int blocks, int count, int quant, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
+MPT_KERNEL_API hipError_t mpt_launch_render_lds4(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
 MPT_KERNEL_API hipError_t mpt_launch_render_pool(const MptRenderParams *, int grid, int block, size_t lds_bytes, int count, hipStream_t);
 MPT_KERNEL_API size_t mpt_pool_lds_overhead(void);
 MPT_KERNEL_API hipError_t mpt_launch_preview_fast(const MptRenderParams *, int grid, int stack, hipStream_t);
@@ -96,6 +97,7 @@ struct mpt_ctx {
 
     // options
     int mode = MPT_MODE_FAST, batch = 32, chunk = 0, count = 0, use_lds = 1, lds_block = 0, zero_copy = 1;
+    int lds_wide = 1;                                 // 1: scenes that fit LDS beside them walk the 4-wide nodes there (render_kernel_lds4), 0: the binary ones (render_kernel_lds)
     int skip_dark = -1;                  // -1 auto (production build on, strict build off), 0 / 1 as set: do not trace shadow rays whose candidate direct light is exactly zero (production build: default;
                                          // the strict build traces them like the reference unless the option is set explicitly to 1 there)
     int use_pool = 0, pool_shaders = 3;  // LDS kernel with specialised waves and path pools (render_pool.h)
@@ -142,7 +144,8 @@ struct mpt_ctx {
     MptVec4 *qnode = nullptr; size_t qnode_cap = 0;   // the same nodes, child boxes quantised to 8 bits, 4 float4 each
     int use_quant = 1;
     MptVec4 *wnode = nullptr; size_t wnode_cap = 0;   // 4-wide nodes of the fast tree (gather kernel), 8 float4 each
-    int wide_nodes = 0, wide_depth = 0;               // 0 nodes: not built (scene fits LDS, or too deep)
+    int wide_nodes = 0, wide_depth = 0;               // 0 nodes: not built (too deep)
+    int wide_stack = 0;                               // stack levels a traversal of the 4-wide tree can ask for (exact from the host pass, 3 x depth + 2 from the device pass)
     float wide_ratio = 1.f;                           // expected fetches per ray, wide / binary (surface-area sums)
     int sah_exact_max = 8192;                         // host SAH pass: ranges up to this size are swept exactly (diagnostics)
     int sah_inject_fail = 0;                          // test door: treat the device SAH pass as failed after it ran

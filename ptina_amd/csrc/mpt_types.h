@@ -96,6 +96,9 @@ struct MptImage { int32_t nx, ny, base, pad; };   // image.py:14-16
 #ifndef MPT_LDS_NODE_STRIDE
 #define MPT_LDS_NODE_STRIDE 72
 #endif
+#ifndef MPT_LDS4_NODE_STRIDE
+#define MPT_LDS4_NODE_STRIDE 112     // bytes between the 4-wide node records in LDS (render_kernel_lds4: seven float4 of a wnode record)
+#endif
 
 struct MptRenderParams {
     int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders
@@ -104,7 +107,8 @@ struct MptRenderParams {
     int32_t tiles_y, ntiles;
     int32_t fnode_soa_n;                    // 0, or the node count when fnode holds the SoA transpose (layout A/B)
     float sobol_inv_dim;                    // 1 / sobol_dim (quotient estimate of the draw index reduction)
-    int32_t nitems, tile_w_shift, tile_h_shift, pad2;   // fast build: (2^w x 2^h tile, chunk) work items of this launch
+    int32_t nitems, tile_w_shift, tile_h_shift;   // fast build: (2^w x 2^h tile, chunk) work items of this launch
+    int32_t nwide;                          // records of qnode (render_kernel_lds4 copies them into LDS)
     // columns rendered: x = x0 + s*stripe_pitch + w, w < stripe_w, x < x1 (one contiguous slab: stripe_w = 2^30)
     int32_t stripe_w, stripe_pitch;
     int32_t partial_stride;

@@ -257,9 +257,22 @@ struct Stack {
     DEV int peek(int at) const { return base[at * MPT_BLOCK]; }
 };
 
+// extra NODE steps behind one scheduling decision of trace_stream (render_kernel.hip), per kind of scene (SCENE::NODE_REP)
+#ifndef MPT_NODE_REP
+#define MPT_NODE_REP 2        // extra NODE steps per decision (MI355X: 0 / 1 / 2 / 3 -> 4.03 / 3.85 / 3.72 / 3.72 ms with one extra LEAF step)
+#endif
+#ifndef MPT_WIDE_REP
+#define MPT_WIDE_REP 0        // extra 4-wide NODE steps per decision (gather kernels)
+#endif
+#ifndef MPT_LDS4_REP
+#define MPT_LDS4_REP 1        // ... of the LDS-resident 4-wide kernel
+#endif
+
 // scene records served from HBM/L2 through the vector L1 (any scene size)
 struct GlobalScene {
+    static constexpr bool AVOID_IN_LEAF = false;
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
+    static constexpr int NODE_REP = MPT_NODE_REP;
     static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
     const MptVec4 *fnode, *tgeo;
     int soa_n;                 // node count, for the layout A/B build below
@@ -284,7 +297,9 @@ struct GlobalScene {
 // those fetches, not their bytes, are what bounds the big scenes (measured: binary16 boxes at half the bytes
 // bought 3-7 %)
 struct WideScene {
+    static constexpr bool AVOID_IN_LEAF = false;
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
+    static constexpr int NODE_REP = MPT_WIDE_REP;
     static constexpr bool WIDE = true, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
     const MptVec4 *wnode, *tgeo;
     // entry (n*) and exit (f*) planes of the four children, picked by the ray's direction signs: o* is 0 for a ray
@@ -334,7 +349,9 @@ struct WideScene {
 // for is the number of divergent gathers, not bytes -- and the 36 extra VALU instructions of the decode are free
 // at 34-43 % issue utilisation.
 struct QuantScene {
+    static constexpr bool AVOID_IN_LEAF = false;
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
+    static constexpr int NODE_REP = MPT_WIDE_REP;      // extra NODE steps per scheduling decision
     static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
     const MptVec4 *qnode, *tgeo;
     DEV void node4q(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &id) const {
@@ -373,6 +390,9 @@ struct SpillStack {
 #define MPT_X_SPILL_CAP 24     // (a test build sets it to a handful of levels so that every ray uses the global strip)
 #endif
     static constexpr int CAP = MPT_X_SPILL_CAP, SPILL = 128 - CAP;    // 24 levels x 256 lanes x 4 B = 24 KiB of LDS: the five workgroups per CU the registers allow (and a sixth)
+    static constexpr int STRIDE = MPT_BLOCK;           // entries from one level of a lane's stack to the next
+    typedef int entry_t;
+    static constexpr bool NO_SPILL = false;
     int *base;                 // &lds[threadIdx.x]
     int *spill;                // the launch's strips (wave-uniform: stays in scalar registers) ...
     unsigned lane_off;         // ... and this lane's first entry in them: one register instead of a 64-bit pointer per lane
@@ -394,7 +414,9 @@ struct SpillStack {
 // eight box tests; the order the children are met in is slot XOR the ray's direction octant -- no sort -- and a node leaves at most
 // two stack entries behind (its other internal hits, its other leaf hits), each a (base | mask, slots to go) pair
 struct OctScene {
+    static constexpr bool AVOID_IN_LEAF = false;
     static constexpr int SHADE_MIN = 0;
+    static constexpr int NODE_REP = 0;
     static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false, OCT = true;
     const MptVec4 *onode, *tgeo;                       // tgeo: tfast8, the 48-byte records in the 8-wide tree's leaf order
     DEV void node8(int i, MptVec4 &h0, MptVec4 &h1, MptVec4 &px, MptVec4 &py, MptVec4 &pz) const {
@@ -465,6 +487,8 @@ struct LdsSceneT {
 #define MPT_SHADE_MIN_LDS 24
 #endif
     static constexpr bool PRESCALED_IDS = PRESCALED;
+    static constexpr bool AVOID_IN_LEAF = false;
+    static constexpr int NODE_REP = MPT_NODE_REP;
     static constexpr int SHADE_MIN = MPT_SHADE_MIN_LDS; // SHADE waits until this many lanes want it (render_kernel.hip trace_stream)
     static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = true, LDS_MATS = true, OCT = false;
     LdsVec4Ptr fnode, tgeo;
@@ -516,6 +540,57 @@ struct Stack16 {
     DEV void push(int v) { base[sp * MPT_LDS_BLOCK] = (short)v; sp++; }
     DEV int pop() { sp--; return (int)base[sp * MPT_LDS_BLOCK]; }
     static constexpr bool PEEK = true;
+    DEV int peek(int at) const { return (int)base[at * MPT_LDS_BLOCK]; }
+};
+
+// The 4-wide nodes with exact boxes resident in LDS (render_kernel_lds4): the first seven float4 of a wnode record -- {lo.x[4]}
+// {hi.x[4]}{lo.y[4]}{hi.y[4]}{lo.z[4]}{hi.z[4]}{id[4]} -- MPT_LDS4_NODE_STRIDE = 112 bytes apart (a ds_read_b128 is served sixteen
+// lanes at a time over sixteen 16-byte bank groups: piece k of record i starts on group (7 i + k) mod 16, sixteen positions), the
+// internal ids as byte offset / 8.  The entry planes of an axis are the 16 bytes at offset 0 for a ray going up the axis and at 16
+// for one going down, the exit planes the other 16: no decode, no min / max, no select -- what the 8-bit nodes of the gather
+// kernels pay 39 VALU instructions a step for, to save gathers this kernel does not make
+#ifndef MPT_LDS4_AVOID_IN_LEAF
+#define MPT_LDS4_AVOID_IN_LEAF 1   // the triangle a ray left from is filtered by the LEAF step (one compare) instead of by the NODE step (four)
+#endif
+struct LdsWideScene {
+    static constexpr bool PRESCALED_IDS = true;
+    static constexpr bool AVOID_IN_LEAF = MPT_LDS4_AVOID_IN_LEAF != 0;
+    static constexpr int NODE_REP = MPT_LDS4_REP;
+    static constexpr int SHADE_MIN = MPT_SHADE_MIN_LDS;
+    static constexpr bool WIDE = true, QUANT = false, SIGNED_PLANES = false, LDS_MATS = true, OCT = false;
+    LdsVec4Ptr wnode, tgeo, mats;
+    LdsU8Ptr mtl;
+    int mat_last, mat_default;
+    DEV void node4(int i, int ox, int oy, int oz, MptVec4 &nx, MptVec4 &fx, MptVec4 &ny, MptVec4 &fy, MptVec4 &nz, MptVec4 &fz,
+                   MptVec4 &id) const {
+        LdsBytePtr nd = (LdsBytePtr)wnode + (i << 3);
+        nx = lds_ld((LdsVec4Ptr)(nd + ox));      fx = lds_ld((LdsVec4Ptr)(nd + (ox ^ 16)));
+        ny = lds_ld((LdsVec4Ptr)(nd + 32 + oy)); fy = lds_ld((LdsVec4Ptr)(nd + 32 + (oy ^ 16)));
+        nz = lds_ld((LdsVec4Ptr)(nd + 64 + oz)); fz = lds_ld((LdsVec4Ptr)(nd + 64 + (oz ^ 16)));
+        id = lds_ld((LdsVec4Ptr)(nd + 96));
+    }
+    DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2) const {
+        LdsVec4Ptr g = tgeo + slot * 3;
+        g0 = lds_ld(g); g1 = lds_ld(g + 1); g2 = lds_ld(g + 2);
+    }
+};
+
+// its LIFO: 16-bit entries, [level][lane of 1024], as many levels as the tree can ask for (3 x depth + 2, the host checks): a
+// step's three pushes are plain stores, nothing spills
+#ifndef MPT_LDS4_PLANE_OFF
+#define MPT_LDS4_PLANE_OFF 0       // 16: the ray carries the offsets of its entry planes (three registers); 0: the step reads the signs off 1/d
+#endif
+struct Stack16W {
+    static constexpr int SENTINEL = -32768;
+    static constexpr int PLANE_OFF = MPT_LDS4_PLANE_OFF;
+    static constexpr int CAP = 1 << 20, STRIDE = MPT_LDS_BLOCK;
+    static constexpr bool NO_SPILL = true;
+    typedef short entry_t;
+    LdsShortPtr base;          // &lds16[threadIdx.x]
+    int sp;
+    DEV void push(int v) { base[sp * MPT_LDS_BLOCK] = (short)v; sp++; }
+    DEV int pop() { sp--; return (int)base[sp * MPT_LDS_BLOCK]; }
+    static constexpr bool PEEK = true;                 // (the LEAF step reads the entry it will pop together with its triangle)
     DEV int peek(int at) const { return (int)base[at * MPT_LDS_BLOCK]; }
 };
 

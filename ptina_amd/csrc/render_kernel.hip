@@ -462,6 +462,9 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
 // record, the children that are hit sorted
 // by entry distance (a five-comparator network on (distance bits, id) pairs; a miss sorts last), the nearest
 // taken next and the others pushed farthest first.
+#ifndef MPT_SORT_PACKED
+#define MPT_SORT_PACKED 1     // the 4-wide step of the LDS-resident kernel sorts (distance bits | 16-bit id) words (0: (key, id) pairs)
+#endif
 template <bool COUNT, class SCENE, class STACK>
 DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     int id0, id1, id2, id3;
@@ -495,8 +498,9 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
 #undef MPT_UB
     } else {
         MptVec4 nx, fx, ny, fy, nz, fz, idv;
-        sc.node4(L.curr, __float_as_int(L.inv.x) < 0 ? 16 : 0, __float_as_int(L.inv.y) < 0 ? 16 : 0, __float_as_int(L.inv.z) < 0 ? 16 : 0,
-                 nx, fx, ny, fy, nz, fz, idv);
+        if constexpr (STACK::PLANE_OFF != 0) sc.node4(L.curr, L.offx, L.offy, L.offz, nx, fx, ny, fy, nz, fz, idv);     // (per-ray constants)
+        else sc.node4(L.curr, __float_as_int(L.inv.x) < 0 ? 16 : 0, __float_as_int(L.inv.y) < 0 ? 16 : 0, __float_as_int(L.inv.z) < 0 ? 16 : 0,
+                      nx, fx, ny, fy, nz, fz, idv);
         id0 = __float_as_int(idv.x); id1 = __float_as_int(idv.y); id2 = __float_as_int(idv.z); id3 = __float_as_int(idv.w);
 #define MPT_SLAB(c, tn, h)                                                                                              \
         tn = fmaxf(fmaxf(__builtin_fmaf(nx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(ny.c, L.inv.y, -L.oinv.y)),            \
@@ -509,25 +513,43 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     // entry distances are >= 0, so their bit patterns order like the values; a miss (or the triangle the ray
     // left from, lbvh.py:329) gets the largest key
     const unsigned MISS = 0xffffffffu;
-    unsigned k0 = (h0 && id0 != L.navoid) ? (unsigned)__float_as_int(t0) : MISS;
-    unsigned k1 = (h1 && id1 != L.navoid) ? (unsigned)__float_as_int(t1) : MISS;
-    unsigned k2 = (h2 && id2 != L.navoid) ? (unsigned)__float_as_int(t2) : MISS;
-    unsigned k3 = (h3 && id3 != L.navoid) ? (unsigned)__float_as_int(t3) : MISS;
+    unsigned k0, k1, k2, k3;
+    if constexpr (MPT_SORT_PACKED && sizeof(typename STACK::entry_t) == 2) {
+        // 16-bit ids (the LDS-resident kernel): the upper half of the distance's bits over the id is ONE word that sorts with
+        // v_min_u32 / v_max_u32 -- ten instructions instead of the 25 of five compare-and-swaps on (key, id) pairs; distances that
+        // agree in their first 8 mantissa bits are met in id order, which costs a step now and then and never a hit (the
+        // order only decides what is looked at first)
+        if constexpr (!SCENE::AVOID_IN_LEAF) { h0 = h0 && id0 != L.navoid; h1 = h1 && id1 != L.navoid; h2 = h2 && id2 != L.navoid; h3 = h3 && id3 != L.navoid; }
+        k0 = h0 ? __builtin_amdgcn_perm((unsigned)__float_as_int(t0), (unsigned)id0, 0x07060100u) : MISS;
+        k1 = h1 ? __builtin_amdgcn_perm((unsigned)__float_as_int(t1), (unsigned)id1, 0x07060100u) : MISS;
+        k2 = h2 ? __builtin_amdgcn_perm((unsigned)__float_as_int(t2), (unsigned)id2, 0x07060100u) : MISS;
+        k3 = h3 ? __builtin_amdgcn_perm((unsigned)__float_as_int(t3), (unsigned)id3, 0x07060100u) : MISS;
+        const unsigned a0 = min(k0, k1), a1 = max(k0, k1), b0 = min(k2, k3), b1 = max(k2, k3);
+        const unsigned m0 = max(a0, b0), m1 = min(a1, b1);
+        k0 = min(a0, b0); k3 = max(a1, b1); k1 = min(m0, m1); k2 = max(m0, m1);
+        id0 = (int)(short)(k0 & 0xffffu); id1 = (int)k1; id2 = (int)k2; id3 = (int)k3;      // (the pushes store the low halves)
+    } else {
+        k0 = (h0 && id0 != L.navoid) ? (unsigned)__float_as_int(t0) : MISS;
+        k1 = (h1 && id1 != L.navoid) ? (unsigned)__float_as_int(t1) : MISS;
+        k2 = (h2 && id2 != L.navoid) ? (unsigned)__float_as_int(t2) : MISS;
+        k3 = (h3 && id3 != L.navoid) ? (unsigned)__float_as_int(t3) : MISS;
 #define MPT_CSWAP(ka, ia, kb, ib) { bool sw = kb < ka; unsigned tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
                                     int ti_ = sw ? ib : ia; ib = sw ? ia : ib; ia = ti_; }
-    MPT_CSWAP(k0, id0, k1, id1) MPT_CSWAP(k2, id2, k3, id3) MPT_CSWAP(k0, id0, k2, id2) MPT_CSWAP(k1, id1, k3, id3)
-    MPT_CSWAP(k1, id1, k2, id2)
+        MPT_CSWAP(k0, id0, k1, id1) MPT_CSWAP(k2, id2, k3, id3) MPT_CSWAP(k0, id0, k2, id2) MPT_CSWAP(k1, id1, k3, id3)
+        MPT_CSWAP(k1, id1, k2, id2)
 #undef MPT_CSWAP
+    }
     int next = id0;
-    if (__ballot(L.sp > STACK::CAP - 3) == 0ull) {
-        // no lane of the wave is within three entries of the LDS part of its stack (the rule, not the exception):
-        // the three pushes are plain stores at a running index -- a store that is not wanted lands on the slot
-        // the next one overwrites -- instead of three divergent regions with a spill test each
+    if (STACK::NO_SPILL || __ballot(L.sp > STACK::CAP - 3) == 0ull) {
+        // no lane of the wave is within three entries of the LDS part of its stack (the rule, not the exception; the LDS-resident
+        // kernel's stack holds every level the tree can ask for): the three pushes are plain stores at a running index -- a store
+        // that is not wanted lands on the slot the next one overwrites -- instead of three divergent regions with a spill test each
+        typedef typename STACK::entry_t entry_t;
         int sp = L.sp;
-        stk.base[sp * MPT_BLOCK] = id3; sp += k3 != MISS ? 1 : 0;
-        stk.base[sp * MPT_BLOCK] = id2; sp += k2 != MISS ? 1 : 0;
-        stk.base[sp * MPT_BLOCK] = id1; sp += k1 != MISS ? 1 : 0;
-        if (k0 == MISS) { sp--; next = stk.base[sp * MPT_BLOCK]; }           // sorted: then nothing was pushed
+        stk.base[sp * STACK::STRIDE] = (entry_t)id3; sp += k3 != MISS ? 1 : 0;
+        stk.base[sp * STACK::STRIDE] = (entry_t)id2; sp += k2 != MISS ? 1 : 0;
+        stk.base[sp * STACK::STRIDE] = (entry_t)id1; sp += k1 != MISS ? 1 : 0;
+        if (k0 == MISS) { sp--; next = (int)stk.base[sp * STACK::STRIDE]; }           // sorted: then nothing was pushed
         L.sp = sp;
     } else {
         stk.sp = L.sp;
@@ -675,7 +697,9 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     MptVec4 g0, g1, g2;
     sc.tri(slot, g0, g1, g2);
     float dd, su, sv;
-    if (tri_test_fast(g0, g1, g2, L.to, L.td, &dd, &su, &sv)) {
+    bool hit = tri_test_fast(g0, g1, g2, L.to, L.td, &dd, &su, &sv);
+    if constexpr (SCENE::AVOID_IN_LEAF) hit = hit && L.curr != L.navoid;    // the triangle the ray left from (lbvh.py:329): the NODE step let it through
+    if (hit) {
         if (L.shadow) {
             if (dd <= L.tbest) { L.hidx = slot; stop = true; }              // path.py:51: any occluder within li.dis
         } else if (dd < L.tbest) {                                          // lbvh.py:331
@@ -837,12 +861,6 @@ DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(by
 #define MPT_LEAVE_A 2    // leave traversal mode when traversing * A < waiting * B
 #define MPT_LEAVE_B 1
 #endif
-#ifndef MPT_NODE_REP
-#define MPT_NODE_REP 2        // extra NODE steps per decision (MI355X: 0 / 1 / 2 / 3 -> 4.03 / 3.85 / 3.72 / 3.72 ms with one extra LEAF step)
-#endif
-#ifndef MPT_WIDE_REP
-#define MPT_WIDE_REP 0        // extra 4-wide NODE steps per decision (gather kernels)
-#endif
 #ifndef MPT_LEAF_REP
 #define MPT_LEAF_REP 1        // extra LEAF steps per decision (0 / 1 / 2 -> 3.83 / 3.72 / 3.77 ms with two extra NODE steps)
 #endif
@@ -961,28 +979,18 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                     else if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
                     else stage_node<COUNT>(sc, stk, L, cnt);
                 }
-#if MPT_NODE_REP
                 // further steps for the lanes that are still at a node, without counting again: the three ballots
                 // and the decision chain in front of every step cost a wave about as many cycles as half a step
-                if constexpr (!SCENE::WIDE) {
 #pragma unroll
-                    for (int rep = 0; rep < MPT_NODE_REP; rep++) {
-                        if (__ballot(L.st == ST_NODE) == 0ull) break;
-                        if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
-                        if (L.st == ST_NODE) stage_node<COUNT>(sc, stk, L, cnt);
+                for (int rep = 0; rep < SCENE::NODE_REP; rep++) {
+                    if (__ballot(L.st == ST_NODE) == 0ull) break;
+                    if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
+                    if (L.st == ST_NODE) {
+                        if constexpr (SCENE::OCT) stage_node8<COUNT>(sc, stk, L, cnt);
+                        else if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
+                        else stage_node<COUNT>(sc, stk, L, cnt);
                     }
                 }
-#if MPT_WIDE_REP
-                else {
-#pragma unroll
-                    for (int rep = 0; rep < MPT_WIDE_REP; rep++) {
-                        if (__ballot(L.st == ST_NODE) == 0ull) break;
-                        if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
-                        if (L.st == ST_NODE) stage_node4<COUNT>(sc, stk, L, cnt);
-                    }
-                }
-#endif
-#endif
                 MPT_STAMP_END(acc_node)
             } else {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
@@ -1437,6 +1445,65 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds(const MptRend
 #endif
     flush_counters<COUNT>(p, cnt);
 }
+
+// ---------------------------------------------------------------- LDS-resident persistent kernel over the 4-wide nodes
+// dynamic LDS: [ nwide node records of MPT_LDS4_NODE_STRIDE bytes | (n+1)*3 triangle float4 (tfast; record n: the unused slots' NaNs) |
+//                (lds_nmats+1)*6 material float4 (the records the model uses, then the default one) | n material-record bytes,
+//                padded to 16 | lds_stack x 1024 int16 ]
+template <bool COUNT>
+__global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds4(const MptRenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) MptVec4 smem[];
+    const int nnode4 = p.nwide * (MPT_LDS4_NODE_STRIDE / 16), ntri4 = (p.n + 1) * 3, nmat4 = (p.lds_nmats + 1) * MPT_LDS_MAT_VEC4;
+    const int nmtl4 = (p.n + 15) >> 4;
+    unsigned long long *tl = p.timeline ? p.timeline + MPT_TIMELINE_WORDS * (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
+    if (tl && (threadIdx.x & 63) == 0) tl[0] = wall_clock64();
+    {
+        for (int k = threadIdx.x; k < p.nwide * 7; k += blockDim.x) {
+            const int rec = k / 7, w = k - rec * 7;
+            MptVec4 v = p.wnode[rec * 8 + w];
+            if (w == 6) {                                                        // the four ids: internal ones become byte offset / 8
+                const int i0 = __float_as_int(v.x), i1 = __float_as_int(v.y), i2 = __float_as_int(v.z), i3 = __float_as_int(v.w);
+                v.x = __int_as_float(i0 >= 0 ? i0 * (MPT_LDS4_NODE_STRIDE / 8) : i0);
+                v.y = __int_as_float(i1 >= 0 ? i1 * (MPT_LDS4_NODE_STRIDE / 8) : i1);
+                v.z = __int_as_float(i2 >= 0 ? i2 * (MPT_LDS4_NODE_STRIDE / 8) : i2);
+                v.w = __int_as_float(i3 >= 0 ? i3 * (MPT_LDS4_NODE_STRIDE / 8) : i3);
+            }
+            smem[k] = v;
+        }
+        for (int k = threadIdx.x; k < ntri4; k += blockDim.x) smem[nnode4 + k] = p.tfast[k];
+        for (int k = threadIdx.x; k < nmat4; k += blockDim.x) {
+            const int rec = k / MPT_LDS_MAT_VEC4, w = k - rec * MPT_LDS_MAT_VEC4;
+            const int grec = rec == p.lds_nmats ? p.default_mtl : rec;          // the default material's record is kept last
+            smem[nnode4 + ntri4 + k] = ((const MptVec4 *)(p.mats + grec))[w < 4 ? w : w + 4];
+        }
+        unsigned char *mtl = (unsigned char *)(smem + nnode4 + ntri4 + nmat4);
+        for (int k = threadIdx.x; k < p.n; k += blockDim.x) {
+            const int id = __float_as_int(p.tshade[(size_t)k * 4 + 3].w);
+            mtl[k] = (unsigned char)(id == -1 ? p.lds_nmats : id);
+        }
+    }
+    __syncthreads();
+    if (tl && (threadIdx.x & 63) == 0) tl[1] = wall_clock64();
+
+    LdsWideScene sc;
+    sc.wnode = (LdsVec4Ptr)(void *)smem;
+    sc.tgeo = (LdsVec4Ptr)(void *)(smem + nnode4);
+    sc.mats = (LdsVec4Ptr)(void *)(smem + nnode4 + ntri4);
+    sc.mtl = (LdsU8Ptr)(void *)(smem + nnode4 + ntri4 + nmat4);
+    sc.mat_last = p.lds_nmats; sc.mat_default = p.default_mtl;
+    Stack16W stk;
+    stk.base = (LdsShortPtr)(void *)(smem + nnode4 + ntri4 + nmat4 + nmtl4) + threadIdx.x;
+    stk.sp = 0;
+    Cnt cnt = {};
+    WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
+    trace_stream<COUNT>(p, sc, stk, wq, cnt, tl);
+    if (tl && (threadIdx.x & 63) == 0) tl[3] = wall_clock64();
+    const int fin_tiles = finalise_tiles<MPT_FIN_GROUP_LDS>(p);
+#if !MPT_X_TIMELINE2
+    if (tl && (threadIdx.x & 63) == 0) { tl[4] = wall_clock64(); tl[5] = (unsigned long long)fin_tiles; }
+#endif
+    flush_counters<COUNT>(p, cnt);
+}
 #endif
 
 // PreviewEngine._render, engine/preview.py:23-41
@@ -1526,6 +1593,27 @@ static hipError_t launch_lds(const MptRenderParams *p, int grid, int block, size
     }
     hipLaunchKernelGGL((render_kernel_lds<COUNT>), dim3(grid), dim3(block), lds_bytes, stream, *p);
     return hipGetLastError();
+}
+
+template <bool COUNT>
+static hipError_t launch_lds4(const MptRenderParams *p, int grid, int block, size_t lds_bytes, hipStream_t stream) {
+    static std::atomic<bool> configured[MPT_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MPT_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!configured[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)render_kernel_lds4<COUNT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((render_kernel_lds4<COUNT>), dim3(grid), dim3(block), lds_bytes, stream, *p);
+    return hipGetLastError();
+}
+
+// the same over the 4-wide nodes (p->wnode, p->nwide)
+MPT_KERNEL_API hipError_t mpt_launch_render_lds4(const MptRenderParams *p, int grid, int block, size_t lds_bytes, int count,
+                                             hipStream_t stream) {
+    return count ? launch_lds4<true>(p, grid, block, lds_bytes, stream) : launch_lds4<false>(p, grid, block, lds_bytes, stream);
 }
 
 // lds_bytes = scene records + 2 KiB per stack level; grid = one persistent workgroup per CU

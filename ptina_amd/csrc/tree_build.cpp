@@ -558,8 +558,27 @@ static int build_tree_gpu(mpt_ctx *c) {
 // surface area is replaced by its own two children until four are held (or only leaves are left).  A ray then
 // makes about half as many dependent record fetches, which is what the scenes that do not fit LDS wait for.
 // Host pass over the downloaded records (1 M triangles: 64 MB down, ~0.1 s, 64 MB up), off the render path.
+// The stack levels a traversal of the 4-wide tree can ask for, exactly (render_kernel_lds4 keeps them all in LDS): a step at a
+// node with k children leaves up to k - 1 entries behind and goes on with one child; children come after their parents in the
+// array.  ids: the id vector of node w at ids[w * stride]; an unused slot names leaf n
+static int wide_stack_levels(const MptVec4 *ids, size_t stride, size_t nw, int n) {
+    auto asi = [](float f) { int32_t v; memcpy(&v, &f, 4); return v; };
+    std::vector<int> need(nw, 0);
+    for (size_t w = nw; w-- > 0;) {
+        const MptVec4 &idv = ids[w * stride];
+        const int32_t id[4] = { asi(idv.x), asi(idv.y), asi(idv.z), asi(idv.w) };
+        int k = 0, deep = 0;
+        for (int q = 0; q < 4; q++) {
+            if (id[q] != ~n) k++;
+            if (id[q] >= 0 && (size_t)id[q] < nw) deep = std::max(deep, need[id[q]]);
+        }
+        need[w] = std::max(k - 1, 0) + deep;
+    }
+    return 1 + (nw ? need[0] : 0) + 1;      // the sentinel below, and the level the step's last (unwanted) plain store lands on
+}
+
 static int make_wide_host(mpt_ctx *c) {
-    c->wide_nodes = 0; c->wide_depth = 0;
+    c->wide_nodes = 0; c->wide_depth = 0; c->wide_stack = 0;
     const int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
     if (ni < 1) return 0;
     std::vector<MptVec4> fnode((size_t)ni * 4);
@@ -692,6 +711,7 @@ static int make_wide_host(mpt_ctx *c) {
     }
     HIP_TRY(hipMemcpy(c->qnode, qnode.data(), nw * 4 * sizeof(MptVec4), hipMemcpyHostToDevice));
     c->wide_nodes = (int)nw; c->wide_depth = depth;
+    c->wide_stack = wide_stack_levels(wnode.data() + 6, 8, nw, n);
     c->wide_ratio = area_bin > 0.0 ? (float)(area_wide / area_bin) : 1.f;
     return 0;
 }
@@ -699,7 +719,7 @@ static int make_wide_host(mpt_ctx *c) {
 // The same collapse on the device (wide_build.hip): nothing is downloaded, one integer per level comes back.  Produces the
 // host pass's bytes (tests/test_parity_gpu.py::test_device_wide_collapse_equals_the_host_pass).
 static int make_wide_device(mpt_ctx *c) {
-    c->wide_nodes = 0; c->wide_depth = 0;
+    c->wide_nodes = 0; c->wide_depth = 0; c->wide_stack = 0;
     const int n = c->nfaces, ni = n > 1 ? n - 1 : 0;
     if (ni < 1) return 0;
     if ((size_t)ni * 8 * sizeof(MptVec4) >= ((size_t)1 << 31)) return 0;   // the kernel addresses the records with 32-bit byte offsets
@@ -728,6 +748,13 @@ static int make_wide_device(mpt_ctx *c) {
     // a step pushes up to three entries: 3 x depth + sentinel must fit the LDS levels plus the spill strip
     if (3 * depth + 2 > 128) return 0;      // too deep: the gather kernel keeps walking the binary tree
     c->wide_nodes = nw; c->wide_depth = depth;
+    c->wide_stack = 3 * depth + 2;          // the bound ...
+    if (nw > 0 && nw <= 4096) {             // ... and for a tree that may be walked out of LDS the exact count, from its id vectors (64 KiB at most)
+        std::vector<MptVec4> ids((size_t)nw);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy2D(ids.data(), sizeof(MptVec4), c->wnode + 6, 8 * sizeof(MptVec4), sizeof(MptVec4), (size_t)nw, hipMemcpyDeviceToHost));
+        c->wide_stack = std::min(c->wide_stack, wide_stack_levels(ids.data(), 1, (size_t)nw, n));
+    }
     c->wide_ratio = area[1] > 0.0 ? (float)(area[0] / area[1]) : 1.f;
     return 0;
 }

@@ -38,6 +38,7 @@ def main():
             reset_all()
             eng = _engine(None, scene, nx, ny, mode='fast', lights=lts)
             c = ctx()
+            c.set_option('lds_wide', 0)                # (the pooled kernel walks the binary nodes: compare like with like)
             c.set_option('pool', pool)
             c.set_option('pool_shaders', shaders)
             c.set_option('batch', 16)

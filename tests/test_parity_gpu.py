@@ -331,21 +331,23 @@ def test_workgroup_size_does_not_change_the_film(fresh):
     from ptina_amd.things import FilmTable
     from ptina_amd.common import ctx, reset_all
     for nx, ny, spp in ((52, 43, 8), (640, 512, 6)):          # 0.07 and 7.5 samples per lane of a 256-CU launch
-        films = {}
-        for block in (0, 256, 512, 768, 1024):
+        for lds_wide in (1, 0):                                # over the 4-wide nodes (the default) and over the binary ones
+            films = {}
+            for block in (0, 256, 512, 768, 1024):
+                reset_all()
+                eng = _engine(None, scenes.scene_s978(), nx, ny, mode='fast', max_filmsize=max(nx * ny, 1 << 18))
+                c = ctx()
+                c.set_option('batch', 8)
+                c.set_option('lds_block', block)
+                c.set_option('lds_wide', lds_wide)
+                eng.render(spp)
+                c.call('mpt_flush')
+                assert c.get_option('last_kernel') == (5 if lds_wide else 1)
+                films[block] = FilmTable().get_raw().copy()
             reset_all()
-            eng = _engine(None, scenes.scene_s978(), nx, ny, mode='fast', max_filmsize=max(nx * ny, 1 << 18))
-            c = ctx()
-            c.set_option('batch', 8)
-            c.set_option('lds_block', block)
-            eng.render(spp)
-            c.call('mpt_flush')
-            assert c.get_option('last_kernel') == 1
-            films[block] = FilmTable().get_raw().copy()
-        reset_all()
-        assert np.all(films[0].reshape(nx, ny, 4)[..., 3] == spp)
-        for block, film in films.items():
-            assert np.array_equal(film.view(np.uint32), films[0].view(np.uint32)), (nx, ny, block)
+            assert np.all(films[0].reshape(nx, ny, 4)[..., 3] == spp)
+            for block, film in films.items():
+                assert np.array_equal(film.view(np.uint32), films[0].view(np.uint32)), (nx, ny, lds_wide, block)
 
 
 def test_slabs_reassemble_bit_identically(fresh):
@@ -434,7 +436,7 @@ def test_lds_and_gather_kernels_agree_bit_for_bit(fresh):
     from ptina_amd.things import FilmTable, BVHTree
     from ptina_amd.common import ctx, reset_all
     films = {}
-    for lds, tree, wide, quant in ((1, 1, 0, 1), (0, 1, 0, 1), (1, 0, 0, 1), (0, 0, 0, 1), (0, 1, 1, 1), (0, 0, 1, 1), (0, 1, 1, 0)):
+    for lds, tree, wide, quant in ((1, 1, 0, 1), (0, 1, 0, 1), (1, 0, 0, 1), (0, 0, 0, 1), (0, 1, 1, 1), (0, 0, 1, 1), (0, 1, 1, 0), (1, 1, 1, 0), (1, 0, 1, 0)):
         reset_all()
         eng = _engine(None, scenes.scene_s978(), 96, 80, mode='fast')
         c = ctx()
@@ -452,6 +454,16 @@ def test_lds_and_gather_kernels_agree_bit_for_bit(fresh):
             assert c.get_option('wide_nodes') > 0 and 1 < c.get_option('wide_depth') <= c.get_option('fast_depth')
     reset_all()
     assert films[(1, 1, 0, 1)][2] == 1 and films[(0, 1, 0, 1)][2] == 0 and films[(0, 1, 1, 1)][2] == 2 and films[(0, 1, 1, 0)][2] == 2
+    # the LDS-resident kernel over the 4-wide nodes (exact boxes; what a scene that fits LDS gets by default): the gather kernel's
+    # tree and boxes, its own sort (distance bits over 16-bit ids in one word) and the origin triangle filtered in the LEAF step
+    assert films[(1, 1, 1, 0)][2] == 5 and films[(1, 0, 1, 0)][2] == 5
+    assert_parity(films[(1, 1, 1, 0)][1], films[(0, 1, 1, 0)][1], *FAST, what='4-wide nodes in LDS vs gathered (SAH)')
+    assert_parity(films[(1, 1, 1, 0)][1], films[(1, 1, 0, 1)][1], *FAST, what='4-wide nodes in LDS vs binary nodes in LDS (SAH)')
+    assert_parity(films[(1, 0, 1, 0)][1], films[(1, 0, 0, 1)][1], *FAST, what='4-wide nodes in LDS vs binary nodes in LDS (LBVH)')
+    l4, g4 = films[(1, 1, 1, 0)][3], films[(0, 1, 1, 0)][3]
+    assert l4['rays'] == g4['rays'] and np.all(films[(1, 1, 1, 0)][0][:, 3] == 6)
+    assert 0.98 * g4['n_node'] <= l4['n_node'] <= 1.02 * g4['n_node']               # same boxes; the order of near-equal entries may differ
+    assert g4['n_tri'] <= l4['n_tri'] <= g4['n_tri'] + 1.05 * l4['rays']            # + the origin triangle's own leaf, once per ray that starts on one
     assert np.array_equal(films[(1, 1, 0, 1)][0], films[(0, 1, 0, 1)][0])
     assert np.array_equal(films[(1, 0, 0, 1)][0], films[(0, 0, 0, 1)][0])
     assert_parity(films[(1, 1, 0, 1)][1], films[(1, 0, 0, 1)][1], *FAST, what='SAH tree vs LBVH')
@@ -746,7 +758,7 @@ def test_random_scenes_parity(fresh, oracle_mod, seed):
     ref.render(spp)
     want = ref.get_image()
     assert np.isfinite(want).all()
-    for mode, opts in (('strict', {}), ('fast', {}), ('fast', {'lds': 0, 'wide': 0}), ('fast', {'lds': 0}), ('fast', {'lds': 0, 'wide8': 1})):
+    for mode, opts in (('strict', {}), ('fast', {}), ('fast', {'lds_wide': 0}), ('fast', {'lds': 0, 'wide': 0}), ('fast', {'lds': 0}), ('fast', {'lds': 0, 'wide8': 1})):
         reset_all()
         eng = _engine(None, scene, nx, ny, mode=mode, lights=lights, world=world)
         for key, val in opts.items():
@@ -759,7 +771,7 @@ def test_random_scenes_parity(fresh, oracle_mod, seed):
         assert np.all(raw[..., 3] == spp)
         kernel = ctx().get_option('last_kernel')
         if mode == 'fast':
-            assert kernel == (1 if not opts else 4 if 'wide8' in opts else 0 if 'wide' in opts else 2), (opts, kernel)
+            assert kernel == (5 if not opts else 1 if 'lds_wide' in opts else 4 if 'wide8' in opts else 0 if 'wide' in opts else 2), (opts, kernel)
         assert_parity(FilmTable().get_image(), want, *bounds(mode), what=f'random scene {seed} ({k} triangles) {mode} {opts}')
     reset_all()
 
@@ -908,7 +920,7 @@ def test_tiny_scenes_through_every_production_kernel(fresh, oracle_mod):
         ref = setup_oracle(oracle_mod, scene, 48, 40)
         ref.render(8)
         want = ref.get_image()
-        for lds, wide, quant, kernel in ((1, 1, 1, 1), (0, 0, 1, 0), (0, 1, 1, 2), (0, 1, 0, 2)):
+        for lds, wide, quant, kernel in ((1, 1, 1, 5), (1, 0, 1, 1), (0, 0, 1, 0), (0, 1, 1, 2), (0, 1, 0, 2)):
             reset_all()
             eng = _engine(None, scene, 48, 40, mode='fast')
             c = ctx()
@@ -1812,6 +1824,37 @@ def test_config4_full_scene_with_environment_vs_oracle(fresh, oracle_mod):
     reset_all()
 
 
+def test_kernel_ladder_by_scene_size(fresh):
+    '''which kernel serves a scene is decided by what fits a CU's 160 KiB of LDS beside the stacks (miptina.cpp): the 4-wide
+    nodes with exact boxes (112 B a node, about half a node per triangle) and the triangles, else the 4-wide 8-bit nodes gathered
+    from L2; the LDS-resident kernel over the binary nodes (72 B, one per triangle: it fits less) is what option lds_wide = 0
+    asks for.  The benchmark model and the same with a finer sphere: the same picture from each kernel as from the gather kernel
+    that can serve them all (equal up to ties: FAST bounds)'''
+    from helpers import assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd.scenes import cornell_walls, bumpy_sphere, _compose
+    base = scenes.scene_s978()
+    for segments, rings, lds_wide, want_kernel in ((22, 23, 1, 5), (22, 23, 0, 1), (28, 27, 1, 2), (28, 27, 0, 2)):
+        vertices, mtlids = _compose([cornell_walls(), bumpy_sphere(segments=segments, rings=rings)])
+        scene = (vertices, mtlids, base[2], [])
+        n = mtlids.shape[0]
+        films = {}
+        for lds in (1, 0):
+            reset_all()
+            eng = _engine(None, scene, 96, 80, mode='fast')
+            c = ctx()
+            c.set_option('lds', lds)
+            c.set_option('lds_wide', lds_wide)
+            eng.render(8)
+            films[lds] = FilmTable().get_image().copy()
+            raw = FilmTable().get_raw()
+            assert np.all(raw[:, 3] == 8) and np.isfinite(raw).all()
+            assert c.get_option('last_kernel') == (want_kernel if lds else 2), (n, lds, c.get_option('last_kernel'), c.get_option('wide_nodes'), c.get_option('wide_stack'))
+        assert_parity(films[1], films[0], *FAST, what='%d triangles: kernel %d vs the gather kernel' % (n, want_kernel))
+    reset_all()
+
+
 def _same_film(a, b, what):
     '''bit equality of two films (columns, rows, 4), saying where they differ when they do'''
     d = (np.ascontiguousarray(a).view(np.uint32) != np.ascontiguousarray(b).view(np.uint32)).any(axis=-1)
@@ -1846,7 +1889,19 @@ def test_config3_eight_stripe_shares_reassemble_bit_identically(fresh):
         part = FilmTable().get_raw().reshape(n, n, 4)
         cols = stripe_columns(n, R, r)
         assert np.all(part[np.setdiff1d(np.arange(n), cols)] == 0)
-        assert _same_film(part[cols], full[cols], 'share %d as rendered' % r)
+        if not np.array_equal(part[cols].view(np.uint32), full[cols].view(np.uint32)):
+            # which of the two is off?  (diagnosis only: render the whole film once more)
+            mine = part[cols].copy()
+            reset_all()
+            eng = _engine(None, scene, n, n, mode='fast', max_filmsize=n * n)
+            eng.render(spp)
+            again = FilmTable().get_raw().reshape(n, n, 4).copy()
+            same_full = np.array_equal(again.view(np.uint32), full.view(np.uint32))
+            same_part = np.array_equal(again[cols].view(np.uint32), mine.view(np.uint32))
+            d = (full.view(np.uint32) != again.view(np.uint32)).any(axis=-1)
+            cx, cy = np.nonzero(d)
+            where = 'whole films differ in %d pixels, columns %s rows %s' % (len(cx), sorted(set((cx // 8 * 8).tolist()))[:12], sorted(set((cy // 8 * 8).tolist()))[:12]) if len(cx) else ''
+            _same_film(mine, full[cols], 'share %d as rendered (a second whole-film render equals the first: %s, equals the share: %s; %s)' % (r, same_full, same_part, where))
         if r == 0:
             tiled[cols] = part[cols]                      # the root's own share is already in its film
         else:

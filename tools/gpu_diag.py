@@ -580,6 +580,8 @@ def stamps(name='s978', spp=32, n=512):
     eng = setup_engine(scenes.get_scene(name, **kw), n, n, mode='fast', world=world, max_filmsize=max(n * n, 1 << 21))
     c = ctx()
     c.set_option('batch', spp)
+    for kv in filter(None, os.environ.get('MIPTINA_OPTS', '').split(',')):    # A/B switches, e.g. lds_wide=1
+        c.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     eng.render(spp)
     c.call('mpt_synchronize')
     c.set_option('count', 1)

@@ -42,6 +42,13 @@ for step in "$@"; do
     shares_sync) run shares_sync 300 python tools/gpu_diag.py shares_sync ;;
     sync_sweep)  run sync_sweep 300 python tools/gpu_diag.py sync_sweep ;;
     ubench)      run ubench 200 tools/microbench/valu_microbench --json ;;
+    l4ab)        # the LDS-resident 4-wide kernel of each library in ABLIBS (main = the product library), stamps for *stamp
+                 for L in $ABLIBS; do
+                   if [ "$L" = main ]; then run l4_$L 200 python tools/ab_lds4.py 0 1
+                   elif [[ "$L" == *stamp* ]]; then MIPTINA_OPTS=lds_wide=1 MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_$L.so run l4_$L 200 python tools/gpu_diag.py stamps
+                   else MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_$L.so run l4_$L 200 python tools/ab_lds4.py 1; fi
+                 done ;;
+    gbench)      run gbench 400 tools/microbench/gather_microbench ;;
     ubench_pmc)  run ubench_pmc 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/ubench_pmc -- tools/microbench/valu_microbench ;;
     bench_quick) run bench_quick 300 python bench.py --no-pmc --no-cpu-baseline ;;
     bench_nofin) MIPTINA_OPTS=finalise=0 run bench_nofin 300 python bench.py --no-pmc --no-cpu-baseline ;;

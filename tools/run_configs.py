@@ -67,7 +67,7 @@ for title, name, kw, n, spp, world in CONFIGS:
     bps = algorithmic_bytes(cnt) / cnt['samples']
     ms = n * n * spp / dt / 1e6
     out[title] = {'ntri': int(scene[1].shape[0]), 'setup_s': round(setup_s, 3), 'msamples_s': round(ms, 1),
-                  'ms_per_step': round(dt * 1e3, 3), 'kernel': ('gather', 'lds', 'gather4', 'lds_pool', 'gather8')[c.get_option('last_kernel')],
+                  'ms_per_step': round(dt * 1e3, 3), 'kernel': ('gather', 'lds', 'gather4', 'lds_pool', 'gather8', 'lds4')[c.get_option('last_kernel')],
                   'bytes_per_sample': round(bps, 1), 'achieved_GBs': round(bps * ms * 1e6 / 1e9, 1),
                   'rays_per_sample': round(cnt['rays'] / cnt['samples'], 2),
                   'nodes_per_ray': round(cnt['n_node'] / cnt['rays'], 2), 'tris_per_ray': round(cnt['n_tri'] / cnt['rays'], 2),

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-'''Diagnostic: the same pipelined render (2048 x 2048, render(256) = eight launches back to back; whole film or one stripe share)
-repeated in fresh contexts must give the same raw film every time.  usage: stress_pipelined.py [rounds] [finalise] [stripes 0/1]'''
+'''Diagnostic: 2048 x 2048, render(256) = eight launches back to back.  The whole film is rendered once; then the stripe shares
+r = 0..7 of eight (mpt_set_stripes(16, r, 8)) are rendered in fresh contexts, `rounds` times over, and each share's columns are
+compared with the whole film's, bit for bit.  usage: stress_pipelined.py [rounds] [poison] [key=value options for every context ...]'''
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,38 +11,50 @@ import numpy as np  # noqa: E402
 from ptina_amd import scenes, common  # noqa: E402
 from ptina_amd.common import ctx  # noqa: E402
 from ptina_amd.things import FilmTable  # noqa: E402
+from ptina_amd.dist import stripe_columns  # noqa: E402
 from helpers import setup_engine  # noqa: E402
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-fin = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-stripes = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-n, spp = 2048, 256
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+poison = 'poison' in sys.argv[2:]
+opts = [(a.split('=')[0], int(a.split('=')[1])) for a in sys.argv[2:] if '=' in a]
+n, spp, R = 2048, 256, 8
 scene = scenes.scene_s978()
-ref = None
-bad = 0
-for i in range(rounds):
+
+
+def render(share):
+    if poison:
+        # a context whose only launch finalises its own tiles leaves its tag in every entry of a slab as large as the next
+        # context's; the allocator hands that memory out again
+        common.reset_all()
+        eng = setup_engine(scenes.scene_s34(), n, n if share is None else n // R, mode='fast', max_filmsize=n * n)
+        eng.render(32)
+        FilmTable().get_raw()
     common.reset_all()
     eng = setup_engine(scene, n, n, mode='fast', max_filmsize=n * n)
     c = ctx()
-    c.set_option('finalise', fin)
-    if stripes:
-        c.call('mpt_set_stripes', 16, i % 8 if stripes == 2 else 3, 8)
+    for k, v in opts:
+        c.set_option(k, v)
+    if share is not None:
+        c.call('mpt_set_stripes', 16, share, R)
     eng.render(spp)
-    raw = FilmTable().get_raw().copy()
-    if stripes == 2:
-        continue
-    if ref is None:
-        ref = raw
-        print('round 0: counted', float(raw[:, 3].max()), flush=True)
-    else:
-        d = (raw.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
+    return FilmTable().get_raw().reshape(n, n, 4).copy()
+
+
+full = render(None)
+print('whole film: counted', float(full[..., 3].min()), float(full[..., 3].max()), 'options', opts, flush=True)
+bad = 0
+for i in range(rounds):
+    for r in range(R):
+        part = render(r)
+        cols = stripe_columns(n, R, r)
+        d = (part[cols].view(np.uint32) != full[cols].view(np.uint32)).any(axis=-1)
         if d.any():
             bad += 1
-            idx = np.flatnonzero(d)
-            x, y = idx // n, idx % n
-            print(f'round {i}: {len(idx)} pixels differ; x range {x.min()}..{x.max()}, y range {y.min()}..{y.max()}; '
-                  f'w values {np.unique(raw[idx, 3])[:8]} vs {np.unique(ref[idx, 3])[:8]}; first {idx[:8]}', flush=True)
-        else:
-            print(f'round {i}: identical', flush=True)
+            cx, cy = np.nonzero(d)
+            diff = part[cols][cx, cy, :3] - full[cols][cx, cy, :3]
+            print(f'round {i} share {r}: {len(cx)} pixels differ; share columns {cx.min()}..{cx.max()}, rows {cy.min()}..{cy.max()}; '
+                  f'w {np.unique(part[cols][cx, cy, 3])}; diff range {diff.min():.4g}..{diff.max():.4g}; '
+                  f'first {[(int(cols[a]), int(b)) for a, b in zip(cx[:6], cy[:6])]} diffs {diff[:4].round(4).tolist()}', flush=True)
+    print(f'round {i} done, bad so far {bad}', flush=True)
 common.reset_all()
 print('BAD' if bad else 'OK', bad)
