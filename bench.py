@@ -61,8 +61,8 @@ C3_N = 2048                  # BASELINE.json configs[2]: 2048 x 2048 film ...
 C3_SPP = 256                 # ... at 256 spp: one c3 step = render(256) (eight launches of 32 frames, pipelined) + gather + get_image()
 # the launch model of DESIGN.md section 6, measured on ONE MI355X (tools/gpu_diag.py shares_sync): a launch of 1/N of
 # a film costs a / N + b -- b = the end-of-launch drain, independent of N
-MODEL = {'headline': {'a_ms': 2.65, 'b_ms': 0.24}, 'c3': {'a_ms': 41.0, 'b_ms': 0.24},
-         'from': 'one-GPU share measurements, DESIGN.md section 6 (round 4: 2.89 / 1.57 / 0.88 / 0.57 ms per launch for N = 1 / 2 / 4 / 8)'}
+MODEL = {'headline': {'a_ms': 2.39, 'b_ms': 0.22}, 'c3': {'a_ms': 38.8, 'b_ms': 0.22},
+         'from': 'one-GPU share measurements, DESIGN.md section 6 (round 4, render_kernel_lds4: 2.61 / 1.42 / 0.79 / 0.52 ms per launch for N = 1 / 2 / 4 / 8)'}
 
 PMC_PASSES = [
     ['SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES',
@@ -192,8 +192,8 @@ def roofline_blocks(pmc, source, kernel, avg_kernel_s, clock_hz, concurrent):
         'wave_cycles_valu_frac': round(g('SQ_ACTIVE_INST_VALU') / g('SQ_WAVE_CYCLES'), 3) if g('SQ_WAVE_CYCLES') else None,
         'wave_cycles_wait_inst_frac': round(g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'), 3) if g('SQ_WAVE_CYCLES') and g('SQ_WAIT_INST_ANY') else None,
         'counters_from': source,
-        'note': 'f32 vector lane-operations per second against 256 CU x 4 SIMD-32 x clock; the 125 KB of nodes + '
-                'triangles are LDS-resident, so HBM is not the binding limit (see "hbm") and there is no contraction '
+        'note': 'f32 vector lane-operations per second against 256 CU x 4 SIMD-32 x clock; the node and triangle records '
+                'are LDS-resident, so HBM is not the binding limit (see "hbm") and there is no contraction '
                 'for MFMA',
     }
     hbm = None

@@ -38,12 +38,26 @@ __global__ __launch_bounds__(256) void sobol_update_kernel(const int *X, int *Xo
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= dim) return;
     int x = X[j];
-    for (int f = 0; f < count; f++) {
-        int i = count_low_bits(time0 + f);
-        if (i < rows) x ^= V[(size_t)i * dim + j];
-        // only the last `pstride_frames` frames are kept when count exceeds the P capacity
-        // (reset's skipped updates never read P)
-        if (f >= count - pstride_frames) P[(size_t)(f - (count - pstride_frames)) * dim + j] = construct_float(x);
+    // eight frames at a time: which row of V a frame takes depends on the frame number only, so the eight loads are issued
+    // together and the kernel waits for memory four times per batch of 32 frames instead of 32 times (it runs beside the start of
+    // a render launch, whose persistent workgroups need whole CUs: 35 us of it delayed a third of them -- DESIGN.md 3.6)
+    for (int f0 = 0; f0 < count; f0 += 8) {
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = count_low_bits(time0 + f0 + k);
+            v[k] = (f0 + k < count && i < rows) ? V[(size_t)i * dim + j] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int f = f0 + k;
+            if (f < count) {
+                x ^= v[k];
+                // only the last `pstride_frames` frames are kept when count exceeds the P capacity
+                // (reset's skipped updates never read P)
+                if (f >= count - pstride_frames) P[(size_t)(f - (count - pstride_frames)) * dim + j] = construct_float(x);
+            }
+        }
     }
     // Xout = X: the sampler's state moves.  Xout = a second buffer: the points of the NEXT batch computed ahead of time, and the
     // state that batch will leave behind with them -- the host swaps the two buffers when that batch is launched

@@ -689,7 +689,8 @@ template <bool COUNT, class SCENE, class STACK>
 DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     int slot = ~L.curr;
     bool stop = false;
-    if (COUNT) cnt.n_tri++;
+    // (the counters count the reference's work: it never tests the triangle a ray left from, lbvh.py:329)
+    if (COUNT) cnt.n_tri += (SCENE::AVOID_IN_LEAF && L.curr == L.navoid) ? 0u : 1u;
 #if MPT_SPEC_POP
     int spec = 0;
     if constexpr (STACK::PEEK) spec = stk.peek(L.sp - 1);      // a leaf step always pops: asked for with the triangle record

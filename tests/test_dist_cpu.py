@@ -274,8 +274,10 @@ def test_bench_n_gpu_line_carries_the_config3_leg(tmp_path):
     assert c3['n_gpus'] == 2 and c3['steps'] == 2 and '2048x2048' in c3['workload']
     assert c3['spp'] == 256 and '256 spp' in c3['workload'] and 'BASELINE configs[2]' in c3['workload']   # the stated config
     assert c3['msamples_s'] > 0 and c3['ms_per_step'] > 0
-    assert abs(c3['model_ms_per_step'] - (8 * 41.0 / 2 + 0.24)) < 1e-6 and 'a / N + b' in c3['model']
-    assert abs(line['model_ms_per_step'] - (2.65 / 2 + 0.24)) < 1e-6
+    import bench
+    m1, m3 = bench.MODEL['headline'], bench.MODEL['c3']
+    assert abs(c3['model_ms_per_step'] - (8 * m3['a_ms'] / 2 + m3['b_ms'])) < 1e-3 and 'a / N + b' in c3['model']
+    assert abs(line['model_ms_per_step'] - (m1['a_ms'] / 2 + m1['b_ms'])) < 1e-3
     # the N > 1 line is not "unmeasured": a roofline block from rank 0's kernel time and the committed counters x its share
     roof = line['roofline']
     assert roof['frac'] is not None and roof['avg_kernel_ms'] > 0 and 'x 0.5000' in roof['counters_from']

@@ -463,7 +463,7 @@ def test_lds_and_gather_kernels_agree_bit_for_bit(fresh):
     l4, g4 = films[(1, 1, 1, 0)][3], films[(0, 1, 1, 0)][3]
     assert l4['rays'] == g4['rays'] and np.all(films[(1, 1, 1, 0)][0][:, 3] == 6)
     assert 0.98 * g4['n_node'] <= l4['n_node'] <= 1.02 * g4['n_node']               # same boxes; the order of near-equal entries may differ
-    assert g4['n_tri'] <= l4['n_tri'] <= g4['n_tri'] + 1.05 * l4['rays']            # + the origin triangle's own leaf, once per ray that starts on one
+    assert 0.98 * g4['n_tri'] <= l4['n_tri'] <= 1.02 * g4['n_tri']                  # (the origin triangle's own LEAF step is not counted: the reference never tests it)
     assert np.array_equal(films[(1, 1, 0, 1)][0], films[(0, 1, 0, 1)][0])
     assert np.array_equal(films[(1, 0, 0, 1)][0], films[(0, 0, 0, 1)][0])
     assert_parity(films[(1, 1, 0, 1)][1], films[(1, 0, 0, 1)][1], *FAST, what='SAH tree vs LBVH')
