@@ -84,7 +84,9 @@ void mpt_destroy(mpt_ctx *ctx);
 
 /* "mode" (MPT_MODE_*), "batch" (max frames per launch, 1..64), "chunk" (frames per work item,
  * 0 = auto), "count" (1 = accumulate mpt_counters, slower), "lds" (1 = use the LDS-resident
- * persistent kernel when the scene fits a CU's 160 KiB LDS, default; 0 = always gather from HBM/L2).
+ * persistent kernel when the scene fits a CU's 160 KiB LDS, default; 0 = always gather from HBM/L2),
+ * "lds_wide" (what that kernel walks: 1 = the 4-wide nodes with exact boxes, 112 bytes apart in LDS, default -- needs "wide" = 1;
+ * 0 = the binary nodes; the same film up to ties between equally distant hits).
  * "tree" (fast build: 1 = SAH re-partition of the LBVH's leaves, default; 0 = walk the LBVH itself;
  * takes effect at the next mpt_build_tree), "tile_w_shift"/"tile_h_shift" (work-item tile 2^w x 2^h pixels),
  * "wide" (scenes that do not fit LDS: 1 = walk the fast tree collapsed into 4-wide nodes, default; 0 = the
@@ -109,8 +111,10 @@ void mpt_destroy(mpt_ctx *ctx);
  * writes out finished tiles itself while its last paths drain; 0: always the combine pass after the launch; same film bit for bit),
  * "timeline" (1 = record mpt_get_timeline data), "reserve_cus" (CUs every persistent render launch leaves
  * unclaimed, default 0; measured to be of no use to foreign kernels while launches overlap, kept for experiments).
- * read-only: "tree_depth", "fast_depth", "wide_nodes", "wide_depth", "wide_ratio_permille", "pending", "last_kernel" (0 = gather over
- * the binary tree, 1 = LDS-resident, 2 = gather over 4-wide nodes), "num_cus",
+ * read-only: "tree_depth", "fast_depth", "wide_nodes", "wide_depth", "wide_stack" (stack levels a traversal of the 4-wide tree can
+ * ask for), "wide_ratio_permille", "pending", "last_kernel" (0 = gather over the binary tree, 1 = LDS-resident over the binary
+ * nodes, 2 = gather over 4-wide nodes, 3 = pooled LDS kernel (A/B library), 4 = gather over 8-wide nodes, 5 = LDS-resident over
+ * the 4-wide nodes), "num_cus",
  * "cur_div", "cur_depth" (the ring the last launch belonged to: G launches of 1/G of the CUs, that many batches in
  * flight), "last_div" (what the last launch really took: 1 when it found the ring idle, else cur_div), "hw_queues"
  * (GPU_MAX_HW_QUEUES as the HIP runtime was asked for it -- the library requests 12 at load time unless the variable is
