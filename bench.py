@@ -61,8 +61,8 @@ C3_N = 2048                  # BASELINE.json configs[2]: 2048 x 2048 film ...
 C3_SPP = 256                 # ... at 256 spp: one c3 step = render(256) (eight launches of 32 frames, pipelined) + gather + get_image()
 # the launch model of DESIGN.md section 6, measured on ONE MI355X (tools/gpu_diag.py shares_sync): a launch of 1/N of
 # a film costs a / N + b -- b = the end-of-launch drain, independent of N
-MODEL = {'headline': {'a_ms': 2.39, 'b_ms': 0.22}, 'c3': {'a_ms': 38.8, 'b_ms': 0.22},
-         'from': 'one-GPU share measurements, DESIGN.md section 6 (round 4, render_kernel_lds4: 2.61 / 1.42 / 0.79 / 0.52 ms per launch for N = 1 / 2 / 4 / 8)'}
+MODEL = {'headline': {'a_ms': 2.42, 'b_ms': 0.19}, 'c3': {'a_ms': 38.8, 'b_ms': 0.19},
+         'from': 'one-GPU share measurements, DESIGN.md section 6 (round 4, render_kernel_lds4: 2.61 / 1.43 / 0.80 / 0.49 ms per launch for N = 1 / 2 / 4 / 8)'}
 
 PMC_PASSES = [
     ['SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES',

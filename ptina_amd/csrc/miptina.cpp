@@ -914,8 +914,10 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     // of the benchmark film: four) is over before a steady state forms: its length is a few path latencies, and a path is
     // faster with three waves per SIMD than with four (MI355X, 1/8 share: 0.78 ms at 768 lanes against 0.84 at 1024; from a
     // quarter share upwards 1024 is as good or better).  Same film either way.
+    // (The kernel over the 4-wide nodes is fastest with 1024 lanes at every size: solo launch of a 1/8 share 0.49 ms against 0.53
+    // at 768, 0.64 at 512; whole film 2.59 / 2.97 / 3.94.)
     int lds_block_used = c->lds_block ? c->lds_block : 1024;
-    if (lds_kernel && !pool_kernel && c->lds_block == 0 &&
+    if (lds_kernel && !lds4_kernel && !pool_kernel && c->lds_block == 0 &&
         ((long long)p.nitems * chunk << (c->tile_w_shift + c->tile_h_shift)) < 6ll * launch_cus * 1024) lds_block_used = 768;
     p.timeline = nullptr;
     if (c->timeline && lds_kernel) {

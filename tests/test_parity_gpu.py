@@ -324,8 +324,8 @@ def test_image_hint_is_advice_only(fresh):
 
 
 def test_workgroup_size_does_not_change_the_film(fresh):
-    '''the LDS-resident kernel picks its persistent workgroup by the launch's size (768 lanes below six samples per lane,
-    1024 above: miptina.cpp); whatever is picked or forced -- 256, 512, 768, 1024 lanes, i.e. 1 to 4 waves per SIMD sharing
+    '''the LDS-resident kernel over the binary nodes picks its persistent workgroup by the launch's size (768 lanes below six
+    samples per lane, 1024 above: miptina.cpp), the one over the 4-wide nodes always takes 1024; whatever is picked or forced -- 256, 512, 768, 1024 lanes, i.e. 1 to 4 waves per SIMD sharing
     the scheduler's passes differently -- the film is the same bit for bit, on a film small enough for the rule's small side
     and on one on its large side'''
     from ptina_amd.things import FilmTable
