@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 '''GPU-box stress (not a test): 40 seeded random scenes (1..900 triangles beside the walls, random opaque materials, lights,
-film sizes, spp and batch sizes) through the strict build and the three production kernels; prints each kernel's distance
+film sizes, spp and batch sizes) through the strict build and the four production kernels (LDS-resident over 4-wide and over binary nodes, binary gather, 4-wide gather); prints each kernel's distance
 from the strict film and whether the LDS-resident and binary gather kernels agree bit for bit.  Round 3: all 40 agree bit for
 bit between kernels, outliers <= 0.04 % (bound 0.5 %); the three rel-RMSE marks are single firefly pixels where the STRICT
 build and the oracle differ by one libm-last-bit decision (seed 129 checked against the oracle).'''
@@ -37,7 +37,8 @@ for seed in range(100, 140):
     world=([float(x) for x in rng.uniform(0,0.4,3)]+[1.0],-1)
     nx,ny,spp=int(rng.integers(20,200)),int(rng.integers(20,160)),int(rng.integers(1,40))
     imgs={}
-    for name,mode,opts in (('strict','strict',{}),('lds','fast',{}),('bin','fast',{'lds':0,'wide':0}),('wide','fast',{'lds':0})):
+    kernels={}
+    for name,mode,opts in (('strict','strict',{}),('lds4','fast',{}),('lds','fast',{'lds_wide':0}),('bin','fast',{'lds':0,'wide':0}),('wide','fast',{'lds':0})):
         reset_all()
         eng=setup_engine(scene,nx,ny,mode=mode,lights=lights,world=world)
         for a,b in opts.items(): ctx().set_option(a,b)
@@ -46,14 +47,16 @@ for seed in range(100, 140):
         raw=FilmTable().get_raw().reshape(nx,ny,4)
         assert np.all(raw[...,3]==spp), (seed,name)
         imgs[name]=FilmTable().get_image()
+        kernels[name]=ctx().get_option('last_kernel')
     msg=[]
-    for name in ('lds','bin','wide'):
+    for name in ('lds4','lds','bin','wide'):
         d,refn,rel=image_stats(imgs[name],imgs['strict'])
         out=float((d>FAST[0]*(1+refn)).mean())
         ok = out<=FAST[1]*2 and rel<=FAST[2]*2
         if not ok: bad+=1
         msg.append(f'{name} rel {rel:.1e} out {out*100:.2f}%'+('' if ok else ' <<<<'))
     same=np.array_equal(imgs['lds'].view(np.uint32),imgs['bin'].view(np.uint32))
-    print(seed,k+10,'tris',nx,ny,spp,'|',' | '.join(msg),'| lds==bin',same,flush=True)
+    same4=float((imgs['lds4'].view(np.uint32)==imgs['lds'].view(np.uint32)).all(axis=-1).mean())
+    print(seed,k+10,'tris',nx,ny,spp,'|',' | '.join(msg),'| lds==bin',same,'| lds4==lds on %.3f %% of the pixels'%(100*same4),'| kernels',kernels,flush=True)
 print('bad',bad)
 reset_all()
