@@ -292,12 +292,18 @@ struct GlobalScene {
     }
 };
 
+// The triangle a ray left from is filtered by the LEAF step (one compare) instead of by the 4-wide NODE step (four compares and
+// four mask merges): its own leaf is then visited once per ray that starts on a surface -- three gathers -- and it is still
+// cheaper: MI355X C4 1583 -> 1607, C5 804 -> 824 Msamples/s (alternated twice)
+#ifndef MPT_WIDE_AVOID_IN_LEAF
+#define MPT_WIDE_AVOID_IN_LEAF 1
+#endif
 // 4-wide nodes gathered from HBM / L2 / Infinity Cache (scenes that do not fit LDS): a traversal step is one
 // 128-B record and four box tests, and a ray makes half as many DEPENDENT fetches as through the binary tree --
 // those fetches, not their bytes, are what bounds the big scenes (measured: binary16 boxes at half the bytes
 // bought 3-7 %)
 struct WideScene {
-    static constexpr bool AVOID_IN_LEAF = false;
+    static constexpr bool AVOID_IN_LEAF = MPT_WIDE_AVOID_IN_LEAF != 0;
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr int NODE_REP = MPT_WIDE_REP;
     static constexpr bool WIDE = true, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
@@ -349,7 +355,7 @@ struct WideScene {
 // for is the number of divergent gathers, not bytes -- and the 36 extra VALU instructions of the decode are free
 // at 34-43 % issue utilisation.
 struct QuantScene {
-    static constexpr bool AVOID_IN_LEAF = false;
+    static constexpr bool AVOID_IN_LEAF = MPT_WIDE_AVOID_IN_LEAF != 0;
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr int NODE_REP = MPT_WIDE_REP;      // extra NODE steps per scheduling decision
     static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;

@@ -529,10 +529,11 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
         k0 = min(a0, b0); k3 = max(a1, b1); k1 = min(m0, m1); k2 = max(m0, m1);
         id0 = (int)(short)(k0 & 0xffffu); id1 = (int)k1; id2 = (int)k2; id3 = (int)k3;      // (the pushes store the low halves)
     } else {
-        k0 = (h0 && id0 != L.navoid) ? (unsigned)__float_as_int(t0) : MISS;
-        k1 = (h1 && id1 != L.navoid) ? (unsigned)__float_as_int(t1) : MISS;
-        k2 = (h2 && id2 != L.navoid) ? (unsigned)__float_as_int(t2) : MISS;
-        k3 = (h3 && id3 != L.navoid) ? (unsigned)__float_as_int(t3) : MISS;
+        if constexpr (!SCENE::AVOID_IN_LEAF) { h0 = h0 && id0 != L.navoid; h1 = h1 && id1 != L.navoid; h2 = h2 && id2 != L.navoid; h3 = h3 && id3 != L.navoid; }
+        k0 = h0 ? (unsigned)__float_as_int(t0) : MISS;
+        k1 = h1 ? (unsigned)__float_as_int(t1) : MISS;
+        k2 = h2 ? (unsigned)__float_as_int(t2) : MISS;
+        k3 = h3 ? (unsigned)__float_as_int(t3) : MISS;
 #define MPT_CSWAP(ka, ia, kb, ib) { bool sw = kb < ka; unsigned tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
                                     int ti_ = sw ? ib : ia; ib = sw ? ia : ib; ia = ti_; }
         MPT_CSWAP(k0, id0, k1, id1) MPT_CSWAP(k2, id2, k3, id3) MPT_CSWAP(k0, id0, k2, id2) MPT_CSWAP(k1, id1, k3, id3)
