@@ -1824,6 +1824,27 @@ def test_config4_full_scene_with_environment_vs_oracle(fresh, oracle_mod):
     reset_all()
 
 
+def test_headline_film_is_the_same_over_4wide_and_binary_nodes(fresh):
+    '''BASELINE configs[1] at full size (512 x 512 x 32 spp) through the LDS-resident kernel over the 4-wide nodes (shipped) and over
+    the binary nodes: another tree shape, another order among equally distant candidates, the same closest hits -- measured
+    bit-identical in every pixel; the bound leaves room for a tie or two'''
+    from helpers import assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    films = {}
+    for lds_wide in (1, 0):
+        reset_all()
+        eng = _engine(None, scenes.scene_s978(), 512, 512, mode='fast')
+        ctx().set_option('lds_wide', lds_wide)
+        eng.render(32)
+        films[lds_wide] = (FilmTable().get_raw().copy(), FilmTable().get_image().copy())
+        assert ctx().get_option('last_kernel') == (5 if lds_wide else 1)
+    reset_all()
+    same = (films[1][0].view(np.uint32) == films[0][0].view(np.uint32)).all(axis=-1).mean()
+    assert np.all(films[1][0][:, 3] == 32) and same >= 0.9999, same
+    assert_parity(films[1][1], films[0][1], *FAST, what='headline film: 4-wide vs binary nodes in LDS')
+
+
 def test_kernel_ladder_by_scene_size(fresh):
     '''which kernel serves a scene is decided by what fits a CU's 160 KiB of LDS beside the stacks (miptina.cpp): the 4-wide
     nodes with exact boxes (112 B a node, about half a node per triangle) and the triangles, else the 4-wide 8-bit nodes gathered
