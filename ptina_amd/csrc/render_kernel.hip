@@ -1069,7 +1069,13 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
         unsigned long long m_new = __ballot(L.st == ST_NEW);
         if (m_new != 0ull) {
             if (next >= S && more) {                // pool drained: fetch the next work item right away,
+#if MPT_X_STAMPS == 3       // diagnostic: cycles (units of 16) inside the pull and inside the preparation of 64 primary rays, of NEW's total
+                const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
                 int item = wq.pull();               // while the other lanes are still busy (no per-item tail)
+#if MPT_X_STAMPS == 3
+                if (COUNT && (threadIdx.x & 63) == 0) cnt.pl_local += (unsigned)((__builtin_amdgcn_s_memtime() - tp0) >> 4);
+#endif
                 if (item < 0) {
                     more = false;
 #if MPT_X_TAIL_PRIO
@@ -1106,7 +1112,19 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                     const int smp = pool_base + lane;
                     const int q = smp & ((1 << tps) - 1);
                     const int i = ti + (q >> ths), j = tj + (q & ((1 << ths) - 1));
+#if MPT_X_STAMPS == 3
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
                     pool_prepare(p, pool, smp < S && i < p.x1 && j < p.ny, i, j, f0 + (smp >> tps));
+#if MPT_X_STAMPS == 3
+                    {   // (the rays are used right below: make the wait for the Sobol gathers part of this segment)
+                        float sink = pool.rd.x + pool.ro.x;
+                        asm volatile("" :: "v"(sink));
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (COUNT && (threadIdx.x & 63) == 0) cnt.pl_batches += (unsigned)((__builtin_amdgcn_s_memtime() - tq0) >> 4);
+                    }
+#endif
                 }
                 // idle lanes take the next consecutive samples (neighbouring pixels of one frame)
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_new >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_new, 0u));

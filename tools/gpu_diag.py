@@ -595,7 +595,10 @@ def stamps(name='s978', spp=32, n=512):
     res['rest'] = 1.0 - sum(res.values())
     res['stages_per_64_samples'] = {s: k['it_' + s] / k['samples'] * 64 for s in ('node', 'leaf', 'shade', 'new')}
     res['cycles_per_stage'] = {s: v * 256 / max(k['it_' + s], 1) for s, v in (('node', k['n_box']), ('leaf', k['n_tri']), ('shade', k['n_shade']), ('new', k['bounces']))}
-    if k.get('pl_local', 0):         # -DMPT_X_STAMPS=2: the segments of SHADE, cycles per SHADE stage
+    if os.environ.get('STAMPS3'):     # -DMPT_X_STAMPS=3: of NEW's cycles, the pull (once per work item) and the preparation of 64 primary rays
+        res['new_segments_cycles_per_64_samples'] = {'pull': k['pl_local'] * 16 / k['samples'] * 64, 'prepare': k['pl_batches'] * 16 / k['samples'] * 64,
+                                                     'new_total': k['bounces'] * 256 / k['samples'] * 64}
+    elif k.get('pl_local', 0):         # -DMPT_X_STAMPS=2: the segments of SHADE, cycles per SHADE stage
         seg = (('lights_hit', 'pl_local'), ('geometry_material_after_gathers', 'pl_batches'), ('light_sample', 'pl_batch_lanes'),
                ('bsdf_eval_mis', 'pl_prim'), ('bsdf_sample', 'pl_tidle'), ('ray_start', 'pl_sidle'))
         res['shade_segments_cycles'] = {a: k[b] * 16 / max(k['it_shade'], 1) for a, b in seg}
