@@ -264,12 +264,19 @@ struct Stack {
 #ifndef MPT_WIDE_REP
 #define MPT_WIDE_REP 0        // extra 4-wide NODE steps per decision (gather kernels)
 #endif
+#ifndef MPT_LEAF_REP
+#define MPT_LEAF_REP 1        // extra LEAF steps per decision, LDS-resident kernels (0 / 1 / 2 -> 3.83 / 3.72 / 3.77 ms with two extra NODE steps)
+#endif
+#ifndef MPT_WIDE_LEAF_REP
+#define MPT_WIDE_LEAF_REP 0   // ... gather kernels: MI355X C5 822 -> 853 Msamples/s with none instead of one, C4 1606 -> 1597 (alternated twice)
+#endif
 #ifndef MPT_LDS4_REP
 #define MPT_LDS4_REP 1        // ... of the LDS-resident 4-wide kernel
 #endif
 
 // scene records served from HBM/L2 through the vector L1 (any scene size)
 struct GlobalScene {
+    static constexpr int LEAF_REP = MPT_WIDE_LEAF_REP;
     static constexpr bool AVOID_IN_LEAF = false;
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr int NODE_REP = MPT_NODE_REP;
@@ -303,6 +310,7 @@ struct GlobalScene {
 // those fetches, not their bytes, are what bounds the big scenes (measured: binary16 boxes at half the bytes
 // bought 3-7 %)
 struct WideScene {
+    static constexpr int LEAF_REP = MPT_WIDE_LEAF_REP;
     static constexpr bool AVOID_IN_LEAF = MPT_WIDE_AVOID_IN_LEAF != 0;
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr int NODE_REP = MPT_WIDE_REP;
@@ -355,6 +363,7 @@ struct WideScene {
 // for is the number of divergent gathers, not bytes -- and the 36 extra VALU instructions of the decode are free
 // at 34-43 % issue utilisation.
 struct QuantScene {
+    static constexpr int LEAF_REP = MPT_WIDE_LEAF_REP;
     static constexpr bool AVOID_IN_LEAF = MPT_WIDE_AVOID_IN_LEAF != 0;
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr int NODE_REP = MPT_WIDE_REP;      // extra NODE steps per scheduling decision
@@ -420,6 +429,7 @@ struct SpillStack {
 // eight box tests; the order the children are met in is slot XOR the ray's direction octant -- no sort -- and a node leaves at most
 // two stack entries behind (its other internal hits, its other leaf hits), each a (base | mask, slots to go) pair
 struct OctScene {
+    static constexpr int LEAF_REP = MPT_WIDE_LEAF_REP;
     static constexpr bool AVOID_IN_LEAF = false;
     static constexpr int SHADE_MIN = 0;
     static constexpr int NODE_REP = 0;
@@ -493,6 +503,7 @@ struct LdsSceneT {
 #define MPT_SHADE_MIN_LDS 24
 #endif
     static constexpr bool PRESCALED_IDS = PRESCALED;
+    static constexpr int LEAF_REP = MPT_LEAF_REP;
     static constexpr bool AVOID_IN_LEAF = false;
     static constexpr int NODE_REP = MPT_NODE_REP;
     static constexpr int SHADE_MIN = MPT_SHADE_MIN_LDS; // SHADE waits until this many lanes want it (render_kernel.hip trace_stream)
@@ -559,6 +570,7 @@ struct Stack16 {
 #define MPT_LDS4_AVOID_IN_LEAF 1   // the triangle a ray left from is filtered by the LEAF step (one compare) instead of by the NODE step (four)
 #endif
 struct LdsWideScene {
+    static constexpr int LEAF_REP = MPT_LEAF_REP;
     static constexpr bool PRESCALED_IDS = true;
     static constexpr bool AVOID_IN_LEAF = MPT_LDS4_AVOID_IN_LEAF != 0;
     static constexpr int NODE_REP = MPT_LDS4_REP;

@@ -863,9 +863,6 @@ DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(by
 #define MPT_LEAVE_A 2    // leave traversal mode when traversing * A < waiting * B
 #define MPT_LEAVE_B 1
 #endif
-#ifndef MPT_LEAF_REP
-#define MPT_LEAF_REP 1        // extra LEAF steps per decision (0 / 1 / 2 -> 3.83 / 3.72 / 3.77 ms with two extra NODE steps)
-#endif
 // Diagnostic build (-DMPT_X_STAMPS=1, counting kernels only): the shader-clock cycles each wave spends in each
 // stage, accumulated into the counters named in MPT_STAMP_END instead of their usual meaning (tools/gpu_diag.py stamps)
 #if MPT_X_STAMPS
@@ -1000,9 +997,8 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                     if constexpr (SCENE::OCT) stage_leaf8<COUNT>(sc, stk, L, cnt);
                     else stage_leaf<COUNT>(sc, stk, L, cnt);
                 }
-#if MPT_LEAF_REP
 #pragma unroll
-                for (int rep = 0; rep < MPT_LEAF_REP; rep++) {
+                for (int rep = 0; rep < SCENE::LEAF_REP; rep++) {
                     if (__ballot(L.st == ST_LEAF) == 0ull) break;
                     if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
                     if (L.st == ST_LEAF) {
@@ -1010,7 +1006,6 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                         else stage_leaf<COUNT>(sc, stk, L, cnt);
                     }
                 }
-#endif
                 MPT_STAMP_END(acc_leaf)
             }
         }
