@@ -224,6 +224,10 @@ int mpt_reset_counters(mpt_ctx *ctx);
  * while the enqueued render launches keep running, and return the wall time until it has completed --
  * what a collective's kernel would wait for a CU beside the persistent render workgroups. */
 int mpt_probe_kernel(mpt_ctx *ctx, int threads, int lds_bytes, double *usec);
+/* Test door (the tail finalisation's soak: tools/soak.py, tests/test_parity_gpu.py): enqueue `count` device-to-device copies of
+ * `mbytes` MiB on a stream of their own and return at once -- HBM / L2 traffic beside the render launches; count = 0 waits for
+ * the copies enqueued so far.  Nothing in the reference corresponds (its film add is one kernel's `+=`, ptina/engine/path.py:93). */
+int mpt_stress_copies(mpt_ctx *ctx, int mbytes, int count);
 /* HIP-event time of the render kernels launched since the last call (ms) and their count */
 int mpt_kernel_time(mpt_ctx *ctx, double *ms, int *launches);
 

@@ -91,6 +91,7 @@ SIGNATURES = {
     'mpt_get_timeline': (_i, [_vp, C.POINTER(C.c_ulonglong), _i, C.POINTER(_i)]),
     'mpt_reset_counters': (_i, [_vp]),
     'mpt_probe_kernel': (_i, [_vp, _i, _i, C.POINTER(C.c_double)]),
+    'mpt_stress_copies': (_i, [_vp, _i, _i]),
     'mpt_kernel_time': (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     'mpt_unit_eval': (_i, [_vp, _i, _vp, _i, _vp, _i, _i]),
     'mpt_comm_unique_id': (_i, [C.c_char_p]),

@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void combine_kernel(MptVec4 *__restrict__ film
     const size_t pix = (size_t)x * ny + y;
     MptVec4 a = film[pix];
     for (int c = 0; c < nframes; c++) {
-        MptVec4 b = partial[(size_t)c * stride + t];
-        film_add_sample(a, b.x, b.y, b.z);             // (b.w is the launch's slab tag: 1, or the ready flag of the tail finalisation)
+        const mpt_u4 b = ((const mpt_u4 *)partial)[(size_t)c * stride + t];       // film_ops.h: {r, g.hi | tag}{b, g.lo | tag}
+        film_add_sample(a, slab_r(b), slab_g(b), slab_b(b));
     }
     film[pix] = a;
 }

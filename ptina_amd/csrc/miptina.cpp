@@ -184,6 +184,8 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     mpt_comm_release(c);
     if (c->aux) hipStreamDestroy(c->aux);
     if (c->probe_stream) hipStreamDestroy(c->probe_stream);
+    if (c->stress_stream) { hipStreamSynchronize(c->stress_stream); hipStreamDestroy(c->stress_stream); }
+    hipFree(c->stress_buf);
     for (int k = 0; k < MPT_MAX_PIPE; k++) {
         if (c->rstream[k]) hipStreamDestroy(c->rstream[k]);
         if (c->ev_render[k]) hipEventDestroy(c->ev_render[k]);
@@ -304,6 +306,13 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
     } else if (k == "finalise") {
         if (value < 0 || value > 2) return fail("finalise must be 0 (combine pass), 1 (tail finalisation) or 2 (the same without the early image: A/B)");
         c->finalise = value;
+    } else if (k == "launch_seq") {
+        // test door: the number of the next launch minus one (its slab tag is 2 + number mod 65534), so that a test can walk
+        // the launches across the point where the tags come round and every slab is zeroed
+        if (value < 0) return fail("launch_seq must be >= 0");
+        if (mpt_flush(c)) return 1;
+        c->launch_seq = (unsigned)value;
+        c->tag_epoch = c->launch_seq / (unsigned)MPT_TAG_PERIOD;
     } else if (k == "pool") {
 #if !MPT_WITH_POOL
         if (value) return fail("this library is built without the pooled LDS kernel (an A/B build: make -C ptina_amd/csrc pool)");
@@ -381,6 +390,8 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "spin_us") *value = c->spin_us;
     else if (k == "finalise") *value = c->finalise;
     else if (k == "last_finalised") *value = c->last_finalised;
+    else if (k == "launch_seq") *value = (int)(c->launch_seq & 0x7fffffffu);
+    else if (k == "tag_wraps") *value = (int)c->tag_wraps;
     else if (k == "pool") *value = c->use_pool;
     else if (k == "skip_dark") *value = c->skip_dark;
     else if (k == "pool_shaders") *value = c->pool_shaders;
@@ -939,14 +950,23 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     // film pixels at the same time, and the main stream is what orders them.
     const bool fin = fast && c->finalise && ring_idle && !pool_kernel && p.nitems > 0;
     c->launch_seq++;
-    p.fin_counter = nullptr; p.image_out = nullptr; p.slab_tag = 1.0f;
+    p.fin_counter = nullptr; p.image_out = nullptr; p.slab_tag = MPT_TAG_COMBINE;
     c->film_version++;                           // this batch changes pass 0, whoever adds it
     if (fin) {
-        if (c->launch_seq % 4194304u == 0u)      // the tags come round again: no entry of any slab may still carry the old one
+        // the 16-bit tag both halves of every sample entry of this launch carry (film_ops.h): never 0 (fresh memory) or 1 (a launch
+        // that keeps the combine pass).  When the tags come round again no entry of any slab may still carry an old one: every slab
+        // is zeroed -- behind whatever still reads one (the ring is idle here, so only a combine pass of an earlier batch on the main
+        // stream can be pending: round-4 ADVICE), and in front of this launch (same stream)
+        const unsigned phase = c->launch_seq % (unsigned)MPT_TAG_PERIOD, epoch = c->launch_seq / (unsigned)MPT_TAG_PERIOD;
+        if (epoch != c->tag_epoch) {             // (told by the epoch, not by phase == 0: the launch with that number may have kept the combine pass)
+            c->tag_epoch = epoch;
+            HIP_TRY(hipStreamSynchronize(c->stream));
             for (int q = 0; q < MPT_MAX_PIPE; q++)
                 if (c->partial2[q]) HIP_TRY(hipMemsetAsync(c->partial2[q], 0, c->partial2_cap[q] * sizeof(MptVec4), rs));
+            c->tag_wraps++;
+        }
         p.fin_counter = c->d_work2[k] + 8 * MPT_QUEUE_STRIDE;
-        p.slab_tag = 2.0f + (float)(c->launch_seq % 4194304u);               // exact in f32; never 0 (fresh memory) or 1 (a combine-pass launch)
+        p.slab_tag = (unsigned)MPT_TAG_FIRST + phase;
         // everything the main stream still has to do to the film (an earlier batch's combine, a clear, a gather) comes first --
         // nothing, when the stream is idle (a step that ended with a read-back): then the event pair (8 us of API calls in front of
         // the launch, HIP trace of bench.py) is left out
@@ -1203,6 +1223,27 @@ extern "C" int mpt_probe_kernel(mpt_ctx *c, int threads, int lds_bytes, double *
     HIP_TRY(hipStreamSynchronize(c->probe_stream));
     auto t1 = std::chrono::steady_clock::now();
     if (usec) *usec = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    return 0;
+}
+
+// test door (tools/soak.py, the tail finalisation's soak test): `count` device-to-device copies of `mbytes` MiB enqueued on a stream
+// of their own -- HBM and L2 traffic beside the render launches, whose hand-off of samples between XCDs must not care.  Returns
+// at once; count = 0 waits for the copies enqueued so far.
+extern "C" int mpt_stress_copies(mpt_ctx *c, int mbytes, int count) {
+    if (use_ro(c)) return 1;
+    if (mbytes < 1 || mbytes > 4096 || count < 0 || count > 100000) return fail("stress_copies: mbytes in 1..4096, count in 0..100000");
+    if (!c->stress_stream) HIP_TRY(hipStreamCreateWithFlags(&c->stress_stream, hipStreamNonBlocking));
+    if (count == 0) { HIP_TRY(hipStreamSynchronize(c->stress_stream)); return 0; }
+    const size_t bytes = (size_t)mbytes << 20;
+    if (bytes != c->stress_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stress_stream));
+        hipFree(c->stress_buf); c->stress_buf = nullptr; c->stress_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&c->stress_buf, 2 * bytes));
+        HIP_TRY(hipMemsetAsync(c->stress_buf, 0x5a, 2 * bytes, c->stress_stream));
+        c->stress_bytes = bytes;
+    }
+    for (int k = 0; k < count; k++)
+        HIP_TRY(hipMemcpyAsync(c->stress_buf + ((k & 1) ? 0 : bytes), c->stress_buf + ((k & 1) ? bytes : 0), bytes, hipMemcpyDeviceToDevice, c->stress_stream));
     return 0;
 }
 

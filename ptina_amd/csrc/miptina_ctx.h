@@ -194,6 +194,9 @@ struct mpt_ctx {
     hipEvent_t ev_render[MPT_MAX_PIPE] = {};          // render of the batch on rstream[k] finished
     hipEvent_t ev_free[MPT_MAX_PIPE] = {};            // combine has consumed partial[k]
     hipStream_t probe_stream = nullptr;               // mpt_probe_kernel
+    hipStream_t stress_stream = nullptr;              // mpt_stress_copies: a stream of device-to-device copies beside the render
+    char *stress_buf = nullptr;                       // 2 x stress_bytes
+    size_t stress_bytes = 0;
     hipStream_t aux = nullptr;                        // Sobol advances + queue resets of the pipelined batches
     hipEvent_t ev_sobol2[MPT_MAX_PIPE] = {};          // Sobol points + zeroed queue heads of the batch on rstream[k] ready
     int pipe_depth = 0;                               // batches in flight (slots of P / partial / queue heads); 0 = auto
@@ -208,6 +211,8 @@ struct mpt_ctx {
     int finalise = 1;
     int spin_us = 20000;                              // mpt_get_image polls a finalising launch for this long before it blocks
     unsigned launch_seq = 0;
+    unsigned tag_epoch = 0;                           // launch_seq / MPT_TAG_PERIOD when the slabs were last zeroed
+    unsigned tag_wraps = 0;                           // times the slab tags came round (every slab zeroed): a test reads it
     unsigned long long film_version = 0;
     float *hint_image = nullptr;
     float *early_ptr = nullptr;

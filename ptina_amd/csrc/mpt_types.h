@@ -100,6 +100,10 @@ struct MptImage { int32_t nx, ny, base, pad; };   // image.py:14-16
 #define MPT_LDS4_NODE_STRIDE 112     // bytes between the 4-wide node records in LDS (render_kernel_lds4: seven float4 of a wnode record)
 #endif
 
+// 16-bit tags of a launch's sample entries (film_ops.h): 0 = zeroed memory, 1 = a launch that keeps the combine pass, 2 ... 65535 =
+// finalising launches in turn
+enum { MPT_TAG_COMBINE = 1, MPT_TAG_FIRST = 2, MPT_TAG_PERIOD = 65534 };
+
 struct MptRenderParams {
     int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders
     int32_t nframes, chunk, nchunks, n;     // batch frames; frames per work item; items per tile; #triangles
@@ -142,12 +146,12 @@ struct MptRenderParams {
     unsigned int *watchdog;                  // host-pinned flag a persistent wave raises when it gives up
     // Tail finalisation (fast build): a wave that has run out of work sums, resolves and writes out the tiles
     // whose samples are all in the slab, while other waves still drain their last paths.  fin_counter: the next tile to
-    // finalise (zeroed with the queue heads), null = the combine pass does it after the launch; slab_tag: the w every sample
-    // of THIS launch is stored with (the ready flag of its 16-byte slab entry; 1 when fin_counter is null); image_out: where the
-    // resolved pixel goes as well (FilmTable.get_image's array, device-visible), or null
+    // finalise (zeroed with the queue heads), null = the combine pass does it after the launch; slab_tag: the 16-bit tag both
+    // 8-byte halves of every sample entry of THIS launch carry (their ready flags, film_ops.h; 1 when fin_counter is null);
+    // image_out: where the resolved pixel goes as well (FilmTable.get_image's array, device-visible), or null
     unsigned int *fin_counter;
     MptVec4 *image_out;
-    float slab_tag;
+    uint32_t slab_tag;                       // MPT_TAG_COMBINE, or MPT_TAG_FIRST + launch number mod MPT_TAG_PERIOD
     int32_t pad3;
     unsigned long long *timeline;            // diagnostics: per wave {start, scene ready, queue empty, exit} in
                                              // 100 MHz ticks, or null

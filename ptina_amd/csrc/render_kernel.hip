@@ -298,32 +298,33 @@ DEV void lane_draws(const MptRenderParams &p, LaneState &L, float *out) {
 }
 
 // One sample's radiance into the launch's slab, path.py:93 (the combine pass or the tail finalisation adds the frames in order).
-// The entry's w is the launch's tag: with the tail finalisation on, the 16 bytes are stored write-through (sc1: they leave this
-// XCD's L2 at once, where a finishing wave of any other XCD can see them) and the tag says that they have arrived -- the data is
-// the flag, one store, nothing to order (MI355X_MICROARCH.md, visibility: R2 granules; 16-B sc1 stores observed untorn).
+// The entry is two self-validating 8-byte granules (film_ops.h: slab_pack), each written by ONE naturally aligned 8-byte store --
+// single-copy atomic -- and write-through (sc1: it leaves this XCD's L2 at once, where a finishing wave of any other XCD can see
+// it): a half that carries the launch's tag carries its data, so the data is the flag, nothing to order, no fence and no atomic
+// in the shading pass (the guide's R2 form: cdna_hip_programming.md Guideline 16, Pitfall 8 "ONE aligned 8-B store").
 // Inline asm, because the builtin that takes cache bits wants a buffer descriptor (four more scalar registers held through the
-// traversal loop); the compiler does not count this store in its vmcnt bookkeeping, which only makes its own waits stricter.
-// (Every launch stores that way, finalising or not: a 16-byte sc1 store costs what a plain one does, and a wave-uniform choice
-//  between the two in the shading pass cost the whole kernel 4 % -- the pass is short of scalar registers.)
+// traversal loop); the compiler does not count these stores in its vmcnt bookkeeping, which only makes its own waits stricter.
+// (Every launch stores that way, finalising or not: sc1 stores cost what plain ones do, and a wave-uniform choice between the two
+//  in the shading pass cost the whole kernel 4 % -- the pass is short of scalar registers.  -DMPT_SC1_STORES=0: plain stores, an
+//  A/B build whose tail finalisation must stay off.)
 #ifndef MPT_SC1_STORES
-#define MPT_SC1_STORES 1      // 0: plain stores (A/B; the tail finalisation must then stay off)
+#define MPT_SC1_STORES 1
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "render_kernel.hip is written for gfx950 (MI355X): the sc1 cache bit of the sample stores and the LDS sizes are that target's"
+#endif
+typedef unsigned int mpt_u2 __attribute__((ext_vector_type(2)));
 DEV void store_sample(const MptRenderParams &p, int frame, int pix, V3 radiance) {
     MptVec4 *dst = p.partial + ((size_t)frame * (size_t)p.partial_stride + pix);
-#if MPT_SC1_STORES == 1
-    mpt_f4 v = { radiance.x, radiance.y, radiance.z, p.slab_tag };
+    const mpt_u4 v = slab_pack(radiance.x, radiance.y, radiance.z, p.slab_tag);
+#if MPT_SC1_STORES == 3       // (A/B: the same entry behind ONE 16-byte store, round 4's shape -- what the second store instruction costs)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
-#elif MPT_SC1_STORES == 2     // (A/B: the round-4 first attempt, a wave-uniform choice)
-    if (p.fin_counter) {
-        mpt_f4 v = { radiance.x, radiance.y, radiance.z, p.slab_tag };
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
-        return;
-    }
-    MptVec4 o; o.x = radiance.x; o.y = radiance.y; o.z = radiance.z; o.w = p.slab_tag;
-    *dst = o;
+#elif MPT_SC1_STORES
+    const mpt_u2 lo = { v.x, v.y }, hi = { v.z, v.w };
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\tglobal_store_dwordx2 %0, %2, off offset:8 sc1\n\ts_nop 1"
+                 : : "v"(dst), "v"(lo), "v"(hi) : "memory");
 #else
-    MptVec4 o; o.x = radiance.x; o.y = radiance.y; o.z = radiance.z; o.w = p.slab_tag;
-    *dst = o;
+    *(mpt_u4 *)dst = v;
 #endif
 }
 
@@ -1188,7 +1189,6 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
 // stored write-through (store_sample) and are read here with sc1 loads (L1 bypassed, re-read every pass: R2 of the guide).
 // Nothing waits for a finishing wave, and what IT waits for is in the hands of waves that are running (every item has been pulled
 // before the first wave gets here), so the loop ends; a bounded spin raises the watchdog instead of hanging if it ever does not.
-typedef unsigned int mpt_u4 __attribute__((ext_vector_type(4)));
 DEV mpt_u4 slab_load_sc1(const MptVec4 *frame_base, unsigned frame_bytes, unsigned byte_off) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)frame_base, (short)0, (int)frame_bytes, 0x00020000);
 #ifndef MPT_FIN_AUX
@@ -1216,7 +1216,7 @@ struct FinArgs {
     MptVec4 *partial, *film0, *image_out;
     unsigned int *fin_counter, *watchdog;
     int tile_w_shift, tile_h_shift, ny, nitems, nchunks, nframes, partial_stride, stripe_w, stripe_pitch, x0, x1;
-    float slab_tag;
+    unsigned slab_tag;
 };
 DEV int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <class T> DEV T *uniform_p(T *ptr) {
@@ -1233,7 +1233,7 @@ __device__ __attribute__((noinline)) int finalise_tiles_impl(
 #endif
         MptVec4 *a_partial, MptVec4 *a_film0, MptVec4 *a_image_out, unsigned int *a_fin_counter, unsigned int *a_watchdog,
         int a_tws, int a_ths, int a_ny, int a_nitems, int a_nchunks, int a_nframes, int a_partial_stride, int a_stripe_w,
-        int a_stripe_pitch, int a_x0, int a_x1, float a_slab_tag) {
+        int a_stripe_pitch, int a_x0, int a_x1, unsigned a_slab_tag) {
     FinArgs p;
     p.partial = a_partial; p.film0 = a_film0; p.image_out = a_image_out; p.fin_counter = a_fin_counter; p.watchdog = a_watchdog;
     p.tile_w_shift = a_tws; p.tile_h_shift = a_ths; p.ny = a_ny; p.nitems = a_nitems; p.nchunks = a_nchunks; p.nframes = a_nframes;
@@ -1249,7 +1249,8 @@ __device__ __attribute__((noinline)) int finalise_tiles_impl(
     const int ntile = p.nitems / p.nchunks;                 // items are tile-major: nchunks per tile
     const int B = p.nframes;
     const unsigned frame_bytes = (unsigned)p.partial_stride * 16u;      // (a frame of the slab is far below 4 GiB: the film's cap is 2^26 pixels)
-    const unsigned tag = (unsigned)__float_as_int(p.slab_tag);
+    const unsigned tag = p.slab_tag;
+    const mpt_u4 absent = slab_pack(0.0f, 0.0f, 0.0f, tag);     // a frame past the batch's end, a pixel past the film's edge: ready, adds nothing
     const unsigned long long t_begin = wall_clock64();
     int done = 0;
     for (;; done++) {
@@ -1274,9 +1275,9 @@ __device__ __attribute__((noinline)) int finalise_tiles_impl(
                     bool ready = true;
 #pragma unroll
                     for (int k = 0; k < GROUP; k++) {
-                        v[k] = mpt_u4{ 0u, 0u, 0u, tag };
+                        v[k] = absent;
                         if (f0 + k < B && inside) v[k] = slab_load_sc1(p.partial + (size_t)(f0 + k) * (size_t)p.partial_stride, frame_bytes, off);
-                        ready = ready && v[k].w == tag;
+                        ready = ready && slab_ready(v[k], tag);       // each 8-byte half on its own tag (film_ops.h)
                     }
                     if (__ballot(!ready) == 0ull) break;
                     if (wall_clock64() - t_begin > 400000000ull) {       // 4 s at 100 MHz: some sample never came
@@ -1287,7 +1288,7 @@ __device__ __attribute__((noinline)) int finalise_tiles_impl(
                 }
 #pragma unroll
                 for (int k = 0; k < GROUP; k++)
-                    if (f0 + k < B) film_add_sample(acc, __uint_as_float(v[k].x), __uint_as_float(v[k].y), __uint_as_float(v[k].z));
+                    if (f0 + k < B) film_add_sample(acc, slab_r(v[k]), slab_g(v[k]), slab_b(v[k]));
             }
             if (inside) {
                 p.film0[pix] = acc;

@@ -377,8 +377,7 @@ DEV void pool_shader(const MptRenderParams &p, const SCENE &sc, const PoolView p
                 // a miss ends the path in the shader: the sample is stored (path.py:93; what lane_next_bounce does at depth 5)
                 const bool ended = mine && nextk == SH_END;
                 if (ended) {
-                    MptVec4 o; o.x = L.result.x; o.y = L.result.y; o.z = L.result.z; o.w = 1.0f;
-                    p.partial[(size_t)L.frame * (size_t)p.partial_stride + L.pix] = o;
+                    store_sample(p, L.frame, L.pix, L.result);
                 }
                 pool_path_ends<COUNT>(pv, ended);
                 const bool out = mine && nextk != SH_END;

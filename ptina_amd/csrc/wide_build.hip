@@ -60,8 +60,8 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__re
                                                             int count, int empty_id, MptVec4 *__restrict__ wnode, MptVec4 *__restrict__ qnode,
                                                             int *__restrict__ ncount, unsigned long long *__restrict__ area_sum) {
     const int t = blockIdx.x * WB_BLOCK + threadIdx.x;
-    if (t >= count) return;
-    const int w = lo + t;
+    const bool live = t < count;
+    const int w = lo + (live ? t : 0);                        // (lanes past the level stay for the wave reduction below and add 0)
     WbChild ch[4];
     int cnt = 2;
     wb_children_of(fnode, bin_of[w], ch);
@@ -69,12 +69,12 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__re
         // the expected fetches per ray (informational: option "wide_ratio_permille")
         WbChild own = ch[0];
         for (int a = 0; a < 3; a++) { own.lo[a] = fminf(ch[0].lo[a], ch[1].lo[a]); own.hi[a] = fmaxf(ch[0].hi[a], ch[1].hi[a]); }
-        const unsigned long long q = wb_area_fixed(fnode, wb_area(own));
+        const unsigned long long q = live ? wb_area_fixed(fnode, wb_area(own)) : 0ull;
         unsigned long long tot = q;                           // one atomic per wave, and integers: the sum does not depend on the order
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-        const unsigned long long act = __ballot(true);
-        if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) atomicAdd(area_sum, tot);
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);      // every lane of the wave is active here (no early return)
+        if ((threadIdx.x & 63) == 0 && tot) atomicAdd(area_sum, tot);
     }
+    if (!live) return;
     while (cnt < 4) {
         int best = -1; float ba = -1.f;
         for (int k = 0; k < cnt; k++)

@@ -57,19 +57,43 @@ def env_rank():
         int(os.environ.get('LOCAL_RANK', '0'))
 
 
+def _torchrun_job_dir():
+    '''under torch.distributed.run the workers are children of ONE agent process: its pid, MASTER_PORT and the run id name the
+    job.  The directory lives under a per-user directory of mode 0700 that must be a real directory owned by this user (nobody
+    else can pre-create, symlink or read what the ranks leave there); None when not under torchrun'''
+    if not ('TORCHELASTIC_RUN_ID' in os.environ or 'TORCHELASTIC_RESTART_COUNT' in os.environ):
+        return None
+    import stat
+    import tempfile
+    base = os.path.join(tempfile.gettempdir(), 'miptina_%d' % os.getuid())
+    try:
+        os.mkdir(base, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(base)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError('%s is not a private directory of this user: remove it or set MIPTINA_RDZV_DIR' % base)
+    run = ''.join(ch if ch.isalnum() else '_' for ch in os.environ.get('TORCHELASTIC_RUN_ID', 'none'))[:32]
+    d = os.path.join(base, 'job_%s_%d_%s' % (os.environ.get('MASTER_PORT', '0'), os.getppid(), run))
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    return d
+
+
 def rendezvous_path():
     '''where rank 0 leaves the RCCL unique id for the other ranks of this node.
 
     * MIPTINA_RDZV_DIR set (launch_ranks() below makes a private directory per job and hands it to
       every rank through the environment): <dir>/rccl_uid -- nothing to collide with, nothing stale;
     * under torch.distributed.run the workers are children of ONE agent process, so its pid plus
-      MASTER_PORT names the job: /tmp/miptina_uid_<port>_<agent pid>;
+      MASTER_PORT (and the run id) names the job: <tmp>/miptina_<uid>/job_<port>_<agent pid>_<run id>/rccl_uid, the parent
+      a directory of mode 0700 owned by this user (_torchrun_job_dir);
     * ranks started any other way have no common key to derive: they must be given MIPTINA_RDZV_DIR.'''
     d = os.environ.get('MIPTINA_RDZV_DIR')
     if d:
         return os.path.join(d, 'rccl_uid')
-    if 'TORCHELASTIC_RUN_ID' in os.environ or 'TORCHELASTIC_RESTART_COUNT' in os.environ:
-        return '/tmp/miptina_uid_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+    d = _torchrun_job_dir()
+    if d:
+        return os.path.join(d, 'rccl_uid')
     raise RuntimeError('multi-rank run without a rendezvous: start the ranks with bench.py --gpus N, '
                        'ptina_amd.dist.launch_ranks() or torch.distributed.run, or give every rank the same '
                        'MIPTINA_RDZV_DIR')
@@ -104,13 +128,11 @@ def exchange_unique_id(make_uid, rank, world, timeout=120.0):
 
 def phase_dir():
     '''where the ranks of this job leave the name of the phase they are in (PhaseLog): the launcher's private directory,
-    or under torch.distributed.run a directory named after the agent (the workers' common parent) and its port'''
+    or under torch.distributed.run the job's directory under this user's private one (_torchrun_job_dir)'''
     d = os.environ.get('MIPTINA_RDZV_DIR')
     if d:
         return d
-    if 'TORCHELASTIC_RUN_ID' in os.environ or 'TORCHELASTIC_RESTART_COUNT' in os.environ:
-        return '/tmp/miptina_phase_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
-    return None
+    return _torchrun_job_dir()
 
 
 def read_phases(d, world):
@@ -142,6 +164,10 @@ class PhaseLog:
         self.name, self.t0, self.done = 'start', time.time(), False
         if self.dir:
             os.makedirs(self.dir, exist_ok=True)
+            try:                                    # (a file an earlier job with the same key left behind is not this rank's phase)
+                os.remove(os.path.join(self.dir, 'phase_%d' % self.rank))
+            except OSError:
+                pass
             self.enter('start')
             th = threading.Thread(target=self._watch, daemon=True)
             th.start()

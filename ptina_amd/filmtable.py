@@ -63,7 +63,17 @@ class FilmTable(metaclass=Singleton):
                 arr = None
         if arr is None:
             arr = host_array((nx, ny, 4))      # a fresh array, as in the reference; page-locked -> one DMA
-        ctx().call('mpt_get_image', int(id), fptr(arr))
+        try:
+            ctx().call('mpt_get_image', int(id), fptr(arr))
+        except Exception:
+            # the call may have failed before the library let go of the hinted address (a flush that fails): `arr` is about to be
+            # dropped and its page-locked buffer recycled for another array of the same size, so the library must forget it first
+            # (mpt_hint_image(None) also waits for a launch that may still be writing into it)
+            try:
+                ctx().call('mpt_hint_image', 0, None)
+            except Exception:
+                pass
+            raise
         return arr
 
     def fast_export_image(self, out, id=0):

@@ -106,3 +106,54 @@ def assert_parity(img, ref, pix_tol, max_outlier_frac, rel_rmse_tol, what=''):
     assert frac <= max_outlier_frac, msg
     assert rel_rmse <= rel_rmse_tol, msg
     return rel_rmse, frac
+
+
+def soak_finalisation(launches, nx=512, ny=512, frames=4, per_round=50, stripes=None, stress_mb=0, stress_copies=0, log=None):
+    '''The tail finalisation's hand-off (render_kernel.hip store_sample / finalise_tiles: a sample entry of the slab is two
+    8-byte granules that carry the launch's tag) checked on DATA: `per_round` launches of `frames` frames, each followed by a
+    get_image() (so every launch finds the GPU idle and finalises its own tiles), replayed from the same Sobol index with the
+    combine pass (option finalise = 0) once -- then round after round with the finalisation on, and the raw film must be the
+    combine pass's bit for bit every time.  A sample accepted before its data had arrived (a stale or torn entry) changes a sum.
+    stripes = (width, rank, world): a 1/world share as `bench.py --gpus world` deals it; stress_mb / stress_copies: that many
+    device-to-device copies of that size enqueued beside every round (mpt_stress_copies).  Returns the launches checked.'''
+    from ptina_amd import scenes
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd.things import FilmTable
+    from ptina_amd.sampling.sobol import SobolSampler
+    reset_all()
+    eng = setup_engine(scenes.scene_s978(), nx, ny, mode='fast', max_filmsize=max(nx * ny, 1 << 18))
+    c = ctx()
+    c.set_option('batch', frames)
+    if stripes:
+        c.call('mpt_set_stripes', *stripes)
+    film, sob = FilmTable(), SobolSampler()
+
+    def one_round(fin):
+        c.set_option('finalise', fin)
+        sob.reset()
+        film.clear()
+        for _ in range(per_round):
+            eng.render(frames)
+            film.get_image()
+            assert c.get_option('last_finalised') == fin
+        return film.get_raw()
+
+    want = one_round(0).view(np.uint32).copy()
+    assert np.all(want.view(np.float32)[:, 3] % (per_round * frames) == 0)
+    done, rounds = 0, 0
+    while done < launches:
+        if stress_mb and stress_copies:
+            c.call('mpt_stress_copies', int(stress_mb), int(stress_copies))
+        got = one_round(1).view(np.uint32)
+        if stress_mb and stress_copies:
+            c.call('mpt_stress_copies', int(stress_mb), 0)
+        bad = np.flatnonzero((got != want).any(axis=1))
+        assert bad.size == 0, ('finalised film differs from the combine pass film in %d pixels after %d launches: first %d, got %s, want %s'
+                               % (bad.size, done, bad[0], got[bad[0]].view(np.float32), want[bad[0]].view(np.float32)))
+        done += per_round
+        rounds += 1
+        if log and rounds % 20 == 0:
+            log('  %d launches bit-identical (%dx%d, %d frames per launch, stripes %s, stress %d x %d MiB per round)'
+                % (done, nx, ny, frames, stripes, stress_copies, stress_mb))
+    reset_all()
+    return done

@@ -176,7 +176,23 @@ def test_rendezvous_needs_a_common_key(monkeypatch):
         D.exchange_unique_id(lambda: bytes(128), 1, 2, timeout=0.1)
     monkeypatch.setenv('TORCHELASTIC_RUN_ID', 'none')        # torchrun: siblings under one agent
     monkeypatch.setenv('MASTER_PORT', '29511')
-    assert D.rendezvous_path() == '/tmp/miptina_uid_29511_%d' % os.getppid()
+    # ... in a directory of this user's own (mode 0700, not a symlink, not somebody else's: round-4 ADVICE), keyed by port, agent and run
+    import stat
+    import tempfile
+    path = D.rendezvous_path()
+    base = os.path.join(tempfile.gettempdir(), 'miptina_%d' % os.getuid())
+    assert path == os.path.join(base, 'job_29511_%d_none' % os.getppid(), 'rccl_uid')
+    st = os.lstat(base)
+    assert stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o077)
+    assert D.phase_dir() == os.path.dirname(path)
+    # a phase file an earlier job left under the same key is not this rank's phase
+    with open(os.path.join(D.phase_dir(), 'phase_1'), 'w') as f:
+        f.write('first gather 1.0')
+    log = D.PhaseLog(1, 2, timeout=1000)
+    assert D.read_phases(D.phase_dir(), 2)[1].startswith('start')
+    log.finish()
+    import shutil
+    shutil.rmtree(os.path.dirname(path))
 
 
 STUB_RANK = r'''

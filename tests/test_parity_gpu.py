@@ -198,8 +198,8 @@ def test_work_item_shape_does_not_change_the_film(fresh):
 
 def test_tail_finalisation_gives_the_combine_pass_film_and_image(fresh):
     '''option "finalise" (default 1): a render launch that has the chip to itself adds its frames to the film, resolves and writes
-    out finished tiles itself while its last paths drain (render_kernel.hip finalise_tiles: write-through slab entries whose w
-    is the launch's tag, sc1 re-reads until the tag is there); 0 = the combine pass after the launch.  Same raw film and same
+    out finished tiles itself while its last paths drain (render_kernel.hip finalise_tiles: write-through slab entries of two
+    8-byte granules that carry the launch's tag, sc1 re-reads until both tags are there); 0 = the combine pass after the launch.  Same raw film and same
     get_image() bits, every time: for the three production kernels (LDS-resident, 4-wide gather, binary gather), ragged films,
     several tile shapes and frames per work item, several batches in a row, a film that already holds sums, column slabs
     and stripes, the counting build, and the whole 512 x 512 x 32 benchmark film five times over (a hand-off that loses a
@@ -264,6 +264,38 @@ def test_tail_finalisation_gives_the_combine_pass_film_and_image(fresh):
     for a, b in zip(films[1], films[0]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert np.all(films[1][-1][:, 3] == 5 * 32 + 64)
+
+
+def test_tail_finalisation_soak_compares_the_data(fresh):
+    '''VERDICT r04 next #1.  300 + 200 + 200 finalising launches, each round of 50 replayed from the same Sobol index, and the raw film
+    must be the combine pass's bit for bit after every round -- the whole 512 x 512 film, a 1/8 share dealt in stripes (most of a
+    finishing wave's tiles are then somebody else's), a ragged film; the second and third with a stream of 1 GiB device-to-device
+    copies beside the render.  A sample accepted before its bytes had arrived would change a sum (tools/soak.py runs the same for
+    20 000 launches: profiles/r05_soak.log).  Then the tags coming round: the launch numbered 65534 zeroes every slab behind the
+    pending combine pass and starts the tags again, and nothing changes'''
+    from helpers import soak_finalisation
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    assert soak_finalisation(300) == 300
+    assert soak_finalisation(200, stripes=(16, 5, 8), stress_mb=1024, stress_copies=24) == 200
+    assert soak_finalisation(200, nx=500, ny=310, frames=3, stress_mb=1024, stress_copies=24) == 200
+    films = {}
+    for start in (0, 65534 - 6):
+        reset_all()
+        eng = _engine(None, scenes.scene_s978(), 96, 80, mode='fast')
+        c = ctx()
+        c.set_option('batch', 4)
+        c.set_option('launch_seq', start)
+        for k in range(12):
+            eng.render(4)
+            if k % 3 == 2:
+                eng.render(4)                               # a pipelined pair now and then: its second launch keeps the combine pass
+            FilmTable().get_image()
+        films[start] = FilmTable().get_raw().copy()
+        assert c.get_option('tag_wraps') == (1 if start else 0)
+    reset_all()
+    assert np.array_equal(films[0].view(np.uint32), films[65534 - 6].view(np.uint32))
+    assert np.all(films[0][:, 3] == 16 * 4)
 
 
 def test_image_hint_is_advice_only(fresh):

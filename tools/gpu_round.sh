@@ -18,6 +18,8 @@ run() {  # name seconds command...
 for step in "$@"; do
   case $step in
     smoke)       run smoke 300 python __graft_entry__.py smoke ;;
+    soak)        run soak 1000 python tools/soak.py ${SOAK_LAUNCHES:-20000} ;;
+    tests_soak)  run tests_soak 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'finalisation or hint or film_api' ;;
     diag)        run diag 600 python tools/gpu_diag.py parity timing ;;
     diag_parity) run diag_parity 400 python tools/gpu_diag.py parity ;;
     diag_timing) run diag_timing 500 python tools/gpu_diag.py timing ;;
