@@ -298,31 +298,28 @@ DEV void lane_draws(const MptRenderParams &p, LaneState &L, float *out) {
 }
 
 // One sample's radiance into the launch's slab, path.py:93 (the combine pass or the tail finalisation adds the frames in order).
-// The entry is two self-validating 8-byte granules (film_ops.h: slab_pack), each written by ONE naturally aligned 8-byte store --
-// single-copy atomic -- and write-through (sc1: it leaves this XCD's L2 at once, where a finishing wave of any other XCD can see
-// it): a half that carries the launch's tag carries its data, so the data is the flag, nothing to order, no fence and no atomic
-// in the shading pass (the guide's R2 form: cdna_hip_programming.md Guideline 16, Pitfall 8 "ONE aligned 8-B store").
-// Inline asm, because the builtin that takes cache bits wants a buffer descriptor (four more scalar registers held through the
-// traversal loop); the compiler does not count these stores in its vmcnt bookkeeping, which only makes its own waits stricter.
-// (Every launch stores that way, finalising or not: sc1 stores cost what plain ones do, and a wave-uniform choice between the two
-//  in the shading pass cost the whole kernel 4 % -- the pass is short of scalar registers.  -DMPT_SC1_STORES=0: plain stores, an
-//  A/B build whose tail finalisation must stay off.)
+// The entry is two self-validating 8-byte granules (film_ops.h: slab_pack), each written by ONE relaxed agent-scope 64-bit atomic
+// store -- single-copy atomic by the language's memory model; on gfx950 a `global_store_dwordx2 ... sc1`, i.e. write-through: it
+// leaves this XCD's L2 at once, where a finishing wave of any other XCD can see it.  A half that carries the launch's tag carries
+// its data, so the data is the flag: nothing to order, no fence and no read-modify-write in the shading pass (the guide's R2 form:
+// cdna_hip_programming.md Guideline 16, Pitfall 8 "ONE aligned 8-B store").  Every launch stores that way, finalising or not: a
+// wave-uniform choice between two store flavours in the shading pass cost the whole kernel 4 % (it is short of scalar registers).
+// Measured (MI355X, same box, three alternations, profiles/r05_ab_experiments.json): 2.603-2.613 ms per launch against 2.582-2.584
+// with the same entry behind ONE 16-byte sc1 store (-DMPT_SC1_STORES=16, round 4's shape, whose halves are only observed to land
+// together): the second store instruction costs 0.9 %, and buys a hand-off that rests on nothing but 64-bit atomicity.
+// (-DMPT_SC1_STORES=0: plain stores, an A/B build whose tail finalisation must stay off.)
 #ifndef MPT_SC1_STORES
 #define MPT_SC1_STORES 1
 #endif
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
-#error "render_kernel.hip is written for gfx950 (MI355X): the sc1 cache bit of the sample stores and the LDS sizes are that target's"
-#endif
-typedef unsigned int mpt_u2 __attribute__((ext_vector_type(2)));
 DEV void store_sample(const MptRenderParams &p, int frame, int pix, V3 radiance) {
     MptVec4 *dst = p.partial + ((size_t)frame * (size_t)p.partial_stride + pix);
     const mpt_u4 v = slab_pack(radiance.x, radiance.y, radiance.z, p.slab_tag);
-#if MPT_SC1_STORES == 3       // (A/B: the same entry behind ONE 16-byte store, round 4's shape -- what the second store instruction costs)
+#if MPT_SC1_STORES == 16
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
 #elif MPT_SC1_STORES
-    const mpt_u2 lo = { v.x, v.y }, hi = { v.z, v.w };
-    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\tglobal_store_dwordx2 %0, %2, off offset:8 sc1\n\ts_nop 1"
-                 : : "v"(dst), "v"(lo), "v"(hi) : "memory");
+    unsigned long long *d64 = (unsigned long long *)dst;
+    __hip_atomic_store(d64, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d64 + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     *(mpt_u4 *)dst = v;
 #endif
