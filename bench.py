@@ -223,35 +223,31 @@ def algorithmic_bytes(c):
 
 
 def host_threads():
-    '''threads for the CPU baseline: the cores this process may run on, capped at the GPU box's
-    per-GPU CPU share (16)'''
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, int(os.environ.get('MIPTINA_CPU_THREADS', '16'))))
-
-
-def cpu_baseline(scene, camera, budget_s=15.0):
-    '''the CPU restatement (oracle, kind "port") on this host's cores, on a column window of the
-    same 512x512 workload sized to ~budget_s of wall time'''
+    '''threads for the CPU baseline: the CPUs this process can really use (affinity mask capped by the cgroup quota: a GPU box
+    shows the host's 256 cores and gives one GPU's share of 16), capped at MIPTINA_CPU_THREADS (default 16)'''
     import oracle
+    return max(1, min(oracle.usable_cpus(), int(os.environ.get('MIPTINA_CPU_THREADS', '16'))))
+
+
+def _cpu_rate(oracle, scene, camera, threads, budget_s):
+    '''Msamples/s of the CPU restatement with `threads` OpenMP threads on a column window of the 512x512x32 workload sized to
+    ~budget_s of wall time (the whole job if it fits twice that); returns (rate, samples, seconds, x0, columns)'''
     from helpers import setup_oracle
-    threads = host_threads()
     o = setup_oracle(oracle, scene, NX, NY, camera=camera, threads=threads)
-    o.set_window(248, 248 + threads)
+    probe = min(threads, NX)
+    o.set_window((NX - probe) // 2, (NX - probe) // 2 + probe)
     o.render(1)                                   # thread start-up, page faults
     t0 = time.time()
     o.render(1)
-    per_col_frame = (time.time() - t0) / threads
+    per_col_frame = (time.time() - t0) / probe
     o.sobol_reset(64)
     frames = SPP
     full = per_col_frame * NX * frames            # estimated wall time of the whole workload
     if full <= 2 * budget_s:
         cols, x0 = NX, 0                          # the whole 512x512x32 job
     else:
-        cols = int(max(threads, NX * budget_s / full))
-        cols -= cols % threads
+        cols = int(max(probe, NX * budget_s / full))
+        cols -= cols % probe
         x0 = (NX - cols) // 2
     o.set_window(x0, x0 + cols)
     o.clear()
@@ -261,6 +257,22 @@ def cpu_baseline(scene, camera, budget_s=15.0):
     o.render(frames)
     dt = time.time() - t0
     samples = cols * NY * frames
+    return samples / dt / 1e6, samples, dt, x0, cols
+
+
+def cpu_baseline(scene, camera, budget_s=12.0):
+    '''the CPU restatement (oracle, kind "port") on this host's cores: with the GPU box's per-GPU CPU share (16 threads; `value`,
+    `cores`), with every core this process may run on (`value_all_cores`, `cores_all`: BASELINE.md section 2 asks for both the
+    1-thread and the all-thread figure; on a GPU box the cgroup quota IS 16 CPUs of the host's 256, and more threads than CPUs only
+    slow the run down: measured 0.52 Msamples/s with 256 threads against 2.5 with 16) and single-threaded -- each on a column window of the same 512x512x32 workload'''
+    import oracle
+    from helpers import setup_oracle
+    threads = host_threads()
+    rate, samples, dt, x0, cols = _cpu_rate(oracle, scene, camera, threads, budget_s)
+    allc = max(1, min(oracle.usable_cpus(), int(os.environ.get('MIPTINA_CPU_THREADS_ALL', '1024'))))
+    all_rate, all_samples, all_dt = rate, samples, dt
+    if allc != threads:
+        all_rate, all_samples, all_dt, _, _ = _cpu_rate(oracle, scene, camera, allc, budget_s / 2)
     # single-thread rate on 8 centre columns x 4 spp (SURVEY 8d asks for both figures)
     o1 = setup_oracle(oracle, scene, NX, NY, camera=camera, threads=1)
     o1.set_window(252, 260)
@@ -268,11 +280,80 @@ def cpu_baseline(scene, camera, budget_s=15.0):
     t1 = time.time()
     o1.render(4)
     one = 8 * NY * 4 / (time.time() - t1) / 1e6
-    return {'value': round(samples / dt / 1e6, 4), 'unit': 'Msamples/s', 'cores': threads, 'host_cores': os.cpu_count(),
+    return {'value': round(rate, 4), 'unit': 'Msamples/s', 'cores': threads, 'host_cores': os.cpu_count(),
             'kind': 'port',
+            'value_all_cores': round(all_rate, 4), 'cores_all': allc,
             'value_1thread': round(one, 4),
-            'sample': f'columns [{x0},{x0 + cols}) of the 512x512 film x {frames} spp = {samples} samples '
-                      f'in {dt:.1f} s (C restatement of PTina\'s algorithm, OpenMP, {threads} threads)'}
+            'sample': f'columns [{x0},{x0 + cols}) of the 512x512 film x {SPP} spp = {samples} samples '
+                      f'in {dt:.1f} s (C restatement of PTina\'s algorithm, OpenMP, {threads} threads); all cores: {all_samples} samples '
+                      f'in {all_dt:.1f} s with {allc} threads = every CPU this process can use (affinity mask capped by the cgroup quota; '
+                      f'the host has {os.cpu_count()} cores)'}
+
+
+# BASELINE.json's other configurations on ONE GPU (driver-timed, in the N = 1 line's `configs`).  A step is what
+# the headline's is -- PathEngine.render(spp) + FilmTable.get_image(), resolve and read-back included -- after one untimed
+# frame + clear (exams/benchmark.py:25-27); scene generation, upload and mpt_build_tree are outside it and reported beside it.
+OTHER_CONFIGS = [
+    # key, title, scene, scene kwargs, film side, spp, world light, timed steps
+    ('c1', 'BASELINE configs[0]: s34 34-tri cornell two-boxes, 512x512, 32 spp', 's34', {}, 512, 32, None, 5),
+    ('c3_film_1gpu', 'BASELINE configs[2] on ONE GPU: s978 2048x2048, 256 spp (eight pipelined launches of 32 frames)', 's978', {}, 2048, 256, None, 1),
+    ('c4', 'BASELINE configs[3]: 99 382-tri displaced blob in cornell + equirect env light, MIS, 1024x1024, 64 spp', 'c4', {}, 1024, 64,
+     ([1.0, 1.0, 1.0, 1.0], 0), 1),
+    ('c5', 'BASELINE configs[4]: 1M random triangles, on-GPU LBVH + SAH + 4-wide build, 1024x1024, 16 spp', 'c5', {'n': 1000000}, 1024, 16, None, 2),
+]
+
+
+def run_other_configs(mode, stub=False):
+    '''{key: {msamples_s, ms_per_step, kernel, avg_kernel_ms, ...}} for OTHER_CONFIGS; drops the headline's context first'''
+    out = {}
+    if stub:
+        for key, title, name, kw, n, spp, world, steps in OTHER_CONFIGS:
+            out[key] = {'workload': title, 'msamples_s': 1.0, 'ms_per_step': 1.0, 'kernel': 'stub', 'avg_kernel_ms': 1.0,
+                        'steps': steps, 'build_tree_ms': 1.0, 'msamples_s_incl_build': 1.0}
+        return out
+    from ptina_amd import scenes, common
+    from ptina_amd.common import ctx
+    from ptina_amd.things import FilmTable, BVHTree
+    from helpers import setup_engine
+    for key, title, name, kw, n, spp, world, steps in OTHER_CONFIGS:
+        try:
+            common.reset_all()
+            t0 = time.perf_counter()
+            scene = scenes.get_scene(name, **kw)
+            gen_s = time.perf_counter() - t0
+            eng = setup_engine(scene, n, n, mode=mode, world=world, max_filmsize=max(n * n, 1 << 21))
+            c = ctx()
+            film = FilmTable()
+            c.set_option('batch', SPP)
+            c.call('mpt_synchronize')
+            t0 = time.perf_counter()
+            BVHTree().build()                     # mpt_build_tree again, timed alone (the model is resident): LBVH (+ SAH + 4-wide collapse)
+            c.call('mpt_synchronize')
+            build_s = time.perf_counter() - t0
+            eng.render()                          # exams/benchmark.py:25-27
+            film.get_image()
+            film.clear()
+            eng.render(min(spp, SPP))             # untimed: the sample slabs and the host array are allocated here
+            film.get_image()
+            film.clear()
+            c.call('mpt_synchronize')
+            c.kernel_time()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.render(spp)
+                img = film.get_image()
+            dt = (time.perf_counter() - t0) / steps
+            kms, nl = c.kernel_time()
+            assert img.shape == (n, n, 4) and float(img[..., 3].min()) == 1.0
+            kernel = render_kernel_name(mode, c.get_option('last_kernel'))
+            out[key] = {'workload': title, 'ntri': int(scene[1].shape[0]), 'msamples_s': round(n * n * spp / dt / 1e6, 1),
+                        'ms_per_step': round(dt * 1e3, 3), 'kernel': kernel, 'avg_kernel_ms': round(kms / max(nl, 1), 4),
+                        'launches_per_step': nl // steps, 'steps': steps, 'build_tree_ms': round(build_s * 1e3, 2),
+                        'msamples_s_incl_build': round(n * n * spp / (dt + build_s) / 1e6, 1), 'scene_generation_s': round(gen_s, 2)}
+        except Exception as e:                    # a configuration that fails must not cost the run its headline
+            out[key] = {'workload': title, 'error': f'{type(e).__name__}: {e}'}
+    common.reset_all()
+    return out
 
 
 def parse_args(argv=None):
@@ -284,6 +365,7 @@ def parse_args(argv=None):
     ap.add_argument('--mode', default='fast')
     ap.add_argument('--chunk', type=int, default=-1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='N = 1: do not time the other BASELINE configurations (`configs`)')
     ap.add_argument('--no-pmc', action='store_true', help='do not run the rocprofv3 --pmc passes (counters from profiles/)')
     ap.add_argument('--force-comm', action='store_true', help='create the RCCL communicator even for one rank')
     ap.add_argument('--c3-steps', type=int, default=2, help='N > 1: timed steps of the 2048x2048 leg, each --c3-spp samples per pixel (0 = skip it)')
@@ -583,6 +665,8 @@ def _run_rank(args, rank, world, pmc, pmc_source, phases):
             out['model'] = f"a / N + b with a = {m['a_ms']} ms, b = {m['b_ms']} ms per launch ({MODEL['from']}), before the gather"
         if c3 is not None:
             out['c3'] = c3
+        if world == 1 and comm is None and not args.no_configs and args.scene == 's978':
+            out['configs'] = run_other_configs(args.mode, stub=args.stub)      # (drops this rank's context: nothing below needs it)
         if world == 1 and not args.no_cpu_baseline and not args.stub:
             from ptina_amd import scenes
             out['cpu_baseline'] = cpu_baseline(scene, scenes.BENCH_CAMERA)

@@ -303,6 +303,11 @@ def test_bench_n_gpu_line_carries_the_config3_leg(tmp_path):
                        env=env, capture_output=True, text=True, timeout=120)
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert r.returncode == 0 and line['n_gpus'] == 1 and 'c3' not in line and 'model_ms_per_step' not in line
+    # ... and the other BASELINE configurations timed in the same driver-run line
+    assert set(line['configs']) == {'c1', 'c3_film_1gpu', 'c4', 'c5'}
+    for key, v in line['configs'].items():
+        assert {'workload', 'msamples_s', 'ms_per_step', 'kernel', 'avg_kernel_ms'} <= set(v), key
+    assert 'build_tree_ms' in line['configs']['c5'] and '256 spp' in line['configs']['c3_film_1gpu']['workload']
 
 
 def test_bench_rank_that_never_returns_is_reported_with_every_ranks_phase():

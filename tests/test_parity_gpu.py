@@ -1464,6 +1464,63 @@ def test_mid_size_scene_with_environment_vs_oracle(fresh, oracle_mod):
     reset_all()
 
 
+@pytest.mark.parametrize('name', ['s34', 's978', 'c4-7k'])
+def test_counted_work_is_the_oracles_integer_for_integer(fresh, oracle_mod, name):
+    '''the WORK is integer data and must be the reference's, not only the film.  The strict build (the reference's
+    un-culled traversal, lbvh.py:324-345, and its bounce loop, path.py:25-62) against the oracle on the same frames: samples, rays,
+    shaded hits, Sobol draws and bounces EQUAL, counter for counter, and the box tests (= internal nodes popped) and triangle tests equal
+    up to the measured handful of grazing rays (below) -- the direct proof that the kernel does the reference's work and not less.
+    The production build walks another tree in another order (culled, sorted 4-wide steps), so its box and triangle counts are its
+    own; what must still agree with the strict build is the PATH structure: samples exactly, shaded hits / draws / bounces and --
+    with option skip_dark = 0 -- rays up to the measured handful of paths whose fast-math arithmetic flipped a decision.'''
+    from helpers import setup_oracle
+    from ptina_amd.common import ctx, reset_all
+    if name == 'c4-7k':
+        scene, world, nx, ny, spp = scenes.scene_c4(n_side=24), ([1.0, 1.0, 1.0, 1.0], 0), 64, 64, 4
+    else:
+        scene, world = scenes.get_scene(name), None
+        nx, ny, spp = (64, 64, 8) if name == 's34' else (96, 80, 8)
+    ref = setup_oracle(oracle_mod, scene, nx, ny, world=world)
+    ref.reset_counters()
+    ref.render(spp)
+    want = ref.counters()
+    got = {}
+    for mode in ('strict', 'fast'):
+        reset_all()
+        eng = _engine(None, scene, nx, ny, mode=mode, world=world)
+        c = ctx()
+        c.set_option('count', 1)
+        if mode == 'fast':
+            c.set_option('skip_dark', 0)
+        c.call('mpt_reset_counters')
+        eng.render(spp)
+        c.call('mpt_flush')
+        got[mode] = c.counters()
+    reset_all()
+    st, fa = got['strict'], got['fast']
+    from helpers import _report
+    _report('counted work %s: oracle %s | strict %s | fast %s' % (name, want, {k: st[k] for k in ('samples', 'rays', 'n_box', 'n_tri', 'n_shade', 'n_draws', 'bounces')},
+                                                                   {k: fa[k] for k in ('samples', 'rays', 'n_box', 'n_tri', 'n_shade', 'n_draws', 'bounces')}))
+    assert want['samples'] == nx * ny * spp
+    # the path structure: exact
+    for k in ('samples', 'rays', 'n_shade', 'n_draws', 'bounces'):
+        assert st[k] == want[k], (name, k, st[k], want[k])
+    # the traversal's tests.  Every ray is the oracle's up to the last bit of its direction (the device's sinf / cosf against glibc's in
+    # the bounce sampler), and a ray that grazes a box within that bit passes the slab test in one implementation only: a handful of
+    # subtrees more or less, never another hit (n_shade above is exact).  Measured, box / triangle tests: s34 +28 of 4 694 803 / +16 of
+    # 2 435 233 (6e-6, 7e-6); s978 0 of 18 611 489 / +2 of 3 924 633; c4-7k +2 of 6 133 762 / 0 of 998 438; the bound is 2e-5 of the count
+    assert st['n_node'] == st['n_box']                     # one box test per internal node popped (lbvh.py:338)
+    for mine, theirs in (('n_box', 'n_int'), ('n_tri', 'n_leaf')):
+        assert abs(st[mine] - want[theirs]) <= 2e-5 * want[theirs], (name, mine, st[mine], theirs, want[theirs])
+    # production build: the same paths (measured: rays, shaded hits, draws and bounces EQUAL to the strict build's on all three scenes;
+    # bound: 1e-4 of the strict count, for a path that flips a lobe under fast-math)
+    assert fa['samples'] == st['samples']
+    for k in ('n_shade', 'n_draws', 'bounces', 'rays'):
+        assert abs(fa[k] - st[k]) <= max(1e-4 * st[k], 8), (name, k, fa[k], st[k])
+    assert fa['n_draws'] == 2 * fa['samples'] + 6 * fa['n_shade']          # path.py:48,58,87: two jitter draws, six per shaded hit
+    assert fa['n_box'] < st['n_box'] and fa['n_tri'] <= st['n_tri']        # the culled, ordered traversal tests less, never more
+
+
 def test_large_scene_fast_vs_strict(fresh):
     '''config 4 at full triangle count (99 382) and a 200k random-triangle soup: device-built LBVH,
     SAH re-partition (c4) / raw LBVH (soup > sah_max is not reached here, so force it), fast vs strict'''
@@ -1560,13 +1617,26 @@ def test_disney_lobes_parity(fresh, oracle_mod, name):
     same way), sheen / subsurface, tinted specular, a perfect mirror (alpha clamped to 0.001) and a
     black body, on both boxes of the 34-triangle scene.
 
-    Transmission is ill-conditioned in the reference's own algorithm: its f32 and f64 evaluations
-    (the oracle's two builds) already disagree on 5-11 % of the pixels at 16 spp (a refracted path
-    flips between lobes on the last bit of a re-used sample), with equal means.  For those two
-    materials the bound is therefore calibrated against that spread instead of a fixed tolerance.'''
+    The two transmission materials first on the same scene with the boxes raised off the floor, at the ordinary bounds (round 5:
+    the lobes themselves are as well-conditioned as any other).  On the scene as it stands the boxes' bottom faces COINCIDE with
+    the floor quad, a ray inside a glass box meets both at the same depth, and which one the reference keeps hangs on the last
+    bit of its depth formula and on its test order (strict `<`, lbvh.py:331): its f32 and f64 evaluations (the oracle's two
+    builds) already disagree on 5-11 % of the pixels at 16 spp.  Rounds 1-4 read that as chaos of the lobe sampling; it is the
+    tie (test_transmission_converged_shows_no_bias).  There the bound is calibrated against that spread instead of a fixed
+    tolerance.'''
     from helpers import setup_oracle, assert_parity, image_stats, tile_means, _report
     from ptina_amd.things import FilmTable
     from ptina_amd.common import reset_all
+    if LOBE_MATERIALS[name].get('transmission', 0.0) > 0.0:
+        raised = _two_box_scene(LOBE_MATERIALS[name], 0.01)
+        ref = setup_oracle(oracle_mod, raised, 64, 64)
+        ref.render(16)
+        for mode in ('strict', 'fast'):
+            reset_all()
+            eng = _engine(None, raised, 64, 64, mode=mode)
+            eng.render(16)
+            assert_parity(FilmTable().get_image(), ref.get_image(), *bounds(mode), what=f'{name} (boxes raised off the floor) {mode}')
+        reset_all()
     v, m, mats, _ = scenes.scene_s34()
     mats = list(mats)
     mats[3] = scenes.material(**LOBE_MATERIALS[name])
@@ -1614,6 +1684,94 @@ def test_disney_lobes_parity(fresh, oracle_mod, name):
             assert out < 2 * spread_out + 0.02 and rel < 2 * spread_rmse + 1e-2, \
                 f'{name} fast: {out:.3%} outliers (spread {spread_out:.3%}), rel-RMSE {rel:.2e} (spread {spread_rmse:.2e})'
     reset_all()
+
+
+def _two_box_scene(material, lift):
+    '''the 34-triangle scene with both boxes of `material`, standing on the floor as in scene_s34 (lift = 0: their bottom faces
+    COINCIDE with the floor quad) or raised by `lift`'''
+    parts = [scenes.cornell_walls(), scenes.box((-0.7, 1.2 + lift, -0.6), (0.6, 1.2, 0.6), 18.0, 3),
+             scenes.box((0.75, 0.6 + lift, 0.55), (0.6, 0.6, 0.6), -17.0, 4)]
+    v, m = scenes._compose(parts)
+    return v, m, list(scenes.WALL_MATERIALS) + [scenes.material(**material), scenes.material(**material)], []
+
+
+@pytest.mark.parametrize('name,lift', [('glass', 0.01), ('rough_glass', 0.01), ('glass', 0.0), ('rough_glass', 0.0)])
+def test_transmission_converged_shows_no_bias(fresh, oracle_mod, name, lift):
+    '''VERDICT r04 next #6.  At 16 spp the transmission lobes (disney.py:67-72,160-200; microfacet.py:13-27) can only be bounded by
+    the spread of the reference's own algorithm (test_disney_lobes_parity).  Converged, a flipped path is one sample in thousands and a
+    BIAS -- a lobe weighted wrongly, a term dropped -- would stay while the noise falls.  32 x 32 pixels at 512, 2048 and 8192 spp,
+    the same Sobol points in every run, both builds against the f64 oracle with the f32 oracle beside them.'''
+    from helpers import setup_oracle, tile_means, _report
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import reset_all
+    nx = ny = 32
+    stops = (512, 2048, 8192)
+    scene = _two_box_scene(LOBE_MATERIALS[name], lift)
+    imgs = {}
+    for key, f64 in (('o64', True), ('o32', False)):
+        ref = setup_oracle(oracle_mod, scene, nx, ny, f64=f64)
+        done = 0
+        for n in stops:
+            ref.render(n - done)
+            done = n
+            imgs[(key, n)] = ref.get_image()
+    for mode in ('strict', 'fast'):
+        reset_all()
+        eng = _engine(None, scene, nx, ny, mode=mode)
+        done = 0
+        for n in stops:
+            eng.render(n - done)
+            done = n
+            imgs[(mode, n)] = FilmTable().get_image().copy()
+            assert np.isfinite(imgs[(mode, n)]).all() and np.all(FilmTable().get_raw()[:, 3] == n)
+    reset_all()
+    tm = {k: tile_means(im) for k, im in imgs.items()}
+
+    def rms(a, b, n):                  # tile means of a against b at n spp: rms over the tiles of the rgb distance, in units of the mean radiance
+        scale = float(imgs[(b, n)][..., :3].mean())
+        return float(np.sqrt(((tm[(a, n)] - tm[(b, n)]) ** 2).sum(axis=-1).mean())) / scale
+
+    def mean_err(a, b, n):
+        return abs(float(imgs[(a, n)][..., :3].mean()) / float(imgs[(b, n)][..., :3].mean()) - 1.0)
+
+    def worst(a, b, n):
+        scale = float(imgs[(b, n)][..., :3].mean())
+        return float(np.sqrt(((tm[(a, n)] - tm[(b, n)]) ** 2).sum(axis=-1)).max()) / scale
+
+    for mode in ('strict', 'fast'):
+        msg = f'{name} lift {lift} converged {mode}: ' + '; '.join(
+            f'{n} spp: mean vs f64 {mean_err(mode, "o64", n):.4%} (f32 oracle {mean_err("o32", "o64", n):.4%}), tile rms vs f64 {rms(mode, "o64", n):.4%} '
+            f'worst {worst(mode, "o64", n):.4%} (f32 oracle: sigma {rms("o32", "o64", n):.4%} worst {worst("o32", "o64", n):.4%}), vs f32 oracle {rms(mode, "o32", n):.4%}'
+            for n in stops)
+        print(msg)
+        _report(msg)
+    last = stops[-1]
+    sigma = rms('o32', 'o64', last)
+    if lift > 0.0:
+        # No coincident surfaces: nothing but the BSDF, the sampler and the traversal.  Measured (MI355X): strict build = the f32 oracle to
+        # 1e-6 of the mean radiance; production build mean radiance within 0.0044 % at every sample count (bound 0.1 %), tile rms 0.031 %
+        # at 512 spp falling to 0.0085 % at 8192 (noise: 1 / sqrt(16) = 0.25 x; a bias would stay) = 0.96 sigma (glass) / 1.0 sigma (rough glass)
+        for mode in ('strict', 'fast'):
+            for n in stops:
+                assert mean_err(mode, 'o64', n) < 1e-3, (name, mode, n, mean_err(mode, 'o64', n))
+                assert rms(mode, 'o64', n) < 4.1e-4, (name, mode, n, rms(mode, 'o64', n))              # 1.3 x the largest measured (0.0313 %)
+            assert rms(mode, 'o64', last) <= 1.3 * sigma, (name, mode, rms(mode, 'o64', last), sigma)
+            # worst tile: the f32 oracle's own is 2.84 sigma (sigma is an rms over 16 tiles), the production build's 3.48 sigma on glass
+            assert worst(mode, 'o64', last) <= 4.5 * sigma, (name, mode, worst(mode, 'o64', last), sigma)
+    else:
+        # The boxes stand ON the floor: their bottom faces coincide with the floor quad, and a ray inside a glass box meets both at the
+        # same depth.  The reference keeps whichever its own depth formula rounds smaller and, on equal bits, the one it tests first
+        # (strict `<`, lbvh.py:331; SURVEY hard parts: "traversal-order ties"); its f32 and f64 evaluations already disagree there -- THAT is
+        # the "chaos" of the transmission materials (with the boxes raised it is gone: above) -- and converge to each other slowly.
+        # The strict build keeps the reference's formula and test order and converges WITH the f32 oracle; the production build's
+        # 48-byte triangle records give other last bits to the two depths and its ordered traversal another first candidate: a
+        # documented deviation on coincident transmissive geometry, bounded here at 1.3 x the measurement (glass: mean radiance 0.28 %,
+        # tile rms 1.75 %; rough glass 0.094 %, 0.40 %), not a bias of the BSDF (above)
+        assert mean_err('strict', 'o64', last) < 1e-3
+        assert rms('strict', 'o64', last) <= 1.3 * sigma, (name, rms('strict', 'o64', last), sigma)
+        mb, rb = (3.7e-3, 2.3e-2) if name == 'glass' else (1.3e-3, 5.2e-3)
+        for n in stops:
+            assert mean_err('fast', 'o64', n) < mb and rms('fast', 'o64', n) < rb, (name, n, mean_err('fast', 'o64', n), rms('fast', 'o64', n))
 
 
 def test_many_lights(fresh, oracle_mod):

@@ -204,7 +204,7 @@ def test_disney_brdf_and_bounce(gold, dev):
         assert (~fin & ~ior0).sum() == 0
         close(got_brdf[fin & ~chaotic], want_brdf[fin & ~chaotic], 3e-5, 'Disney.brdf', 2e-6)
         # transmission materials at roughness 0.08: GTR2's t = 1 + (a2 - 1) cos^2 cancels to ~a2 = 4e-5 in f32
-        close(got_brdf[fin & chaotic], want_brdf[fin & chaotic], 5e-3, 'Disney.brdf (transmission materials)', 2e-5)
+        close(got_brdf[fin & chaotic], want_brdf[fin & chaotic], 3e-5, 'Disney.brdf (transmission materials)', 2e-6)     # (round 4: 5e-3 / 2e-5, measured 0.004 of it)
     # ---- bounce: the lobe is a discrete decision on the re-used sample (Choice): dead / alive pattern first
     dead_g, dead_w = (got_b[:, :3] == 0).all(axis=1), (want_b[:, :3] == 0).all(axis=1)
     nan_w = np.isnan(want_b).any(axis=1)
@@ -231,13 +231,14 @@ def test_disney_brdf_and_bounce(gold, dev):
     sl = 0.0 if mode == 'strict' else np.nan_to_num(spread(gold, 'disney/bounce'))
     err = np.maximum(np.abs(got_b - want_b) - sl, 0.0) / (np.abs(want_b) + 1e-3)
     per_row = np.where(np.isnan(err), 0.0, err).max(axis=1)
-    bound = pick(mode, 2e-4, 1e-3)
+    bound = pick(mode, 1.3e-6, 1.1e-5)              # 1.3 x measured (9.81e-07 strict, 8.49e-06 production); round 4: 2e-4 / 1e-3
+    ill = pick(mode, 1.3e-6, 1.06e-2)               # 1.3 x measured (9.99e-07, 8.09e-03); round 4: 5e-2 for both builds
     report(f'Disney.bounce [{mode}]: worst relative error, plain materials {per_row[plain].max():.2e} (bound {bound:g}), '
-           f'ill-conditioned materials {per_row[live & chaotic].max():.2e} (bound 5e-2)')
+           f'ill-conditioned materials {per_row[live & chaotic].max():.2e} (bound {ill:g})')
     worst_row = int(np.argmax(np.where(plain, per_row, 0.0)))
     assert (per_row[plain] <= bound).all(), f'Disney.bounce: worst relative error {per_row[plain].max():.2e} (bound {bound:g}) in row {worst_row}, material {names[mat[worst_row]]}'
     # transmission materials at roughness 0.08: three digits are gone in f32; same branch, looser values
-    assert (per_row[live & chaotic] <= 5e-2).all(), f'Disney.bounce (transmission): worst {per_row[live & chaotic].max():.2e}'
+    assert (per_row[live & chaotic] <= ill).all(), f'Disney.bounce (transmission): worst {per_row[live & chaotic].max():.2e} (bound {ill:g})'
     # every transmission / refraction vector took the reference's branch: direction within 2e-2 of the reference's
     tr = live & np.isin(leaf, ['trans_reflect', 'trans_refract'])
     assert tr.sum() >= 6 and (np.abs(got_b[tr, :3] - want_b[tr, :3]).max(axis=1) <= 2e-2).all()

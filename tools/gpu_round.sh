@@ -52,12 +52,12 @@ for step in "$@"; do
                  done ;;
     gbench)      run gbench 400 tools/microbench/gather_microbench ;;
     ubench_pmc)  run ubench_pmc 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/ubench_pmc -- tools/microbench/valu_microbench ;;
-    bench_quick) run bench_quick 300 python bench.py --no-pmc --no-cpu-baseline ;;
-    bench_nofin) MIPTINA_OPTS=finalise=0 run bench_nofin 300 python bench.py --no-pmc --no-cpu-baseline ;;
+    bench_quick) run bench_quick 300 python bench.py --no-pmc --no-cpu-baseline --no-configs ;;
+    bench_nofin) MIPTINA_OPTS=finalise=0 run bench_nofin 300 python bench.py --no-pmc --no-cpu-baseline --no-configs ;;
     tests_fin)   run tests_fin 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'finalisation or hint or film_api or batching or full_size or smoke or pipelin' ;;
     ablibs)      n=0; for L in $ABLIBS; do n=$((n+1)); O=$MIPTINA_OPTS; case $L in base*|nofin*|*nofin) O=finalise=0 ;; *noimg) O=finalise=2 ;; esac;   # (builds without the in-kernel finalisation need the combine pass)
                    F=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_$L.so; [ "$L" = main ] && F=$GRAFT_REPO_ROOT/ptina_amd/libmiptina.so;
-                   MIPTINA_OPTS=$O MIPTINA_LIB=$F run ab${n}_$L 300 python bench.py --no-pmc --no-cpu-baseline; done ;;
+                   MIPTINA_OPTS=$O MIPTINA_LIB=$F run ab${n}_$L 300 python bench.py --no-pmc --no-cpu-baseline --no-configs; done ;;
     tests_fast)  run tests_fast 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'fast_build or strict_build or full_size or batching or pipelining or lds_and_gather or lobes or ordered or idle or work_item or quantised' ;;
     tests_big)   run tests_big 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'config5 or config4 or mid_size or large_scene or lds_and_gather or where_the_tree' ;;
     big_wide)    MIPTINA_WIDE=1 run big_wide 400 python tools/run_configs.py C4 C5 ;;
@@ -69,9 +69,9 @@ for step in "$@"; do
     bench)       run bench 600 python bench.py ;;
     prof)        (cd /tmp; run_dir=$GRAFT_REPO_ROOT/gpurun_out/prof; rm -rf $run_dir; mkdir -p $run_dir;
                   cd $GRAFT_REPO_ROOT;
-                  run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pmc) ;;
+                  run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pmc --no-configs) ;;
     hiptrace)    (run_dir=$GRAFT_REPO_ROOT/gpurun_out/hiptrace; rm -rf $run_dir; mkdir -p $run_dir;
-                  run hiptrace 400 rocprofv3 --hip-trace --kernel-trace --output-format csv -d gpurun_out/hiptrace -- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-pmc) ;;
+                  run hiptrace 400 rocprofv3 --hip-trace --kernel-trace --output-format csv -d gpurun_out/hiptrace -- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-pmc --no-configs) ;;
     slabtrace)   (run_dir=$GRAFT_REPO_ROOT/gpurun_out/slabtrace; rm -rf $run_dir; mkdir -p $run_dir;
                   STRIPE=16 run slabtrace 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/slabtrace -- python3 tools/slab_trace.py 8 3 40) ;;
     counters)    rocprofv3 -L > gpurun_out/counters_list.txt 2>&1; echo "counters listed" ;;
