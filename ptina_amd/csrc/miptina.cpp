@@ -299,6 +299,9 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->skip_dark = value;
     } else if (k == "wide8") {
         if (value != 0 && value != 1) return fail("wide8 must be 0 or 1");
+#if !MPT_WITH_OCT
+        if (value) return fail("this library is built without the 8-wide octant-ordered kernel (an A/B build: make -C ptina_amd/csrc oct)");
+#endif
         if (value != c->use_wide8) { c->use_wide8 = value; c->tree_valid = false; }    // (built by the next mpt_build_tree)
     } else if (k == "spin_us") {
         if (value < 0) return fail("spin_us must be >= 0");
@@ -891,8 +894,11 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     int wide_blocks = 0;
     if (oct_kernel) { p.onode = c->onode; p.tfast = c->tfast8; p.tshade = c->tshade8; }
     if (wide_kernel) {
+#if MPT_WITH_OCT
         if (oct_kernel) HIP_TRY(mpt_oct_blocks(launch_cus, c->count, &wide_blocks));
-        else HIP_TRY(mpt_wide_blocks(launch_cus, c->count, c->use_quant, &wide_blocks));
+        else
+#endif
+        HIP_TRY(mpt_wide_blocks(launch_cus, c->count, c->use_quant, &wide_blocks));
         const size_t need_spill = (size_t)wide_blocks * MPT_BLOCK * 128;   // >= SpillStack::SPILL entries per lane (128 - LDS levels)
         // every slot of the ring at once (an allocation synchronises the device), and one strip PER SLOT: the launches of
         // different slots overlap, and a strip is indexed by block and lane only
@@ -993,7 +999,9 @@ extern "C" int mpt_flush(mpt_ctx *c) {
 #endif
     else if (lds4_kernel) HIP_TRY(mpt_launch_render_lds4(&p, launch_cus, lds_block_used, lds4_bytes, c->count, rs));
     else if (lds_kernel) HIP_TRY(mpt_launch_render_lds(&p, launch_cus, lds_block_used, lds_bytes, c->count, rs));
+#if MPT_WITH_OCT
     else if (oct_kernel) HIP_TRY(mpt_launch_render_oct(&p, wide_blocks, c->count, rs));
+#endif
     else if (wide_kernel) HIP_TRY(mpt_launch_render_wide(&p, wide_blocks, c->count, c->use_quant, rs));
     else HIP_TRY(mpt_launch_render_fast(&p, launch_cus, stack, c->count, rs));
     c->last_kernel = pool_kernel ? 3 : lds4_kernel ? 5 : lds_kernel ? 1 : oct_kernel ? 4 : wide_kernel ? 2 : 0;

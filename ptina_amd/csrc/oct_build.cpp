@@ -20,6 +20,15 @@
 #include "miptina_ctx.h"
 #include <cstring>
 
+#if !MPT_WITH_OCT
+// The 8-wide octant-ordered tree is an A/B build (make -C ptina_amd/csrc oct -> libmiptina_oct.so; DESIGN.md 3.2: -17 ... -19 % against
+// the 4-wide node): the product library keeps the entry point of the C ABI and says so.  (Option "wide8" cannot be set in this build.)
+MPT_INTERNAL int make_oct8(mpt_ctx *) { return fail("this library is built without the 8-wide octant-ordered tree (make -C ptina_amd/csrc oct)"); }
+extern "C" int mpt_get_oct8(mpt_ctx *, float *, int32_t *, int, int *) {
+    return fail("this library is built without the 8-wide octant-ordered tree (an A/B build: make -C ptina_amd/csrc oct)");
+}
+#else
+
 namespace {
 struct OChild { int32_t id; float lo[3], hi[3]; };
 inline int32_t asi(float f) { int32_t v; memcpy(&v, &f, 4); return v; }
@@ -177,3 +186,5 @@ extern "C" int mpt_get_oct8(mpt_ctx *c, float *onode, int32_t *perm, int cap_nod
     if (nw) *nw = c->oct_nodes;
     return 0;
 }
+
+#endif   // MPT_WITH_OCT

@@ -17,8 +17,9 @@
 //     from HBM / L2 / Infinity Cache, per-lane int32 traversal stack in LDS, [level][lane].
 //   After the loop a wave that has run out of work finalises finished tiles of the film -- sum of the frames, resolve, the image's
 //     write-out -- while the others drain (finalise_tiles): a launch that has the GPU to itself needs no combine pass.
-//   render_kernel_wide: 4-wide nodes with 8-bit child boxes (the product path for scenes that do not fit LDS); render_kernel_oct:
-//     8-wide octant-ordered nodes (option wide8; an A/B that lost 17-19 %, kept with its tests).
+//   render_kernel_wide: 4-wide nodes with 8-bit child boxes (the product path for scenes that do not fit LDS); render_kernel_oct
+//     (render_oct.h, -DMPT_WITH_OCT=1: `make oct`): 8-wide octant-ordered nodes, an A/B that lost 17-19 %, kept with its tests
+//     outside the product library.
 //   render_kernel_lds (scenes whose node + triangle records fit the CU's 160 KiB LDS): measured on
 //     MI355X the gather version spends its time in the vector L1 -- a wave's node fetch touches up to 64
 //     different cache lines per load instruction, four instructions per node -- so one persistent
@@ -562,127 +563,9 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     L.st = classify<STACK>(next);
 }
 
-// ---- the 8-wide, octant-ordered tree (OctScene / OctStack; oct_build.cpp)
-// The ray's direction octant: bit a set = the ray goes DOWN axis a.  A child slot's bit a set = the child lies on the high side of
-// the node's centre along a, so slot ^ octant, ascending, is the order the ray meets the children in (nearest first).
-DEV unsigned ray_octant(const LaneState &L) {
-    return ((unsigned)__float_as_int(L.inv.x) >> 31) | (((unsigned)__float_as_int(L.inv.y) >> 31) << 1) | (((unsigned)__float_as_int(L.inv.z) >> 31) << 2);
-}
-// bit i of an 8-bit mask to bit i ^ r: three conditional delta swaps
-DEV unsigned oct_permute(unsigned m, unsigned r) {
-    const unsigned m1 = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
-    m = (r & 1u) ? m1 : m;
-    const unsigned m2 = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
-    m = (r & 2u) ? m2 : m;
-    const unsigned m4 = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
-    return (r & 4u) ? m4 : m;
-}
-// the next thing to do is on top of the stack: a leaf group (b < 0: the lowest slot left names the next triangle), a group of
-// internal children (the lowest MET-ORDER position left names the next node) or the sentinel
-template <class STACK>
-DEV void oct_next(STACK &stk, LaneState &L, unsigned r) {
-    int a, b;
-    const int top = L.sp - 1;
-    stk.get(top, a, b);
-    if (b & STACK::SENTINEL) { L.st = ST_DONE; return; }
-    const bool leaf = b < 0;
-    const unsigned bits = (unsigned)b & 0xffu;
-    const int pos = __builtin_ctz(bits | 0x100u);
-    const unsigned slot = leaf ? (unsigned)pos : ((unsigned)pos ^ r);
-    const int idx = (a & 0xffffff) + __builtin_popcount(((unsigned)a >> 24) & ((1u << slot) - 1u));
-    const unsigned rest = bits & (bits - 1u);
-    if (rest) stk.setb(top, (int)(((unsigned)b & 0x80000000u) | rest));
-    else L.sp = top;
-    L.curr = leaf ? ~idx : idx;
-    L.st = leaf ? ST_LEAF : ST_NODE;
-}
-
-template <bool COUNT, class SCENE, class STACK>
-DEV void stage_node8(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
-    if (COUNT) { cnt.n_node++; cnt.n_box += 8; }
-    MptVec4 h0, h1, px, py, pz;
-    sc.node8(L.curr, h0, h1, px, py, pz);
-    // plane = origin + byte * scale: its distance along the ray is byte * (scale * inv) + (origin * inv - o * inv)
-    const float sx = h0.w * L.inv.x, sy = h1.x * L.inv.y, sz = h1.y * L.inv.z;
-    const float bx = __builtin_fmaf(h0.x, L.inv.x, -L.oinv.x), by = __builtin_fmaf(h0.y, L.inv.y, -L.oinv.y),
-                bz = __builtin_fmaf(h0.z, L.inv.z, -L.oinv.z);
-    const int a_node = __float_as_int(h1.z), a_tri = __float_as_int(h1.w);
-    const unsigned imask = (unsigned)a_node >> 24, lmask = (unsigned)a_tri >> 24;
-    const unsigned r = ray_octant(L);
-    const bool dnx = (r & 1u) != 0, dny = (r & 2u) != 0, dnz = (r & 4u) != 0;
-    // entry planes: the low ones for a ray going up the axis, the high ones for one going down ({lo[0..3], lo[4..7], hi[0..3], hi[4..7]})
-    const unsigned lx0 = (unsigned)__float_as_int(px.x), lx1 = (unsigned)__float_as_int(px.y), hx0 = (unsigned)__float_as_int(px.z), hx1 = (unsigned)__float_as_int(px.w);
-    const unsigned ly0 = (unsigned)__float_as_int(py.x), ly1 = (unsigned)__float_as_int(py.y), hy0 = (unsigned)__float_as_int(py.z), hy1 = (unsigned)__float_as_int(py.w);
-    const unsigned lz0 = (unsigned)__float_as_int(pz.x), lz1 = (unsigned)__float_as_int(pz.y), hz0 = (unsigned)__float_as_int(pz.z), hz1 = (unsigned)__float_as_int(pz.w);
-    const unsigned nx0 = dnx ? hx0 : lx0, nx1 = dnx ? hx1 : lx1, fx0 = dnx ? lx0 : hx0, fx1 = dnx ? lx1 : hx1;
-    const unsigned ny0 = dny ? hy0 : ly0, ny1 = dny ? hy1 : ly1, fy0 = dny ? ly0 : hy0, fy1 = dny ? ly1 : hy1;
-    const unsigned nz0 = dnz ? hz0 : lz0, nz1 = dnz ? hz1 : lz1, fz0 = dnz ? lz0 : hz0, fz1 = dnz ? lz1 : hz1;
-    unsigned hits = 0u;
-#define MPT_UB(w, c) ((float)(((w) >> (8 * (c))) & 0xffu))
-#define MPT_OSLAB(c, nxw, nyw, nzw, fxw, fyw, fzw, bit)                                                                \
-    {                                                                                                                  \
-        const float tn = fmaxf(fmaxf(__builtin_fmaf(MPT_UB(nxw, c), sx, bx), __builtin_fmaf(MPT_UB(nyw, c), sy, by)),  \
-                               fmaxf(__builtin_fmaf(MPT_UB(nzw, c), sz, bz), 0.0f));                                   \
-        const float tf = fminf(fminf(__builtin_fmaf(MPT_UB(fxw, c), sx, bx), __builtin_fmaf(MPT_UB(fyw, c), sy, by)),  \
-                               fminf(__builtin_fmaf(MPT_UB(fzw, c), sz, bz), L.tbest));                                \
-        hits |= tn <= tf ? (1u << (bit)) : 0u;                                                                         \
-    }
-    MPT_OSLAB(0, nx0, ny0, nz0, fx0, fy0, fz0, 0) MPT_OSLAB(1, nx0, ny0, nz0, fx0, fy0, fz0, 1)
-    MPT_OSLAB(2, nx0, ny0, nz0, fx0, fy0, fz0, 2) MPT_OSLAB(3, nx0, ny0, nz0, fx0, fy0, fz0, 3)
-    MPT_OSLAB(0, nx1, ny1, nz1, fx1, fy1, fz1, 4) MPT_OSLAB(1, nx1, ny1, nz1, fx1, fy1, fz1, 5)
-    MPT_OSLAB(2, nx1, ny1, nz1, fx1, fy1, fz1, 6) MPT_OSLAB(3, nx1, ny1, nz1, fx1, fy1, fz1, 7)
-#undef MPT_OSLAB
-#undef MPT_UB
-    // (an empty slot's box is inverted -- lo 255, hi 0 -- and never hit)
-    const unsigned lh = hits & lmask;                          // leaf hits, by slot: their order does not matter much, all are tested
-    const unsigned pih = oct_permute(hits & imask, r);         // internal hits, by the position the ray meets them in
-    // leaves first (they can only shorten the ray), then the nearest internal child; what is left of either kind goes to the stack
-    const bool take_leaf = lh != 0u;
-    const unsigned sel = take_leaf ? lh : pih;
-    const int pos = __builtin_ctz(sel | 0x100u);
-    const unsigned rest = sel & (sel - 1u);
-    const unsigned slot = take_leaf ? (unsigned)pos : ((unsigned)pos ^ r);
-    const int a_sel = take_leaf ? a_tri : a_node;
-    const int idx = (a_sel & 0xffffff) + __builtin_popcount(((unsigned)a_sel >> 24) & ((1u << slot) - 1u));
-    int sp = L.sp;
-    if (__ballot(sp > STACK::CAP - 2) == 0ull) {
-        // nobody near the end of the LDS part: plain stores at a running index (a store that is not wanted lands on the level the
-        // next one overwrites, or on the free level above the top)
-        stk.base[sp * MPT_BLOCK] = a_node; stk.base[(STACK::CAP + sp) * MPT_BLOCK] = (int)pih;
-        sp += (take_leaf && pih != 0u) ? 1 : 0;
-        stk.base[sp * MPT_BLOCK] = a_sel; stk.base[(STACK::CAP + sp) * MPT_BLOCK] = (int)(rest | (take_leaf ? 0x80000000u : 0u));
-        sp += rest != 0u ? 1 : 0;
-    } else {
-        if (take_leaf && pih != 0u) { stk.put(sp, a_node, (int)pih); sp++; }
-        if (rest != 0u) { stk.put(sp, a_sel, (int)(rest | (take_leaf ? 0x80000000u : 0u))); sp++; }
-    }
-    L.sp = sp;
-    if (sel != 0u) {
-        L.curr = take_leaf ? ~idx : idx;
-        L.st = take_leaf ? ST_LEAF : ST_NODE;
-    } else oct_next(stk, L, r);
-}
-
-template <bool COUNT, class SCENE, class STACK>
-DEV void stage_leaf8(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
-    const int slot = ~L.curr;                                  // (a t8 index: the triangle's place in the 8-wide tree's leaf order)
-    bool stop = false;
-    if (COUNT) cnt.n_tri++;
-    if (L.curr != L.navoid) {                                  // the triangle the ray left from is never tested (lbvh.py:329)
-        MptVec4 g0, g1, g2;
-        sc.tri(slot, g0, g1, g2);
-        float dd, su, sv;
-        if (tri_test_fast(g0, g1, g2, L.to, L.td, &dd, &su, &sv)) {
-            if (L.shadow) {
-                if (dd <= L.tbest) { L.hidx = slot; stop = true; }              // path.py:51: any occluder within li.dis
-            } else if (dd < L.tbest) {                                          // lbvh.py:331
-                L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv;
-            }
-        }
-    }
-    if (stop) L.st = ST_DONE;
-    else oct_next(stk, L, ray_octant(L));
-}
+#if MPT_WITH_OCT
+#include "render_oct.h"      // stage_node8 / stage_leaf8 / oct_next: the 8-wide octant-ordered tree's steps (A/B build)
+#endif
 
 template <bool COUNT, class SCENE, class STACK>
 DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
@@ -870,17 +753,24 @@ DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(by
 #define MPT_STAMP_BEGIN
 #define MPT_STAMP_END(acc)
 #endif
-// A/B (MPT_X_TAIL_PRIO / MPT_X_WAVE_PRIO): user priority by the wave's age within its SIMD (the instruction takes a literal)
-DEV void set_prio_by_age() {
-    const int age = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) & 3;
-    if (age == 1) __builtin_amdgcn_s_setprio(1);
-    else if (age == 2) __builtin_amdgcn_s_setprio(2);
-    else if (age == 3) __builtin_amdgcn_s_setprio(3);
-}
 DEV int wave_count(bool pred) { return (int)__builtin_popcountll(__ballot(pred)); }
 DEV int wave_count32(bool pred) {            // the same in two 32-bit halves: stays on the scalar unit when compared
     unsigned long long m = __ballot(pred);
     return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
+}
+
+// (SCENE::OCT is only ever true in the A/B build with the 8-wide kernel: render_oct.h)
+template <bool COUNT, class SCENE, class STACK>
+DEV void stage_node8_if_built(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
+#if MPT_WITH_OCT
+    stage_node8<COUNT>(sc, stk, L, cnt);
+#endif
+}
+template <bool COUNT, class SCENE, class STACK>
+DEV void stage_leaf8_if_built(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
+#if MPT_WITH_OCT
+    stage_leaf8<COUNT>(sc, stk, L, cnt);
+#endif
 }
 
 // Work items = (8x8 pixel tile, chunk of frames), tile-major, split into 8 contiguous ranges with
@@ -933,12 +823,6 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
     unsigned long long acc_node = 0, acc_leaf = 0, acc_sdone = 0, acc_shade = 0, acc_new = 0;
     const unsigned long long stamp_start = __builtin_amdgcn_s_memtime();
 #endif
-#if MPT_X_WAVE_PRIO
-    set_prio_by_age();     // A/B: the same for the whole launch
-#endif
-#if MPT_X_FIN_PRIO
-    __builtin_amdgcn_s_setprio(MPT_X_FIN_PRIO);
-#endif
     LaneState L;
     L.st = ST_NEW;
     L.sp = 0; L.curr = 0; L.shadow = 0;
@@ -972,7 +856,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             if (cn * MPT_PREF_NODE >= cl * MPT_PREF_LEAF) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
                 if (L.st == ST_NODE) {
-                    if constexpr (SCENE::OCT) stage_node8<COUNT>(sc, stk, L, cnt);
+                    if constexpr (SCENE::OCT) stage_node8_if_built<COUNT>(sc, stk, L, cnt);
                     else if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
                     else stage_node<COUNT>(sc, stk, L, cnt);
                 }
@@ -983,7 +867,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                     if (__ballot(L.st == ST_NODE) == 0ull) break;
                     if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
                     if (L.st == ST_NODE) {
-                        if constexpr (SCENE::OCT) stage_node8<COUNT>(sc, stk, L, cnt);
+                        if constexpr (SCENE::OCT) stage_node8_if_built<COUNT>(sc, stk, L, cnt);
                         else if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
                         else stage_node<COUNT>(sc, stk, L, cnt);
                     }
@@ -992,7 +876,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             } else {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
                 if (L.st == ST_LEAF) {
-                    if constexpr (SCENE::OCT) stage_leaf8<COUNT>(sc, stk, L, cnt);
+                    if constexpr (SCENE::OCT) stage_leaf8_if_built<COUNT>(sc, stk, L, cnt);
                     else stage_leaf<COUNT>(sc, stk, L, cnt);
                 }
 #pragma unroll
@@ -1000,7 +884,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                     if (__ballot(L.st == ST_LEAF) == 0ull) break;
                     if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
                     if (L.st == ST_LEAF) {
-                        if constexpr (SCENE::OCT) stage_leaf8<COUNT>(sc, stk, L, cnt);
+                        if constexpr (SCENE::OCT) stage_leaf8_if_built<COUNT>(sc, stk, L, cnt);
                         else stage_leaf<COUNT>(sc, stk, L, cnt);
                     }
                 }
@@ -1071,12 +955,6 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
 #endif
                 if (item < 0) {
                     more = false;
-#if MPT_X_TAIL_PRIO
-                    // A/B: the hardware issues the oldest wave of a SIMD first (waves 0-3 of a 1024-lane workgroup trace 39 items
-                    // per launch, waves 12-15 23: profiles/r04_timeline2.json); once the queues are dry the younger waves, which are
-                    // the last to finish, get the higher user priority
-                    set_prio_by_age();
-#endif
                     if (tl && (threadIdx.x & 63) == 0) {
                         tl[2] = wall_clock64();
 #if MPT_X_TIMELINE2
@@ -1300,9 +1178,6 @@ __device__ __attribute__((noinline)) int finalise_tiles_impl(
 template <int GROUP>
 DEV int finalise_tiles(const MptRenderParams &p) {
 #if MPT_FIN_INLINE >= 0          // (-1: A/B build without the call: the render kernels as they were before the tail finalisation)
-#if MPT_X_FIN_PRIO
-    __builtin_amdgcn_s_setprio(0);       // A/B: the waves still tracing (priority MPT_X_FIN_PRIO, set in trace_stream) issue first
-#endif
     // In a workgroup of three or four waves per SIMD only the younger two finalise.  The hardware issues the oldest wave of a
     // SIMD first, so the old waves finish tracing first -- and, finalising, stayed in front of the waves still tracing behind
     // them: with all four at it the launch took 3.15 ms, with the younger two 3.12 (the combine pass after the launch: 3.10 + 0.1;
@@ -1381,23 +1256,6 @@ __global__ __launch_bounds__(MPT_BLOCK, MPT_WIDE_WAVES) void render_kernel_wide(
         WideScene sc; sc.wnode = p.wnode; sc.tgeo = p.tfast;
         trace_stream<COUNT>(p, sc, stk, wq, cnt);
     }
-    finalise_tiles<MPT_FIN_GROUP_GATHER>(p);
-    flush_counters<COUNT>(p, cnt);
-}
-
-// ---------------------------------------------------------------- gather kernel over 8-wide octant-ordered nodes (option "wide8")
-template <bool COUNT>
-__global__ __launch_bounds__(MPT_BLOCK, MPT_WIDE_WAVES) void render_kernel_oct(const MptRenderParams p) {
-    __shared__ int s_stack[2 * OctStack::CAP * MPT_BLOCK];
-    OctStack stk;
-    stk.base = s_stack + threadIdx.x;
-    stk.spill = p.stack_spill;
-    stk.lane_off = (blockIdx.x * MPT_BLOCK + threadIdx.x) * (unsigned)(2 * OctStack::SPILL);
-    stk.sp = 0;
-    Cnt cnt = {};
-    WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
-    OctScene sc; sc.onode = p.onode; sc.tgeo = p.tfast;
-    trace_stream<COUNT>(p, sc, stk, wq, cnt);
     finalise_tiles<MPT_FIN_GROUP_GATHER>(p);
     flush_counters<COUNT>(p, cnt);
 }
@@ -1636,6 +1494,11 @@ MPT_KERNEL_API hipError_t mpt_launch_render_lds(const MptRenderParams *p, int gr
 }
 #endif
 
+#if !MPT_STRICT && MPT_WITH_OCT
+#define MPT_OCT_KERNELS 1
+#include "render_oct.h"      // render_kernel_oct + its launchers (second pass over the header)
+#endif
+
 #if !MPT_STRICT && MPT_WITH_POOL
 // The pooled LDS kernel (waves specialised into tracers and shaders, paths traded through LDS pools) measured 15-50 % slower
 // than render_kernel_lds: it is an A/B build (make pool -> libmiptina_pool.so), not part of the product library
@@ -1682,25 +1545,6 @@ MPT_KERNEL_API hipError_t mpt_wide_blocks(int grid, int count, int quant, int *b
     }
     *blocks = grid * occ;
     return hipSuccess;
-}
-
-MPT_KERNEL_API hipError_t mpt_oct_blocks(int grid, int count, int *blocks) {
-    static std::atomic<int> occ_cache[MPT_MAX_DEVICES][2];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MPT_MAX_DEVICES) return hipErrorInvalidDevice;
-    int occ = occ_cache[dev][count ? 1 : 0].load(std::memory_order_relaxed);
-    if (!occ) {
-        occ = count ? blocks_per_cu(render_kernel_oct<true>) : blocks_per_cu(render_kernel_oct<false>);
-        occ_cache[dev][count ? 1 : 0].store(occ, std::memory_order_relaxed);
-    }
-    *blocks = grid * occ;
-    return hipSuccess;
-}
-
-MPT_KERNEL_API hipError_t mpt_launch_render_oct(const MptRenderParams *p, int blocks, int count, hipStream_t stream) {
-    if (count) hipLaunchKernelGGL((render_kernel_oct<true>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
-    else hipLaunchKernelGGL((render_kernel_oct<false>), dim3(blocks), dim3(MPT_BLOCK), 0, stream, *p);
-    return hipGetLastError();
 }
 
 MPT_KERNEL_API hipError_t mpt_launch_render_wide(const MptRenderParams *p, int blocks, int count, int quant, hipStream_t stream) {

@@ -61,7 +61,7 @@ for step in "$@"; do
     tests_fast)  run tests_fast 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'fast_build or strict_build or full_size or batching or pipelining or lds_and_gather or lobes or ordered or idle or work_item or quantised' ;;
     tests_big)   run tests_big 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'config5 or config4 or mid_size or large_scene or lds_and_gather or where_the_tree' ;;
     big_wide)    MIPTINA_WIDE=1 run big_wide 400 python tools/run_configs.py C4 C5 ;;
-    big_oct)     MIPTINA_OPTS=wide8=1 CONFIGS_OUT=configs_oct.json run big_oct 500 python tools/run_configs.py C4 C5 ;;
+    big_oct)     MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_oct.so MIPTINA_OPTS=wide8=1 CONFIGS_OUT=configs_oct.json run big_oct 500 python tools/run_configs.py C4 C5 ;;
     tests_oct)   run tests_oct 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k 'octant or random_scenes' ;;
     big_ablibs)  for L in $ABLIBS; do MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_$L.so run big_$L 400 python tools/run_configs.py C4 C5; done ;;
     tests)       run tests 900 python -m pytest tests -m gpu -x -q ;;
@@ -83,9 +83,9 @@ for step in "$@"; do
     pmcbig2)     run pmcbig2 500 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmcbig2 -- python3 tools/run_configs.py C4 C5 ;;
     pmcbig3)     run pmcbig3 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcbig3 -- python3 tools/run_configs.py C4 C5 ;;
     pmcbig4)     run pmcbig4 500 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM --output-format csv -d gpurun_out/pmcbig4 -- python3 tools/run_configs.py C4 C5 ;;
-    pmcoct3)     MIPTINA_OPTS=wide8=1 run pmcoct3 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcoct3 -- python3 tools/run_configs.py C4 C5 ;;
-    pmcoct4)     MIPTINA_OPTS=wide8=1 run pmcoct4 500 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM --output-format csv -d gpurun_out/pmcoct4 -- python3 tools/run_configs.py C4 C5 ;;
-    pmcoct1)     MIPTINA_OPTS=wide8=1 run pmcoct1 500 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcoct1 -- python3 tools/run_configs.py C4 C5 ;;
+    pmcoct3)     MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_oct.so MIPTINA_OPTS=wide8=1 run pmcoct3 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcoct3 -- python3 tools/run_configs.py C4 C5 ;;
+    pmcoct4)     MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_oct.so MIPTINA_OPTS=wide8=1 run pmcoct4 500 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM --output-format csv -d gpurun_out/pmcoct4 -- python3 tools/run_configs.py C4 C5 ;;
+    pmcoct1)     MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_oct.so MIPTINA_OPTS=wide8=1 run pmcoct1 500 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcoct1 -- python3 tools/run_configs.py C4 C5 ;;
     # (TA_* / TCP_* counter passes over run_configs.py hung rocprofv3 on this pool -- 7 minutes without output -- and are not offered)
     torchrun1)   run torchrun1 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --force-comm --no-cpu-baseline --no-pmc ;;
     *) echo "unknown step $step" ;;
