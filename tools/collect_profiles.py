@@ -103,7 +103,14 @@ if octs:
     with open(os.path.join(dst, f'{tag}_pmc_oct_summary.json'), 'w') as fh:
         json.dump(octs, fh, indent=1, sort_keys=True)
     print('8-wide kernel pmc summary ->', f'{tag}_pmc_oct_summary.json')
-for name in ('bench.log', 'diag.json'):
+for name in ('bench.log',):
     src = os.path.join(ROOT, 'gpurun_out', name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(dst, f'{tag}_{name}'))
+# one tracked file per diagnostic of tools/gpu_diag.py (shares_sync, stamps_<scene>, timeline, fixedcost, ...): nothing overwrites another
+for src in sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', 'diag_*.json'))):
+    key = os.path.basename(src)[len('diag_'):-len('.json')]
+    if key.startswith(('parity_', 'timing_', 'sched_')):
+        continue
+    shutil.copy(src, os.path.join(dst, f'{tag}_{key}.json'))
+    print('diagnostic ->', f'{tag}_{key}.json')

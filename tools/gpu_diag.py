@@ -22,8 +22,14 @@ os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 
 
 def save():
+    '''gpurun_out/diag.json (everything this run measured) and ONE FILE PER DIAGNOSTIC, gpurun_out/diag_<key>.json, which
+    tools/collect_profiles.py copies to profiles/<round>_<key>.json: a later run of another diagnostic then cannot overwrite what
+    DESIGN.md cites (r04_diag.json held only the last run's stamps)'''
     with open(os.path.join(ROOT, 'gpurun_out', 'diag.json'), 'w') as f:
         json.dump(out, f, indent=1)
+    for key, val in out.items():
+        with open(os.path.join(ROOT, 'gpurun_out', 'diag_%s.json' % key), 'w') as f:
+            json.dump({key: val, 'library': os.environ.get('MIPTINA_LIB', 'ptina_amd/libmiptina.so')}, f, indent=1)
 
 
 def parity(name, nx, ny, spp):
