@@ -643,6 +643,7 @@ DEV int shade_core(const MptRenderParams &p, const SCENE &sc, LaneState &L, Cnt 
         rec = shade_rec_load(p, L.hidx);
         lane_draws<6>(p, L, u);
     }
+    MPT_SEG(pl_trips)            // (the entry of the stage -- reloads of what the traversal loop had parked -- and the issue of its gathers)
     LightHit lit = lights_hit(p, ro, rd);
     if (lit.hit && (!was_hit || lit.dis < hdepth)) {
         float mis = power_heuristic(L.last_brdf_pdf, lit.pdf);
@@ -853,6 +854,16 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             // traversing ones 2 : 1 (best of the ratios tried on MI355X)
             if (trav * MPT_LEAVE_A < (64 - ndead - trav - deferred) * MPT_LEAVE_B) break;
             MPT_STAMP_BEGIN
+#if MPT_X_PAIRS
+            // Diagnostic build (counting kernels): what a lane that carried TWO paths could join.  Lanes i and i + 32 stand for the two
+            // paths of one such lane: the pairs with at least one path ready for the step, summed per scheduling decision into pl_local
+            // (NODE) / pl_batches (LEAF) / pl_batch_lanes (SHADE), the ready lanes into pl_prim / pl_tidle / pl_sidle (tools/pairs.py)
+            const unsigned long long mn = __ballot(L.st == ST_NODE), ml = __ballot(L.st == ST_LEAF);      // (every lane votes)
+            if (COUNT && (threadIdx.x & 63) == 0) {
+                if (cn * MPT_PREF_NODE >= cl * MPT_PREF_LEAF) { cnt.pl_local += (unsigned)__builtin_popcount((unsigned)mn | (unsigned)(mn >> 32)); cnt.pl_prim += (unsigned)__builtin_popcountll(mn); cnt.pl_trips++; }
+                else { cnt.pl_batches += (unsigned)__builtin_popcount((unsigned)ml | (unsigned)(ml >> 32)); cnt.pl_tidle += (unsigned)__builtin_popcountll(ml); cnt.pl_taken++; }
+            }
+#endif
             if (cn * MPT_PREF_NODE >= cl * MPT_PREF_LEAF) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
                 if (L.st == ST_NODE) {
@@ -906,6 +917,12 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             deferred = shade_now ? 0 : ns;
         }
         if (shade_now) {
+#if MPT_X_PAIRS
+            const unsigned long long ms = __ballot(L.st == ST_DONE && !L.shadow);
+            if (COUNT && (threadIdx.x & 63) == 0) {
+                cnt.pl_batch_lanes += (unsigned)__builtin_popcount((unsigned)ms | (unsigned)(ms >> 32)); cnt.pl_sidle += (unsigned)__builtin_popcountll(ms);
+            }
+#endif
             if (COUNT && (threadIdx.x & 63) == 0) cnt.it_shade++;
             MPT_STAMP_BEGIN
             if (L.st == ST_DONE && !L.shadow) {

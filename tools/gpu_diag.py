@@ -605,7 +605,7 @@ def stamps(name='s978', spp=32, n=512):
         res['new_segments_cycles_per_64_samples'] = {'pull': k['pl_local'] * 16 / k['samples'] * 64, 'prepare': k['pl_batches'] * 16 / k['samples'] * 64,
                                                      'new_total': k['bounces'] * 256 / k['samples'] * 64}
     elif k.get('pl_local', 0):         # -DMPT_X_STAMPS=2: the segments of SHADE, cycles per SHADE stage
-        seg = (('lights_hit', 'pl_local'), ('geometry_material_after_gathers', 'pl_batches'), ('light_sample', 'pl_batch_lanes'),
+        seg = (('entry_and_gather_issue', 'pl_trips'), ('lights_hit', 'pl_local'), ('geometry_material_after_gathers', 'pl_batches'), ('light_sample', 'pl_batch_lanes'),
                ('bsdf_eval_mis', 'pl_prim'), ('bsdf_sample', 'pl_tidle'), ('ray_start', 'pl_sidle'))
         res['shade_segments_cycles'] = {a: k[b] * 16 / max(k['it_shade'], 1) for a, b in seg}
     res['scene'] = name

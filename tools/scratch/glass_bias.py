@@ -29,3 +29,11 @@ for name in ('glass', 'rough_glass'):
             d = (tile_means(imgs[mode]) - tile_means(imgs['strict'])) / sc
             print(name, 'lift', lift, mode, 'mean diff %.4f%%' % (100 * (imgs[mode][..., :3].mean() / sc - 1)), 'tile rms %.4f%%' % (100 * np.sqrt((d ** 2).sum(-1).mean())))
             if mode == 'fast': print(np.round(100 * d.sum(-1) / 3, 3))
+# how often the near-tie path runs (counting build), coincident scene
+reset_all()
+eng = setup_engine(scene('glass', 0.0), 32, 32, mode='fast')
+ctx().set_option('count', 1); ctx().call('mpt_reset_counters')
+eng.render(64); ctx().call('mpt_flush')
+k = ctx().counters()
+print('near-ties decided by the reference rule: %d of %d triangle tests, %d rays' % (k['pl_taken'], k['n_tri'], k['rays']))
+reset_all()
