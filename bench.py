@@ -57,6 +57,13 @@ SIMD_LANES = 32              # a wave64 VALU instruction issues over 2 cycles on
 PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r04_pmc_summary.json')
 if not os.path.exists(PROFILE_FALLBACK):
     PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r03_pmc_summary.json')
+# The gather kernels' roofline (scenes that do not fit LDS): 64-byte records per second against what tools/microbench/gather_microbench
+# reaches with nothing else to do -- a dependent chain of random 64-byte records, four 16-byte loads each, 5 workgroups of 256 lanes per
+# CU, 58 % of the lanes taking part in a step (profiles/r04_gather_microbench.log, MI355X): 193.5 G records/s inside L2, and per size of
+# the table beyond it.  A traversal step reads one 64-byte node (four gathers), a triangle test one 48-byte record (three: 0.75 record).
+GATHER_IN_L2_GRECS = 193.48
+GATHER_BEYOND_L2_GRECS = {'c4': 78.4, 'c5': 59.3}     # 16.8 MB table (C4's records: ~15 MB) / 67 MB table (C5's: ~80 MB), same log
+GATHER_L2_HIT = {'c4': 0.67, 'c5': 0.90}              # TCC_HIT / (TCC_HIT + TCC_MISS) of the launches, profiles/r05_pmc_big_summary.json
 C3_N = 2048                  # BASELINE.json configs[2]: 2048 x 2048 film ...
 C3_SPP = 256                 # ... at 256 spp: one c3 step = render(256) (eight launches of 32 frames, pipelined) + gather + get_image()
 # the launch model of DESIGN.md section 6, measured on ONE MI355X (tools/gpu_diag.py shares_sync): a launch of 1/N of
@@ -350,6 +357,30 @@ def run_other_configs(mode, stub=False):
                         'ms_per_step': round(dt * 1e3, 3), 'kernel': kernel, 'avg_kernel_ms': round(kms / max(nl, 1), 4),
                         'launches_per_step': nl // steps, 'steps': steps, 'build_tree_ms': round(build_s * 1e3, 2),
                         'msamples_s_incl_build': round(n * n * spp / (dt + build_s) / 1e6, 1), 'scene_generation_s': round(gen_s, 2)}
+            if kernel == 'render_kernel_wide' and name in GATHER_L2_HIT:
+                # what bounds these kernels is the vector memory path's rate of divergent 16-byte gathers, not HBM bytes (their L2 hit
+                # rate is 67 / 90 %) and not MFMA: records of one launch (counting build) / its duration, against the micro-benchmark's
+                # rate blended by the launches' measured L2 hit rate
+                frames = min(spp, SPP)
+                film.clear()
+                c.set_option('count', 1)
+                c.call('mpt_reset_counters')
+                eng.render(frames)
+                c.call('mpt_synchronize')
+                cnt = c.counters()
+                c.set_option('count', 0)
+                recs_per_sample = (cnt['n_node'] + 0.75 * cnt['n_tri']) / max(cnt['samples'], 1)
+                achieved = recs_per_sample * n * n * spp / dt / 1e9       # G records/s over the whole step (its launches overlap; the read-back is in it)
+                h = GATHER_L2_HIT[name]
+                peak = 1.0 / (h / GATHER_IN_L2_GRECS + (1.0 - h) / GATHER_BEYOND_L2_GRECS[name])
+                out[key]['roofline'] = {
+                    'bound': 'gather', 'achieved': round(achieved, 2), 'peak': round(peak, 2), 'unit': 'G 64-B records/s', 'frac': round(achieved / peak, 4),
+                    'traffic': None, 'records_per_sample': round(recs_per_sample, 2), 'node_steps_per_ray': round(cnt['n_node'] / max(cnt['rays'], 1), 2),
+                    'triangle_tests_per_ray': round(cnt['n_tri'] / max(cnt['rays'], 1), 2), 'l2_hit_rate': h,
+                    'note': 'records = 4-wide node steps + 0.75 x triangle tests of one step (counting build) / the step\'s wall time; peak = '
+                            'tools/microbench/gather_microbench (random dependent 64-byte records, 5 workgroups per CU, 58 percent of the lanes): 193.5 G records/s '
+                            f'inside L2 and {GATHER_BEYOND_L2_GRECS[name]} beyond, blended harmonically by the L2 hit rate of these launches '
+                            '(profiles/r05_pmc_big_summary.json). HBM bytes are not the limit: FETCH_SIZE of a launch is 7-14 percent of the peak'}
         except Exception as e:                    # a configuration that fails must not cost the run its headline
             out[key] = {'workload': title, 'error': f'{type(e).__name__}: {e}'}
     common.reset_all()
