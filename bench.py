@@ -54,9 +54,9 @@ SPP = 32
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_SIMD = 256 * 4             # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 SIMD_LANES = 32              # a wave64 VALU instruction issues over 2 cycles on a SIMD-32
-PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r04_pmc_summary.json')
+PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r05_pmc_summary.json')
 if not os.path.exists(PROFILE_FALLBACK):
-    PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r03_pmc_summary.json')
+    PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r04_pmc_summary.json')
 # The gather kernels' roofline (scenes that do not fit LDS): 64-byte records per second against what tools/microbench/gather_microbench
 # reaches with nothing else to do -- a dependent chain of random 64-byte records, four 16-byte loads each, 5 workgroups of 256 lanes per
 # CU, 58 % of the lanes taking part in a step (profiles/r04_gather_microbench.log, MI355X): 193.5 G records/s inside L2, and per size of
@@ -69,7 +69,7 @@ C3_SPP = 256                 # ... at 256 spp: one c3 step = render(256) (eight 
 # the launch model of DESIGN.md section 6, measured on ONE MI355X (tools/gpu_diag.py shares_sync): a launch of 1/N of
 # a film costs a / N + b -- b = the end-of-launch drain, independent of N
 MODEL = {'headline': {'a_ms': 2.42, 'b_ms': 0.19}, 'c3': {'a_ms': 38.8, 'b_ms': 0.19},
-         'from': 'one-GPU share measurements, DESIGN.md section 6 (round 4, render_kernel_lds4: 2.61 / 1.43 / 0.80 / 0.49 ms per launch for N = 1 / 2 / 4 / 8)'}
+         'from': 'one-GPU share measurements, DESIGN.md section 6 (rounds 4 and 5, render_kernel_lds4: 2.61 / 1.42 / 0.80 / 0.49 ms per launch for N = 1 / 2 / 4 / 8; profiles/r05_shares_sync.json)'}
 
 PMC_PASSES = [
     ['SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES',
