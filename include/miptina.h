@@ -105,7 +105,8 @@ void mpt_destroy(mpt_ctx *ctx);
  * "pool_shaders" (the LDS kernel with its waves specialised into tracers and shaders and two path pools in LDS between them:
  * measured slower, default off),
  * "spin_us" (how long mpt_get_image polls a finalising launch before it blocks; default 20000, 0 = block at once),
- * "wide8" (1: scenes that do not fit LDS walk the 8-wide octant-ordered tree instead of the 4-wide one; A/B, default 0; takes effect at the
+ * "wide8" (1: scenes that do not fit LDS walk the 8-wide octant-ordered tree instead of the 4-wide one; only in the A/B build `make oct` ->
+ * libmiptina_oct.so since round 5 -- the product library refuses it; takes effect at the
  * next mpt_build_tree),
  * "finalise" (1, default: a render launch that finds no other launch in flight adds its frames to the film, resolves and
  * writes out finished tiles itself while its last paths drain; 0: always the combine pass after the launch; same film bit for bit),
