@@ -26,9 +26,9 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { K_FMA = 0, K_PKFMA = 1, K_RCP = 2, K_CNDMASK = 3 };
-static const char *kname[] = { "v_fma_f32", "v_pk_fma_f32", "v_rcp_f32", "v_cmp_lt_f32+v_cndmask_b32" };
-static const int vinsts_per_iter[] = { 64, 64, 64, 64 };
+enum { K_FMA = 0, K_PKFMA = 1, K_RCP = 2, K_CNDMASK = 3, K_PKFMA16 = 4, K_PKMIN16 = 5, K_PERM = 6, K_MAXF = 7, K_MINU = 8, K_ADDU = 9, K_MAX3 = 10, K_MUL = 11 };
+static const char *kname[] = { "v_fma_f32", "v_pk_fma_f32", "v_rcp_f32", "v_cmp_lt_f32+v_cndmask_b32", "v_pk_fma_f16", "v_pk_min_f16", "v_perm_b32", "v_max_f32", "v_min_u32", "v_add_u32", "v_max3_f32", "v_mul_f32" };
+static const int vinsts_per_iter[] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -53,6 +53,39 @@ __global__ __launch_bounds__(256) void valu_loop(float *out, unsigned long long 
 #undef M
             } else if (KIND == K_PKFMA) {
 #define M(k) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[k]) : "v"(xx), "v"(yy));
+                REP16(M)
+#undef M
+            } else if (KIND == K_PKFMA16) {
+                // round 5: two f16 FMAs per lane per instruction -- is THAT double rate? (the 4-wide NODE step's 24 FMAs and 16 min / max as 12 + 12)
+#define M(k) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(a[k]) : "v"(x), "v"(y));
+                REP16(M)
+#undef M
+            } else if (KIND == K_PKMIN16) {
+#define M(k) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(a[k]) : "v"(x));
+                REP16(M)
+#undef M
+            } else if (KIND == K_MAXF) {
+#define M(k) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[k]) : "v"(x));
+                REP16(M)
+#undef M
+            } else if (KIND == K_MINU) {
+#define M(k) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[k]) : "v"(x));
+                REP16(M)
+#undef M
+            } else if (KIND == K_ADDU) {
+#define M(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(x));
+                REP16(M)
+#undef M
+            } else if (KIND == K_MAX3) {
+#define M(k) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(x), "v"(y));
+                REP16(M)
+#undef M
+            } else if (KIND == K_MUL) {
+#define M(k) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k]) : "v"(x));
+                REP16(M)
+#undef M
+            } else if (KIND == K_PERM) {
+#define M(k) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(x), "v"(y));
                 REP16(M)
 #undef M
             } else if (KIND == K_RCP) {
@@ -111,11 +144,11 @@ static void run(int ncu, int waves_per_simd, int iters, float *d_out, unsigned l
                "\"clock_ghz\": %.4f, \"cycles_per_wave_inst_per_simd\": %.4f, \"cycles_per_wave_inst_seen_by_one_wave\": %.4f, "
                "\"wave_insts_per_s_per_simd\": %.4e, \"lane_ops_per_s_chip\": %.4e}",
                first ? "" : ",\n ", kname[KIND], waves_per_simd, insts_per_wave, ms, clock_hz / 1e9, cyc_per_inst_simd,
-               cyc_per_inst_wave, wall_rate, wall_rate * 64.0 * (KIND == K_PKFMA ? 2 : 1) * ncu * 4);
+               cyc_per_inst_wave, wall_rate, wall_rate * 64.0 * ((KIND == K_PKFMA || KIND == K_PKFMA16) ? 2 : 1) * ncu * 4);
     else
         printf("%-28s W=%d  %.3f ms  clock %.3f GHz  %.3f cycles/wave-inst/SIMD  (one wave sees %.2f)  %.3e lane-ops/s chip\n",
                kname[KIND], waves_per_simd, ms, clock_hz / 1e9, cyc_per_inst_simd, cyc_per_inst_wave,
-               wall_rate * 64.0 * (KIND == K_PKFMA ? 2 : 1) * ncu * 4);
+               wall_rate * 64.0 * ((KIND == K_PKFMA || KIND == K_PKFMA16) ? 2 : 1) * ncu * 4);
     CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
 }
 
@@ -136,6 +169,14 @@ int main(int argc, char **argv) {
     for (int w : ws) run<K_PKFMA>(ncu, w, iters, d_out, d_st, json, false);
     for (int w : ws) run<K_RCP>(ncu, w, iters / 2, d_out, d_st, json, false);
     for (int w : ws) run<K_CNDMASK>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_PKFMA16>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_PKMIN16>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_PERM>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_MAXF>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_MINU>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_ADDU>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_MAX3>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_MUL>(ncu, w, iters, d_out, d_st, json, false);
     if (json) printf("\n]}\n");
     return 0;
 }
