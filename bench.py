@@ -76,6 +76,8 @@ PMC_PASSES = [
      'SQ_BUSY_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY'],
     ['FETCH_SIZE', 'GRBM_GUI_ACTIVE'],
     ['WRITE_SIZE', 'TCC_HIT_sum', 'TCC_MISS_sum'],
+    # the instruction mix (round 5): add / mul / fma issue at one wave64 instruction per ~2.35 cycles per SIMD, everything else slower
+    ['SQ_INSTS_VALU_ADD_F32', 'SQ_INSTS_VALU_MUL_F32', 'SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_INT32', 'SQ_INSTS_VALU_CVT', 'SQ_INSTS_VALU_TRANS_F32'],
 ]
 
 
@@ -166,6 +168,28 @@ def committed_pmc(kernel):
     return None, 'no counters available'
 
 
+# Cycles per wave64 instruction per SIMD by class, measured on MI355X with tools/microbench/valu_microbench (profiles/r05_valu_microbench.log,
+# 4 waves per SIMD): add / mul / fma 2.3-2.4; compare and select 3.3; min / max (f32 and integer), v_perm, three-operand min / max and every
+# packed form 4.1-4.2; transcendentals 8.1.  The hardware counts add, mul, fma, 32-bit integer, conversion and transcendental instructions
+# separately; what is left of SQ_INSTS_VALU (compares, selects, f32 min / max, moves, v_perm) is priced at 3.5, integer at 3.0 (adds and
+# shifts at 2.3, integer min / max at 4.1).  An ESTIMATE of how busy the vector issue port is: valu_issue_frac prices every instruction at 2.
+CLASS_CYCLES = {'SQ_INSTS_VALU_ADD_F32': 2.35, 'SQ_INSTS_VALU_MUL_F32': 2.35, 'SQ_INSTS_VALU_FMA_F32': 2.4, 'SQ_INSTS_VALU_INT32': 3.0,
+                'SQ_INSTS_VALU_CVT': 3.3, 'SQ_INSTS_VALU_TRANS_F32': 8.1, 'other': 3.5}
+
+
+def issue_time_by_class(g, insts, concurrent, clock_hz, avg_kernel_s):
+    if g('SQ_INSTS_VALU_FMA_F32') is None:
+        return None
+    mix = {k: g(k) or 0.0 for k in CLASS_CYCLES if k != 'other'}
+    mix['other'] = max(insts - sum(mix.values()), 0.0)
+    cycles = sum(mix[k] * CLASS_CYCLES[k] for k in mix)
+    return {'frac': round(cycles * concurrent / (N_SIMD * clock_hz * avg_kernel_s), 4),
+            'mix': {k.replace('SQ_INSTS_VALU_', '').lower(): round(v / insts, 4) for k, v in mix.items()},
+            'cycles_per_instruction': CLASS_CYCLES,
+            'note': 'estimate: instruction counts by class x the cycles per wave64 instruction per SIMD the micro-benchmark measures for the class '
+                    '(profiles/r05_valu_microbench.log), over the SIMD-cycles of the launch'}
+
+
 def roofline_blocks(pmc, source, kernel, avg_kernel_s, clock_hz, concurrent):
     '''VALU roofline + HBM traffic of the dominant kernel from its PMC counters (per launch) and its
     average launch duration measured with HIP events in this run.
@@ -199,6 +223,7 @@ def roofline_blocks(pmc, source, kernel, avg_kernel_s, clock_hz, concurrent):
         'wave_cycles_valu_frac': round(g('SQ_ACTIVE_INST_VALU') / g('SQ_WAVE_CYCLES'), 3) if g('SQ_WAVE_CYCLES') else None,
         'wave_cycles_wait_inst_frac': round(g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'), 3) if g('SQ_WAVE_CYCLES') and g('SQ_WAIT_INST_ANY') else None,
         'counters_from': source,
+        'issue_time_by_class': issue_time_by_class(g, insts, concurrent, clock_hz, avg_kernel_s),
         'note': 'f32 vector lane-operations per second against 256 CU x 4 SIMD-32 x clock; the node and triangle records '
                 'are LDS-resident, so HBM is not the binding limit (see "hbm") and there is no contraction '
                 'for MFMA',

@@ -41,7 +41,7 @@ if f:
           'avg ms:', round(sum(full) / max(len(full), 1) / 1e3, 4))
 
 summary = {}
-for d in ('pmc1', 'pmc2', 'pmc3', 'pmc4'):
+for d in ('pmc1', 'pmc2', 'pmc3', 'pmc4', 'pmc5'):
     f = newest(f'{d}/*/*counter_collection.csv')
     if not f:
         continue

@@ -79,6 +79,7 @@ for step in "$@"; do
     pmc2)        run pmc2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc2 -- python3 bench.py --role pmc-child --steps 3 --warmup 1 ;;
     pmc3)        run pmc3 400 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc3 -- python3 bench.py --role pmc-child --steps 3 --warmup 1 ;;
     pmc4)        run pmc4 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc4 -- python3 bench.py --role pmc-child --steps 3 --warmup 1 ;;
+    pmc5)        run pmc5 400 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 --output-format csv -d gpurun_out/pmc5 -- python3 bench.py --role pmc-child --steps 3 --warmup 1 ;;
     pmcbig1)     run pmcbig1 500 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcbig1 -- python3 tools/run_configs.py C4 C5 ;;
     pmcbig2)     run pmcbig2 500 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmcbig2 -- python3 tools/run_configs.py C4 C5 ;;
     pmcbig3)     run pmcbig3 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcbig3 -- python3 tools/run_configs.py C4 C5 ;;
