@@ -26,9 +26,9 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { K_FMA = 0, K_PKFMA = 1, K_RCP = 2, K_CNDMASK = 3, K_PKFMA16 = 4, K_PKMIN16 = 5, K_PERM = 6, K_MAXF = 7, K_MINU = 8, K_ADDU = 9, K_MAX3 = 10, K_MUL = 11 };
-static const char *kname[] = { "v_fma_f32", "v_pk_fma_f32", "v_rcp_f32", "v_cmp_lt_f32+v_cndmask_b32", "v_pk_fma_f16", "v_pk_min_f16", "v_perm_b32", "v_max_f32", "v_min_u32", "v_add_u32", "v_max3_f32", "v_mul_f32" };
-static const int vinsts_per_iter[] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64 };
+enum { K_FMA = 0, K_PKFMA = 1, K_RCP = 2, K_CNDMASK = 3, K_PKFMA16 = 4, K_PKMIN16 = 5, K_PERM = 6, K_MAXF = 7, K_MINU = 8, K_ADDU = 9, K_MAX3 = 10, K_MUL = 11, K_ANDOR = 12, K_BFI = 13, K_LSHLOR = 14, K_BFE = 15, K_CNDMASK1 = 16, K_CMP1 = 17, K_MOV = 18, K_LSHLADD = 19 };
+static const char *kname[] = { "v_fma_f32", "v_pk_fma_f32", "v_rcp_f32", "v_cmp_lt_f32+v_cndmask_b32", "v_pk_fma_f16", "v_pk_min_f16", "v_perm_b32", "v_max_f32", "v_min_u32", "v_add_u32", "v_max3_f32", "v_mul_f32", "v_and_or_b32", "v_bfi_b32", "v_lshl_or_b32", "v_bfe_i32", "v_cndmask_b32 (vcc set once)", "v_cmp_lt_f32 alone", "v_mov_b32", "v_lshl_add_u32" };
+static const int vinsts_per_iter[] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -82,6 +82,39 @@ __global__ __launch_bounds__(256) void valu_loop(float *out, unsigned long long 
 #undef M
             } else if (KIND == K_MUL) {
 #define M(k) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k]) : "v"(x));
+                REP16(M)
+#undef M
+            } else if (KIND == K_ANDOR) {
+#define M(k) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(x), "v"(y));
+                REP16(M)
+#undef M
+            } else if (KIND == K_BFI) {
+#define M(k) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[k]) : "v"(x), "v"(y));
+                REP16(M)
+#undef M
+            } else if (KIND == K_LSHLOR) {
+#define M(k) asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(a[k]) : "v"(x));
+                REP16(M)
+#undef M
+            } else if (KIND == K_BFE) {
+#define M(k) asm volatile("v_bfe_i32 %0, %0, 0, 16" : "+v"(a[k]));
+                REP16(M)
+#undef M
+            } else if (KIND == K_CNDMASK1) {
+                asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x), "v"(y) : "vcc");
+#define M(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(x) : "vcc");
+                REP16(M)
+#undef M
+            } else if (KIND == K_CMP1) {
+#define M(k) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[k]), "v"(x) : "vcc");
+                REP16(M)
+#undef M
+            } else if (KIND == K_MOV) {
+#define M(k) asm volatile("v_mov_b32 %0, %1" : "=v"(a[k]) : "v"(x));
+                REP16(M)
+#undef M
+            } else if (KIND == K_LSHLADD) {
+#define M(k) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[k]) : "v"(x));
                 REP16(M)
 #undef M
             } else if (KIND == K_PERM) {
@@ -177,6 +210,14 @@ int main(int argc, char **argv) {
     for (int w : ws) run<K_ADDU>(ncu, w, iters, d_out, d_st, json, false);
     for (int w : ws) run<K_MAX3>(ncu, w, iters, d_out, d_st, json, false);
     for (int w : ws) run<K_MUL>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_ANDOR>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_BFI>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_LSHLOR>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_BFE>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_CNDMASK1>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_CMP1>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_MOV>(ncu, w, iters, d_out, d_st, json, false);
+    for (int w : ws) run<K_LSHLADD>(ncu, w, iters, d_out, d_st, json, false);
     if (json) printf("\n]}\n");
     return 0;
 }
