@@ -61,7 +61,7 @@ if summary:
 # big scenes (`tools/gpu_round.sh pmcbig1..4` = `run_configs.py C4 C5` under --pmc): the production kernel
 # of the big scenes (4-wide gather, render_kernel_wide<false, true>: 8-bit child boxes) is dispatched as [C4 1-spp, C4 x6 (32 frames of 1024^2), C5 1-spp, C5 x3 (16 frames of 1024^2)]
 big = {}
-for d in ('pmcbig1', 'pmcbig2', 'pmcbig3', 'pmcbig4'):
+for d in ('pmcbig1', 'pmcbig2', 'pmcbig3', 'pmcbig4', 'pmcbig5'):
     f = newest(f'{d}/*/*counter_collection.csv')
     if not f:
         continue

@@ -84,6 +84,7 @@ for step in "$@"; do
     pmcbig2)     run pmcbig2 500 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmcbig2 -- python3 tools/run_configs.py C4 C5 ;;
     pmcbig3)     run pmcbig3 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcbig3 -- python3 tools/run_configs.py C4 C5 ;;
     pmcbig4)     run pmcbig4 500 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM --output-format csv -d gpurun_out/pmcbig4 -- python3 tools/run_configs.py C4 C5 ;;
+    pmcbig5)     run pmcbig5 500 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 --output-format csv -d gpurun_out/pmcbig5 -- python3 tools/run_configs.py C4 C5 ;;
     pmcoct3)     MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_oct.so MIPTINA_OPTS=wide8=1 run pmcoct3 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcoct3 -- python3 tools/run_configs.py C4 C5 ;;
     pmcoct4)     MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_oct.so MIPTINA_OPTS=wide8=1 run pmcoct4 500 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM --output-format csv -d gpurun_out/pmcoct4 -- python3 tools/run_configs.py C4 C5 ;;
     pmcoct1)     MIPTINA_LIB=$GRAFT_REPO_ROOT/ptina_amd/libmiptina_oct.so MIPTINA_OPTS=wide8=1 run pmcoct1 500 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcoct1 -- python3 tools/run_configs.py C4 C5 ;;
