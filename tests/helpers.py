@@ -108,14 +108,15 @@ def assert_parity(img, ref, pix_tol, max_outlier_frac, rel_rmse_tol, what=''):
     return rel_rmse, frac
 
 
-def soak_finalisation(launches, nx=512, ny=512, frames=4, per_round=50, stripes=None, stress_mb=0, stress_copies=0, log=None):
+def soak_finalisation(launches, nx=512, ny=512, frames=4, per_round=50, stripes=None, stress_mb=0, stress_copies=0, log=None, opts=()):
     '''The tail finalisation's hand-off (render_kernel.hip store_sample / finalise_tiles: a sample entry of the slab is two
     8-byte granules that carry the launch's tag) checked on DATA: `per_round` launches of `frames` frames, each followed by a
     get_image() (so every launch finds the GPU idle and finalises its own tiles), replayed from the same Sobol index with the
     combine pass (option finalise = 0) once -- then round after round with the finalisation on, and the raw film must be the
     combine pass's bit for bit every time.  A sample accepted before its data had arrived (a stale or torn entry) changes a sum.
     stripes = (width, rank, world): a 1/world share as `bench.py --gpus world` deals it; stress_mb / stress_copies: that many
-    device-to-device copies of that size enqueued beside every round (mpt_stress_copies).  Returns the launches checked.'''
+    device-to-device copies of that size enqueued beside every round (mpt_stress_copies); opts: context options, e.g. (('lds', 0),)
+    for the gather kernels.  Returns the launches checked.'''
     from ptina_amd import scenes
     from ptina_amd.common import ctx, reset_all
     from ptina_amd.things import FilmTable
@@ -124,6 +125,8 @@ def soak_finalisation(launches, nx=512, ny=512, frames=4, per_round=50, stripes=
     eng = setup_engine(scenes.scene_s978(), nx, ny, mode='fast', max_filmsize=max(nx * ny, 1 << 18))
     c = ctx()
     c.set_option('batch', frames)
+    for k, v in opts:
+        c.set_option(k, v)
     if stripes:
         c.call('mpt_set_stripes', *stripes)
     film, sob = FilmTable(), SobolSampler()
@@ -153,7 +156,7 @@ def soak_finalisation(launches, nx=512, ny=512, frames=4, per_round=50, stripes=
         done += per_round
         rounds += 1
         if log and rounds % 20 == 0:
-            log('  %d launches bit-identical (%dx%d, %d frames per launch, stripes %s, stress %d x %d MiB per round)'
-                % (done, nx, ny, frames, stripes, stress_copies, stress_mb))
+            log('  %d launches bit-identical (%dx%d, %d frames per launch, stripes %s, stress %d x %d MiB per round, options %s)'
+                % (done, nx, ny, frames, stripes, stress_copies, stress_mb, dict(opts)))
     reset_all()
     return done

@@ -33,6 +33,9 @@ for stress in (0, 24):
     for r in range(8):
         shapes.append(dict(frames=4, per_round=50, stripes=(16, r, 8), stress_mb=1024, stress_copies=stress))
     shapes.append(dict(nx=500, ny=310, frames=3, per_round=50, stress_mb=1024, stress_copies=stress))
+    # the gather kernels' finalisation (the same scene forced off LDS: 4-wide 8-bit nodes; binary nodes), whole film and a 1/8 share
+    shapes.append(dict(frames=4, per_round=50, stress_mb=1024, stress_copies=stress, opts=(('lds', 0),)))
+    shapes.append(dict(frames=4, per_round=50, stripes=(16, 2, 8), stress_mb=1024, stress_copies=stress, opts=(('lds', 0), ('wide', 0))))
 weight = sum(2.0 if 'stripes' not in s else 1.0 for s in shapes)
 done = 0
 for s in shapes:
