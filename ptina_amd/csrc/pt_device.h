@@ -258,6 +258,8 @@ struct Stack {
     DEV void push(int v) { base[sp * MPT_BLOCK] = v; sp++; }
     DEV int pop() { sp--; return base[sp * MPT_BLOCK]; }
     static constexpr bool PEEK = true;                 // the entry a pop would return can be read ahead of the decision
+    static constexpr bool SP_ADDR = false;
+    static constexpr int SP_STEP = 1;
     DEV int peek(int at) const { return base[at * MPT_BLOCK]; }
 };
 
@@ -427,6 +429,8 @@ struct SpillStack {
     }
     static constexpr bool PEEK = false;
     DEV int peek(int) const { return 0; }
+    static constexpr bool SP_ADDR = false;
+    static constexpr int SP_STEP = 1;
 };
 
 // 8-wide nodes with octant-ordered child slots and 8-bit boxes (oct_build.cpp): 80-byte records, FIVE 16-B gathers per step for
@@ -564,6 +568,8 @@ struct Stack16 {
     DEV int pop() { sp--; return (int)base[sp * MPT_LDS_BLOCK]; }
     static constexpr bool PEEK = true;
     DEV int peek(int at) const { return (int)base[at * MPT_LDS_BLOCK]; }
+    static constexpr bool SP_ADDR = false;
+    static constexpr int SP_STEP = 1;
 };
 
 // The 4-wide nodes with exact boxes resident in LDS (render_kernel_lds4): the first seven float4 of a wnode record -- {lo.x[4]}
@@ -603,6 +609,9 @@ struct LdsWideScene {
 
 // its LIFO: 16-bit entries, [level][lane of 1024], as many levels as the tree can ask for (3 x depth + 2, the host checks): a
 // step's three pushes are plain stores, nothing spills
+#ifndef MPT_SP_ADDR
+#define MPT_SP_ADDR 1              // LaneState::sp of the 4-wide LDS kernel is the LDS address of the next free slot (0: the level, as everywhere else)
+#endif
 #ifndef MPT_LDS4_PLANE_OFF
 #define MPT_LDS4_PLANE_OFF 0       // 16: the ray carries the offsets of its entry planes (three registers); 0: the step reads the signs off 1/d
 #endif
@@ -618,6 +627,21 @@ struct Stack16W {
     DEV int pop() { sp--; return (int)base[sp * MPT_LDS_BLOCK]; }
     static constexpr bool PEEK = true;                 // (the LEAF step reads the entry it will pop together with its triangle)
     DEV int peek(int at) const { return (int)base[at * MPT_LDS_BLOCK]; }
+    static constexpr bool SP_ADDR = MPT_SP_ADDR != 0;
+#if MPT_SP_ADDR
+    // The lane's stack pointer as the LDS byte ADDRESS of its next free slot (LaneState::sp in the 4-wide LDS kernel): a push or pop
+    // is a ds access at that register and a full-rate add of SP_STEP -- level * 2048 + base is a v_lshl_add_u32 per access, and
+    // shifts issue at half the rate of adds on gfx950 (tools/microbench/exec_microbench)
+    static constexpr int SP_STEP = MPT_LDS_BLOCK * 2;
+    DEV int sp_at(int level) const { return (int)(unsigned)(unsigned long long)(base + level * MPT_LDS_BLOCK); }
+    DEV static void st(int sp, int v) { *(LdsShortPtr)(unsigned long long)(unsigned)sp = (short)v; }
+    DEV static int ld(int sp) { return (int)*(LdsShortPtr)(unsigned long long)(unsigned)sp; }
+#else
+    static constexpr int SP_STEP = 1;
+    DEV int sp_at(int level) const { return level; }
+    DEV void st(int sp, int v) const { base[sp * MPT_LDS_BLOCK] = (short)v; }
+    DEV int ld(int sp) const { return (int)base[sp * MPT_LDS_BLOCK]; }
+#endif
 };
 
 // the same LIFO for the tracer waves of the pooled kernel: [level][tracer lane], the lane count a launch parameter
@@ -631,6 +655,8 @@ struct Stack16V {
     DEV int pop() { sp--; return (int)base[sp * stride]; }
     static constexpr bool PEEK = true;
     DEV int peek(int at) const { return (int)base[at * stride]; }
+    static constexpr bool SP_ADDR = false;
+    static constexpr int SP_STEP = 1;
 };
 
 #if MPT_STRICT

@@ -347,7 +347,8 @@ DEV void lane_start_ray(LaneState &L, STACK &stk, V3 o, V3 d, float tmax, bool s
     L.tbest = tmax; L.shadow = shadow ? 1 : 0; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f;
     stk.sp = 0;
     stk.push(STACK::SENTINEL);
-    L.curr = 0; L.sp = 1;
+    L.curr = 0;
+    if constexpr (STACK::SP_ADDR) L.sp = stk.sp_at(1); else L.sp = 1;
     if (COUNT) cnt.rays++;
     L.st = ST_NODE;
 }
@@ -457,6 +458,29 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     L.st = classify<STACK>(next);
 }
 
+// min(a, b, c, tbest) of a slab test's exit side.  Written as the two instructions themselves: through fminf the compiler first
+// quiets a signalling NaN its analysis cannot rule out in tbest (a register carried round the loop) -- one v_max_f32 tbest, tbest
+// per step, and min / max issue at half the rate of an FMA on gfx950.  The instructions return the same bits as fminf for every
+// input that is not a signalling NaN, and nothing in the kernel makes one.  MI355X, same box, alternated three times
+// (profiles/r05_ab_experiments.json): 2.593 / 2.566 / 2.554 ms per launch -> 2.560 / 2.537 / 2.526.  (The 8-bit step of the
+// gather kernels, which wait for their gathers as much as for the issue port, did not move with it: C4 1547 / 1543 against 1546 / 1549.)
+#ifndef MPT_ASM_MIN
+#define MPT_ASM_MIN 1
+#endif
+DEV float exit_min_asm(float a, float b, float c, float tbest) {
+    float m, r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(c), "v"(tbest));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+    return r;
+}
+DEV float exit_min(float a, float b, float c, float tbest) {
+#if MPT_ASM_MIN
+    return exit_min_asm(a, b, c, tbest);
+#else
+    return fminf(fminf(a, b), fminf(c, tbest));
+#endif
+}
+
 // The same step through a 4-wide node: four slab tests (planes picked by the ray's direction signs) on one 128-B
 // record, the children that are hit sorted
 // by entry distance (a five-comparator network on (distance bits, id) pairs; a miss sorts last), the nearest
@@ -504,8 +528,8 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
 #define MPT_SLAB(c, tn, h)                                                                                              \
         tn = fmaxf(fmaxf(__builtin_fmaf(nx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(ny.c, L.inv.y, -L.oinv.y)),            \
                    fmaxf(__builtin_fmaf(nz.c, L.inv.z, -L.oinv.z), 0.0f));                                               \
-        h = tn <= fminf(fminf(__builtin_fmaf(fx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(fy.c, L.inv.y, -L.oinv.y)),      \
-                        fminf(__builtin_fmaf(fz.c, L.inv.z, -L.oinv.z), L.tbest));
+        h = tn <= exit_min(__builtin_fmaf(fx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(fy.c, L.inv.y, -L.oinv.y),          \
+                           __builtin_fmaf(fz.c, L.inv.z, -L.oinv.z), L.tbest);
         MPT_SLAB(x, t0, h0) MPT_SLAB(y, t1, h1) MPT_SLAB(z, t2, h2) MPT_SLAB(w, t3, h3)
 #undef MPT_SLAB
     }
@@ -525,7 +549,8 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
         k3 = h3 ? __builtin_amdgcn_perm((unsigned)__float_as_int(t3), (unsigned)id3, 0x07060100u) : MISS;
         const unsigned a0 = min(k0, k1), a1 = max(k0, k1), b0 = min(k2, k3), b1 = max(k2, k3);
         const unsigned m0 = max(a0, b0), m1 = min(a1, b1);
-        k0 = min(a0, b0); k3 = max(a1, b1); k1 = min(m0, m1); k2 = max(m0, m1);
+        k0 = min(a0, b0); k3 = max(a1, b1); k1 = min(m0, m1); k2 = max(m0, m1);    // (measured and not kept: without this fifth
+        // comparator -- the middle pair in whatever order the network leaves it -- the step is two instructions shorter and the launch 1.8 % longer)
         id0 = (int)(short)(k0 & 0xffffu); id1 = (int)k1; id2 = (int)k2; id3 = (int)k3;      // (the pushes store the low halves)
     } else {
         if constexpr (!SCENE::AVOID_IN_LEAF) { h0 = h0 && id0 != L.navoid; h1 = h1 && id1 != L.navoid; h2 = h2 && id2 != L.navoid; h3 = h3 && id3 != L.navoid; }
@@ -546,10 +571,17 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
         // that is not wanted lands on the slot the next one overwrites -- instead of three divergent regions with a spill test each
         typedef typename STACK::entry_t entry_t;
         int sp = L.sp;
-        stk.base[sp * STACK::STRIDE] = (entry_t)id3; sp += k3 != MISS ? 1 : 0;
-        stk.base[sp * STACK::STRIDE] = (entry_t)id2; sp += k2 != MISS ? 1 : 0;
-        stk.base[sp * STACK::STRIDE] = (entry_t)id1; sp += k1 != MISS ? 1 : 0;
-        if (k0 == MISS) { sp--; next = (int)stk.base[sp * STACK::STRIDE]; }           // sorted: then nothing was pushed
+        if constexpr (STACK::SP_ADDR) {                                               // (sp: the address of the slot, Stack16W)
+            STACK::st(sp, id3); sp += k3 != MISS ? STACK::SP_STEP : 0;
+            STACK::st(sp, id2); sp += k2 != MISS ? STACK::SP_STEP : 0;
+            STACK::st(sp, id1); sp += k1 != MISS ? STACK::SP_STEP : 0;
+            if (k0 == MISS) { sp -= STACK::SP_STEP; next = STACK::ld(sp); }
+        } else {
+            stk.base[sp * STACK::STRIDE] = (entry_t)id3; sp += k3 != MISS ? 1 : 0;
+            stk.base[sp * STACK::STRIDE] = (entry_t)id2; sp += k2 != MISS ? 1 : 0;
+            stk.base[sp * STACK::STRIDE] = (entry_t)id1; sp += k1 != MISS ? 1 : 0;
+            if (k0 == MISS) { sp--; next = (int)stk.base[sp * STACK::STRIDE]; }       // sorted: then nothing was pushed
+        }
         L.sp = sp;
     } else {
         stk.sp = L.sp;
@@ -575,7 +607,8 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     if (COUNT) cnt.n_tri += (SCENE::AVOID_IN_LEAF && L.curr == L.navoid) ? 0u : 1u;
 #if MPT_SPEC_POP
     int spec = 0;
-    if constexpr (STACK::PEEK) spec = stk.peek(L.sp - 1);      // a leaf step always pops: asked for with the triangle record
+    if constexpr (STACK::SP_ADDR) spec = STACK::ld(L.sp - STACK::SP_STEP);
+    else if constexpr (STACK::PEEK) spec = stk.peek(L.sp - 1);      // a leaf step always pops: asked for with the triangle record
 #endif
     MptVec4 g0, g1, g2;
     sc.tri(slot, g0, g1, g2);
@@ -591,7 +624,7 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     }
     int next;
 #if MPT_SPEC_POP
-    if constexpr (STACK::PEEK) { next = spec; L.sp = L.sp - 1; } else
+    if constexpr (STACK::PEEK) { next = spec; L.sp = L.sp - (STACK::SP_ADDR ? STACK::SP_STEP : 1); } else
 #endif
     {
         stk.sp = L.sp;
