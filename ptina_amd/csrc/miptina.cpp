@@ -510,6 +510,19 @@ extern "C" int mpt_load_model(mpt_ctx *c, const float *verts, const int32_t *mtl
             return fail("material id %d of face %d outside [-1, %d)", c->mtlids[i], i, c->caps.max_materials);
         c->max_mtlid = std::max(c->max_mtlid, (int)c->mtlids[i]);
     }
+    {   // the bounding sphere of the model's box (MptRenderParams::t_scale)
+        double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+        for (size_t v = 0; v < (size_t)n * 3; v++)
+            for (int k = 0; k < 3; k++) {
+                const double x = c->verts[v * 8 + k];
+                if (x < lo[k]) lo[k] = x;
+                if (x > hi[k]) hi[k] = x;
+            }
+        double r2 = 0;
+        for (int k = 0; k < 3; k++) { c->scene_cen[k] = n ? 0.5 * (lo[k] + hi[k]) : 0.0; r2 += n ? 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]) : 0.0; }
+        c->scene_rad = std::sqrt(r2);
+        if (!std::isfinite(c->scene_rad)) c->scene_rad = 1e30;
+    }
     c->tree_valid = false;
     return 0;
 }
@@ -682,6 +695,25 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     p.ntiles = p.tiles_x * p.tiles_y;
     memcpy(p.world_fac, c->world_fac, sizeof p.world_fac);
     memcpy(p.v2w, c->v2w, sizeof p.v2w);
+    {   // t_scale: 2^-e with 2^e no less than the farthest a ray origin -- a point of the camera's near plane or of a surface -- can be
+        // from any point of the scene's bounding sphere (mpt_load_model)
+        double reach = c->nfaces > 0 ? 2.0 * c->scene_rad : 1.0;
+        for (int corner = 0; corner < 4 && c->nfaces > 0; corner++) {
+            const double x = (corner & 1) ? 1.0 : -1.0, y = (corner & 2) ? 1.0 : -1.0;
+            const float *M = c->v2w;
+            const double a3 = M[12] * x + M[13] * y - M[14] + M[15];
+            double d2 = 0;
+            for (int k = 0; k < 3; k++) {
+                const double o = (M[4 * k] * x + M[4 * k + 1] * y - M[4 * k + 2] + M[4 * k + 3]) / a3;
+                d2 += (o - c->scene_cen[k]) * (o - c->scene_cen[k]);
+            }
+            if (std::isfinite(d2)) reach = std::max(reach, std::sqrt(d2) + c->scene_rad);
+        }
+        int e = 0;
+        std::frexp(std::min(std::max(reach * 1.001, 1e-30), 1e30), &e);       // reach * 1.001 <= 2^e
+        p.t_scale = (float)std::ldexp(1.0, -e);
+        p.t_unscale = (float)std::ldexp(1.0, e);
+    }
     p.wnode = c->wnode; p.qnode = c->qnode; p.nwide = c->wide_nodes; p.onode = nullptr; p.stack_spill = nullptr;
     p.snode = c->snode; p.fnode = c->fnode; p.tgeo = c->tgeo; p.tshade = c->tshade; p.tfast = c->tfast;
     p.default_mtl = c->caps.max_materials;
@@ -780,8 +812,9 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     const size_t lds4_bytes = ((size_t)c->wide_nodes * (MPT_LDS4_NODE_STRIDE / 16) + ((size_t)c->nfaces + 1) * 3 + (size_t)(lds4_nmats + 1) * 6) * sizeof(MptVec4) +
                               (((size_t)c->nfaces + 15) & ~(size_t)15) + (size_t)c->wide_stack * 1024 * sizeof(short);
     const bool lds4_kernel = fast && c->use_lds && c->lds_wide && c->use_wide && !c->use_pool && c->wide_nodes > 0 && c->wide_stack > 0 && c->wnode &&
-                             c->nfaces >= 2 && c->nfaces < 32767 && lds4_nmats < 255 && lds4_bytes <= 160 * 1024 &&
-                             (size_t)c->wide_nodes * (MPT_LDS4_NODE_STRIDE / 8) < 32768;
+                             c->nfaces >= 2 && c->nfaces < (MPT_LDS4_IDS ? 4095 : 32767) && lds4_nmats < 255 && lds4_bytes <= 160 * 1024 &&
+                             (MPT_LDS4_IDS ? (size_t)c->wide_nodes * MPT_LDS4_NODE_STRIDE < 65536     // (16-bit ids: mpt_types.h MPT_LDS4_IDS)
+                                           : (size_t)c->wide_nodes * (MPT_LDS4_NODE_STRIDE / 8) < 32768);
     const bool lds_kernel = lds4_kernel ||
                             (fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && c->caps.max_materials < 256 &&
                              lds_bytes <= 160 * 1024 &&

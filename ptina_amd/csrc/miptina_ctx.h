@@ -119,6 +119,7 @@ struct mpt_ctx {
     // model (host copy kept for the tree build)
     int nfaces = 0;
     std::vector<float> verts;            // [3n][8]
+    double scene_cen[3] = { 0, 0, 0 }, scene_rad = 0;   // bounding sphere of the model's box (mpt_load_model)
     std::vector<int32_t> mtlids;
     bool tree_valid = false;
     int tree_depth = 0;                  // reference LBVH (strict build)

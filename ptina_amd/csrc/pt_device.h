@@ -258,7 +258,7 @@ struct Stack {
     DEV void push(int v) { base[sp * MPT_BLOCK] = v; sp++; }
     DEV int pop() { sp--; return base[sp * MPT_BLOCK]; }
     static constexpr bool PEEK = true;                 // the entry a pop would return can be read ahead of the decision
-    static constexpr bool SP_ADDR = false;
+    static constexpr bool SP_ADDR = false, ODD_IDS = false, T_SCALED = false;
     static constexpr int SP_STEP = 1;
     DEV int peek(int at) const { return base[at * MPT_BLOCK]; }
 };
@@ -287,6 +287,7 @@ struct GlobalScene {
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr int NODE_REP = MPT_NODE_REP;
     static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
+    static constexpr bool ODD_IDS = false, T_SCALED = false;
     const MptVec4 *fnode, *tgeo;
     int soa_n;                 // node count, for the layout A/B build below
     DEV void node(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &d) const {
@@ -321,6 +322,7 @@ struct WideScene {
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr int NODE_REP = MPT_WIDE_REP;
     static constexpr bool WIDE = true, QUANT = false, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
+    static constexpr bool ODD_IDS = false, T_SCALED = false;
     const MptVec4 *wnode, *tgeo;
     // entry (n*) and exit (f*) planes of the four children, picked by the ray's direction signs: o* is 0 for a ray
     // going up the axis and 16 (bytes: the next float4) for one going down -- still seven dwordx4 gathers
@@ -374,6 +376,7 @@ struct QuantScene {
     static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
     static constexpr int NODE_REP = MPT_WIDE_REP;      // extra NODE steps per scheduling decision
     static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
+    static constexpr bool ODD_IDS = false, T_SCALED = false;
     const MptVec4 *qnode, *tgeo;
     DEV void node4q(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &id) const {
         const char *base = (const char *)qnode;
@@ -429,7 +432,7 @@ struct SpillStack {
     }
     static constexpr bool PEEK = false;
     DEV int peek(int) const { return 0; }
-    static constexpr bool SP_ADDR = false;
+    static constexpr bool SP_ADDR = false, ODD_IDS = false, T_SCALED = false;
     static constexpr int SP_STEP = 1;
 };
 
@@ -442,6 +445,7 @@ struct OctScene {
     static constexpr int SHADE_MIN = 0;
     static constexpr int NODE_REP = 0;
     static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false, OCT = true;
+    static constexpr bool ODD_IDS = false, T_SCALED = false;
     const MptVec4 *onode, *tgeo;                       // tgeo: tfast8, the 48-byte records in the 8-wide tree's leaf order
     DEV void node8(int i, MptVec4 &h0, MptVec4 &h1, MptVec4 &px, MptVec4 &py, MptVec4 &pz) const {
         const char *base = (const char *)onode;
@@ -492,6 +496,7 @@ struct OctStack {
 typedef float mpt_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const mpt_f4 *LdsVec4Ptr;
 typedef __attribute__((address_space(3))) short *LdsShortPtr;
+typedef __attribute__((address_space(3))) unsigned short *LdsUShortPtr;
 
 DEV MptVec4 lds_ld(LdsVec4Ptr q) { mpt_f4 v = *q; MptVec4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
 
@@ -516,6 +521,7 @@ struct LdsSceneT {
     static constexpr int NODE_REP = MPT_NODE_REP;
     static constexpr int SHADE_MIN = MPT_SHADE_MIN_LDS; // SHADE waits until this many lanes want it (render_kernel.hip trace_stream)
     static constexpr bool WIDE = false, QUANT = false, SIGNED_PLANES = true, LDS_MATS = true, OCT = false;
+    static constexpr bool ODD_IDS = false, T_SCALED = false;
     LdsVec4Ptr fnode, tgeo;
     // The material records (parameters + derived terms, 96 B each, the default material last) and one byte per
     // leaf slot naming the record: SHADE reads its material out of LDS while the shading record of the triangle is
@@ -568,7 +574,7 @@ struct Stack16 {
     DEV int pop() { sp--; return (int)base[sp * MPT_LDS_BLOCK]; }
     static constexpr bool PEEK = true;
     DEV int peek(int at) const { return (int)base[at * MPT_LDS_BLOCK]; }
-    static constexpr bool SP_ADDR = false;
+    static constexpr bool SP_ADDR = false, ODD_IDS = false, T_SCALED = false;
     static constexpr int SP_STEP = 1;
 };
 
@@ -588,12 +594,17 @@ struct LdsWideScene {
     static constexpr int NODE_REP = MPT_LDS4_REP;
     static constexpr int SHADE_MIN = MPT_SHADE_MIN_LDS;
     static constexpr bool WIDE = true, QUANT = false, SIGNED_PLANES = false, LDS_MATS = true, OCT = false;
+    // ids as the LDS copy of the node records holds them (render_kernel_lds4 rewrites them while it copies): a node's is its record's
+    // byte offset in LDS -- the address itself, no shift -- and a leaf's (slot << 4) | 1; records are 16-byte aligned, so bit 0 tells
+    // them apart with a full-rate v_and where the sign needed a shift or a sign extension (half rate on gfx950)
+    static constexpr bool ODD_IDS = MPT_LDS4_IDS != 0;
+    static constexpr bool T_SCALED = MPT_T_SCALED != 0;     // (Stack16W::ts)
     LdsVec4Ptr wnode, tgeo, mats;
     LdsU8Ptr mtl;
     int mat_last, mat_default;
     DEV void node4(int i, int ox, int oy, int oz, MptVec4 &nx, MptVec4 &fx, MptVec4 &ny, MptVec4 &fy, MptVec4 &nz, MptVec4 &fz,
                    MptVec4 &id) const {
-        LdsBytePtr nd = (LdsBytePtr)wnode + (i << 3);
+        LdsBytePtr nd = (LdsBytePtr)wnode + (ODD_IDS ? i : (i << 3));
         nx = lds_ld((LdsVec4Ptr)(nd + ox));      fx = lds_ld((LdsVec4Ptr)(nd + (ox ^ 16)));
         ny = lds_ld((LdsVec4Ptr)(nd + 32 + oy)); fy = lds_ld((LdsVec4Ptr)(nd + 32 + (oy ^ 16)));
         nz = lds_ld((LdsVec4Ptr)(nd + 64 + oz)); fz = lds_ld((LdsVec4Ptr)(nd + 64 + (oz ^ 16)));
@@ -602,7 +613,9 @@ struct LdsWideScene {
     DEV void tri(int slot, MptVec4 &g0, MptVec4 &g1, MptVec4 &g2) const {
         // (`tgeo + slot * 3` is compiled into a 64-bit multiply-add, v_mad_u64_u32 -- gfx950 has no 32-bit integer mad -- for a 32-bit LDS
         //  address; the 24-bit multiply is one instruction, v_mad_u32_u24: -0.25 % per launch.  Slots are below 2^15)
-        LdsVec4Ptr g = (LdsVec4Ptr)((LdsBytePtr)tgeo + __umul24((unsigned)slot, 48u));
+        // with ODD_IDS `slot` is the leaf's id, 16 * slot + 1: three times that is the record's offset plus three
+        LdsVec4Ptr g = ODD_IDS ? (LdsVec4Ptr)((LdsBytePtr)tgeo - 3 + __umul24((unsigned)slot, 3u))
+                               : (LdsVec4Ptr)((LdsBytePtr)tgeo + __umul24((unsigned)slot, 48u));
         g0 = lds_ld(g); g1 = lds_ld(g + 1); g2 = lds_ld(g + 2);
     }
 };
@@ -616,13 +629,21 @@ struct LdsWideScene {
 #define MPT_LDS4_PLANE_OFF 0       // 16: the ray carries the offsets of its entry planes (three registers); 0: the step reads the signs off 1/d
 #endif
 struct Stack16W {
-    static constexpr int SENTINEL = -32768;
+    static constexpr bool ODD_IDS = MPT_LDS4_IDS != 0;
+    static constexpr int SENTINEL = ODD_IDS ? 0xffff : -32768;      // (ODD_IDS: the id of leaf slot 4095, which no scene that fits has)
     static constexpr int PLANE_OFF = MPT_LDS4_PLANE_OFF;
     static constexpr int CAP = 1 << 20, STRIDE = MPT_LDS_BLOCK;
     static constexpr bool NO_SPILL = true;
     typedef short entry_t;
     LdsShortPtr base;          // &lds16[threadIdx.x]
     int sp;
+    // T_SCALED: while a ray is traversed its 1/d, o/d and tbest are held multiplied by ts = MptRenderParams::t_scale, a power of two
+    // small enough that no box is entered beyond distance 1 / ts: every t of a slab test is the unscaled one times ts bit for bit
+    // (so is every comparison between them), and the entry side's max(t, 0) becomes the clamp bit of one of its FMAs -- four
+    // half-rate v_max_f32 less per step.  (A t beyond 1 / ts -- a plane nearly parallel to the ray -- clamps to 1: the box test
+    // can only pass where it failed, never fail where it passed.)
+    static constexpr bool T_SCALED = MPT_T_SCALED != 0;
+    float ts;
     DEV void push(int v) { base[sp * MPT_LDS_BLOCK] = (short)v; sp++; }
     DEV int pop() { sp--; return (int)base[sp * MPT_LDS_BLOCK]; }
     static constexpr bool PEEK = true;                 // (the LEAF step reads the entry it will pop together with its triangle)
@@ -635,12 +656,15 @@ struct Stack16W {
     static constexpr int SP_STEP = MPT_LDS_BLOCK * 2;
     DEV int sp_at(int level) const { return (int)(unsigned)(unsigned long long)(base + level * MPT_LDS_BLOCK); }
     DEV static void st(int sp, int v) { *(LdsShortPtr)(unsigned long long)(unsigned)sp = (short)v; }
-    DEV static int ld(int sp) { return (int)*(LdsShortPtr)(unsigned long long)(unsigned)sp; }
+    DEV static int ld(int sp) {
+        if constexpr (ODD_IDS) return (int)*(LdsUShortPtr)(unsigned long long)(unsigned)sp;
+        else return (int)*(LdsShortPtr)(unsigned long long)(unsigned)sp;
+    }
 #else
     static constexpr int SP_STEP = 1;
     DEV int sp_at(int level) const { return level; }
     DEV void st(int sp, int v) const { base[sp * MPT_LDS_BLOCK] = (short)v; }
-    DEV int ld(int sp) const { return (int)base[sp * MPT_LDS_BLOCK]; }
+    DEV int ld(int sp) const { return ODD_IDS ? (int)(unsigned short)base[sp * MPT_LDS_BLOCK] : (int)base[sp * MPT_LDS_BLOCK]; }
 #endif
 };
 
@@ -655,7 +679,7 @@ struct Stack16V {
     DEV int pop() { sp--; return (int)base[sp * stride]; }
     static constexpr bool PEEK = true;
     DEV int peek(int at) const { return (int)base[at * stride]; }
-    static constexpr bool SP_ADDR = false;
+    static constexpr bool SP_ADDR = false, ODD_IDS = false, T_SCALED = false;
     static constexpr int SP_STEP = 1;
 };
 

@@ -330,13 +330,15 @@ DEV void store_sample(const MptRenderParams &p, int frame, int pix, V3 radiance)
 // popping the sentinel means the traversal is over
 template <class STACK>
 DEV int classify(int v) {      // what a popped / chosen entry means for the lane's state
-    return v == STACK::SENTINEL ? ST_DONE : (v < 0 ? ST_LEAF : ST_NODE);
+    if constexpr (STACK::ODD_IDS) return v == STACK::SENTINEL ? ST_DONE : (v & 1);      // (ST_LEAF == 1, ST_NODE == 0)
+    else return v == STACK::SENTINEL ? ST_DONE : (v < 0 ? ST_LEAF : ST_NODE);
 }
 
 template <bool COUNT, class STACK>
 DEV void lane_start_ray(LaneState &L, STACK &stk, V3 o, V3 d, float tmax, bool shadow, Cnt &cnt) {
     L.to = o; L.td = d;
     L.inv = v3(m_rcp(d.x), m_rcp(d.y), m_rcp(d.z));
+    if constexpr (STACK::T_SCALED) { L.inv = L.inv * stk.ts; tmax *= stk.ts; }
     L.oinv = o * L.inv;
     // which of an axis' two planes the ray enters through: offset of that plane in the node record
     if constexpr (STACK::PLANE_OFF != 0) {     // (the 4-wide gather kernels read the signs off L.inv in the step: three registers less to carry)
@@ -527,7 +529,8 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
         id0 = __float_as_int(idv.x); id1 = __float_as_int(idv.y); id2 = __float_as_int(idv.z); id3 = __float_as_int(idv.w);
 #define MPT_SLAB(c, tn, h)                                                                                              \
         tn = fmaxf(fmaxf(__builtin_fmaf(nx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(ny.c, L.inv.y, -L.oinv.y)),            \
-                   fmaxf(__builtin_fmaf(nz.c, L.inv.z, -L.oinv.z), 0.0f));                                               \
+                   STACK::T_SCALED ? __builtin_amdgcn_fmed3f(__builtin_fmaf(nz.c, L.inv.z, -L.oinv.z), 0.0f, 1.0f)       \
+                                   : fmaxf(__builtin_fmaf(nz.c, L.inv.z, -L.oinv.z), 0.0f));                             \
         h = tn <= exit_min(__builtin_fmaf(fx.c, L.inv.x, -L.oinv.x), __builtin_fmaf(fy.c, L.inv.y, -L.oinv.y),          \
                            __builtin_fmaf(fz.c, L.inv.z, -L.oinv.z), L.tbest);
         MPT_SLAB(x, t0, h0) MPT_SLAB(y, t1, h1) MPT_SLAB(z, t2, h2) MPT_SLAB(w, t3, h3)
@@ -551,7 +554,8 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
         const unsigned m0 = max(a0, b0), m1 = min(a1, b1);
         k0 = min(a0, b0); k3 = max(a1, b1); k1 = min(m0, m1); k2 = max(m0, m1);    // (measured and not kept: without this fifth
         // comparator -- the middle pair in whatever order the network leaves it -- the step is two instructions shorter and the launch 1.8 % longer)
-        id0 = (int)(short)(k0 & 0xffffu); id1 = (int)k1; id2 = (int)k2; id3 = (int)k3;      // (the pushes store the low halves)
+        id0 = STACK::ODD_IDS ? (int)(k0 & 0xffffu) : (int)(short)(k0 & 0xffffu);
+        id1 = (int)k1; id2 = (int)k2; id3 = (int)k3;                                         // (the pushes store the low halves)
     } else {
         if constexpr (!SCENE::AVOID_IN_LEAF) { h0 = h0 && id0 != L.navoid; h1 = h1 && id1 != L.navoid; h2 = h2 && id2 != L.navoid; h3 = h3 && id3 != L.navoid; }
         k0 = h0 ? (unsigned)__float_as_int(t0) : MISS;
@@ -572,9 +576,20 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
         typedef typename STACK::entry_t entry_t;
         int sp = L.sp;
         if constexpr (STACK::SP_ADDR) {                                               // (sp: the address of the slot, Stack16W)
+#if MPT_X_ASM_PUSH
+            // A/B: "k != MISS" as the carry of k + 1 (a full-rate add) instead of a half-rate compare
+#define MPT_PUSH_INC(k, inc) asm("v_add_co_u32 %0, vcc, 1, %1\n\tv_cndmask_b32_e64 %0, %2, 0, vcc" : "=&v"(inc) : "v"(k), "v"((int)STACK::SP_STEP) : "vcc");
+            int inc3, inc2, inc1;
+            MPT_PUSH_INC(k3, inc3) MPT_PUSH_INC(k2, inc2) MPT_PUSH_INC(k1, inc1)
+#undef MPT_PUSH_INC
+            STACK::st(sp, id3); sp += inc3;
+            STACK::st(sp, id2); sp += inc2;
+            STACK::st(sp, id1); sp += inc1;
+#else
             STACK::st(sp, id3); sp += k3 != MISS ? STACK::SP_STEP : 0;
             STACK::st(sp, id2); sp += k2 != MISS ? STACK::SP_STEP : 0;
             STACK::st(sp, id1); sp += k1 != MISS ? STACK::SP_STEP : 0;
+#endif
             if (k0 == MISS) { sp -= STACK::SP_STEP; next = STACK::ld(sp); }
         } else {
             stk.base[sp * STACK::STRIDE] = (entry_t)id3; sp += k3 != MISS ? 1 : 0;
@@ -601,7 +616,7 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
 
 template <bool COUNT, class SCENE, class STACK>
 DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
-    int slot = ~L.curr;
+    int slot = SCENE::ODD_IDS ? L.curr : ~L.curr;      // (ODD_IDS: the leaf's id stands for the slot until a shading pass needs it)
     bool stop = false;
     // (the counters count the reference's work: it never tests the triangle a ray left from, lbvh.py:329)
     if (COUNT) cnt.n_tri += (SCENE::AVOID_IN_LEAF && L.curr == L.navoid) ? 0u : 1u;
@@ -614,6 +629,7 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     sc.tri(slot, g0, g1, g2);
     float dd, su, sv;
     bool hit = tri_test_fast(g0, g1, g2, L.to, L.td, &dd, &su, &sv);
+    if constexpr (STACK::T_SCALED) dd *= stk.ts;                            // (L.tbest is held scaled while the ray is traversed)
     if constexpr (SCENE::AVOID_IN_LEAF) hit = hit && L.curr != L.navoid;    // the triangle the ray left from (lbvh.py:329): the NODE step let it through
     if (hit) {
         if (L.shadow) {
@@ -665,15 +681,16 @@ template <bool COUNT, class SCENE>
 DEV int shade_core(const MptRenderParams &p, const SCENE &sc, LaneState &L, Cnt &cnt, V3 &hitpos, V3 &sdir, float &sdis) {
     V3 ro = L.to, rd = L.prd;
     const bool was_hit = L.hidx >= 0;
-    float hdepth = was_hit ? L.tbest : MPT_INF;
+    float hdepth = was_hit ? (SCENE::T_SCALED ? L.tbest * p.t_unscale : L.tbest) : MPT_INF;
     // everything the stage gathers from L2 is asked for first: the shading record of the triangle and the six
     // Sobol numbers of the bounce (path.py:48,58: light triple, then BSDF triple) -- one round trip, under the
     // light tests, instead of three in a row
     ShadeRec rec = {};
     float u[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     MPT_SEG_BEGIN
+    const int hslot = SCENE::ODD_IDS ? (L.hidx >> 4) : L.hidx;
     if (was_hit) {
-        rec = shade_rec_load(p, L.hidx);
+        rec = shade_rec_load(p, hslot);
         lane_draws<6>(p, L, u);
     }
     MPT_SEG(pl_trips)            // (the entry of the stage -- reloads of what the traversal loop had parked -- and the issue of its gathers)
@@ -689,8 +706,8 @@ DEV int shade_core(const MptRenderParams &p, const SCENE &sc, LaneState &L, Cnt 
         L.depth = 5;                                                         // break, path.py:39
         return SH_END;
     }
-    L.navoid = ~L.hidx;
-    Hit hit; hit.hit = 1; hit.depth = hdepth; hit.index = L.hidx; hit.u = L.hu; hit.v = L.hv;
+    L.navoid = SCENE::ODD_IDS ? L.hidx : ~L.hidx;
+    Hit hit; hit.hit = 1; hit.depth = hdepth; hit.index = hslot; hit.u = L.hu; hit.v = L.hv;
     V3 normal; Disney mat;
     get_geometries_rec(p, sc, rec, hit, ro, rd, &hitpos, &normal, mat);
     if (COUNT) { cnt.n_shade++; cnt.n_draws += 6; }
@@ -1382,12 +1399,13 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds4(const MptRen
         for (int k = threadIdx.x; k < p.nwide * 7; k += blockDim.x) {
             const int rec = k / 7, w = k - rec * 7;
             MptVec4 v = p.wnode[rec * 8 + w];
-            if (w == 6) {                                                        // the four ids: internal ones become byte offset / 8
+            if (w == 6) {
+                // the four ids: internal ones become the record's byte offset (/ 8 without ODD_IDS), leaves (slot << 4) | 1 (~slot)
                 const int i0 = __float_as_int(v.x), i1 = __float_as_int(v.y), i2 = __float_as_int(v.z), i3 = __float_as_int(v.w);
-                v.x = __int_as_float(i0 >= 0 ? i0 * (MPT_LDS4_NODE_STRIDE / 8) : i0);
-                v.y = __int_as_float(i1 >= 0 ? i1 * (MPT_LDS4_NODE_STRIDE / 8) : i1);
-                v.z = __int_as_float(i2 >= 0 ? i2 * (MPT_LDS4_NODE_STRIDE / 8) : i2);
-                v.w = __int_as_float(i3 >= 0 ? i3 * (MPT_LDS4_NODE_STRIDE / 8) : i3);
+                const int scale = LdsWideScene::ODD_IDS ? MPT_LDS4_NODE_STRIDE : MPT_LDS4_NODE_STRIDE / 8;
+#define MPT_LDS_ID(i) __int_as_float((i) >= 0 ? (i) * scale : (LdsWideScene::ODD_IDS ? ((~(i)) << 4) | 1 : (i)))
+                v.x = MPT_LDS_ID(i0); v.y = MPT_LDS_ID(i1); v.z = MPT_LDS_ID(i2); v.w = MPT_LDS_ID(i3);
+#undef MPT_LDS_ID
             }
             smem[k] = v;
         }
@@ -1415,6 +1433,7 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds4(const MptRen
     Stack16W stk;
     stk.base = (LdsShortPtr)(void *)(smem + nnode4 + ntri4 + nmat4 + nmtl4) + threadIdx.x;
     stk.sp = 0;
+    stk.ts = p.t_scale;
     Cnt cnt = {};
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
     trace_stream<COUNT>(p, sc, stk, wq, cnt, tl);

@@ -19,10 +19,10 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { K_FMA, K_MAX, K_CVTUB, K_OR, K_AND, K_LSHL, K_SUB, K_MED3, K_CVTU, K_XOR, K_MADU24, K_MULU24, K_ORSDWA, K_CVTSDWA, K_MIN3, K_ADD3, K_FMAMIX, K_CVTF16, K_CVTFP8, K_NKINDS };
+enum { K_FMA, K_MAX, K_CVTUB, K_OR, K_AND, K_LSHL, K_SUB, K_MED3, K_CVTU, K_XOR, K_MADU24, K_MULU24, K_ORSDWA, K_CVTSDWA, K_MIN3, K_ADD3, K_FMAMIX, K_CVTF16, K_CVTFP8, K_MAD64, K_LSHLADD64, K_LSHL64, K_MULLO, K_MULHI, K_ASHR, K_MIXFM, K_MIXFC, K_LSHR, K_NKINDS };
 static const char *kname[] = { "v_fma_f32", "v_max_f32", "v_cvt_f32_ubyte1", "v_or_b32", "v_and_b32", "v_lshlrev_b32", "v_sub_f32", "v_med3_f32",
                                "v_cvt_f32_u32", "v_xor_b32", "v_mad_u32_u24", "v_mul_u32_u24", "v_or_b32_sdwa (BYTE_1)", "v_cvt_f32_u32_sdwa (BYTE_1)",
-                               "v_min3_f32", "v_add3_u32", "v_fma_mix_f32 (f16 hi, f32, f32)", "v_cvt_f32_f16", "v_cvt_pk_f32_fp8 (2 values)" };
+                               "v_min3_f32", "v_add3_u32", "v_fma_mix_f32 (f16 hi, f32, f32)", "v_cvt_f32_f16", "v_cvt_pk_f32_fp8 (2 values)", "v_mad_i64_i32", "v_lshl_add_u64", "v_lshlrev_b64", "v_mul_lo_u32", "v_mul_hi_u32", "v_ashrrev_i32", "v_fma_f32 / v_max_f32 alternating", "v_fma_f32 / v_cvt_f32_ubyte1 alternating", "v_lshrrev_b32" };
 
 #define REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
@@ -111,6 +111,43 @@ __global__ __launch_bounds__(256) void exec_loop(float *out, unsigned long long 
 #define M(k) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a[k]));
                 REP16(M)
 #undef M
+            } else if (KIND == K_MAD64) {
+#define M(k) asm volatile("v_mad_i64_i32 %0, s[10:11], %1, %2, %0" : "+v"(q[k]) : "v"(x), "v"(y) : "s10", "s11");
+                REP16(M)
+#undef M
+            } else if (KIND == K_LSHLADD64) {
+#define M(k) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(q[k]) : "v"(q[(k + 1) & 15]));
+                REP16(M)
+#undef M
+            } else if (KIND == K_LSHL64) {
+#define M(k) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(q[k]));
+                REP16(M)
+#undef M
+            } else if (KIND == K_MULLO) {
+#define M(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(x));
+                REP16(M)
+#undef M
+            } else if (KIND == K_MULHI) {
+#define M(k) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[k]) : "v"(x));
+                REP16(M)
+#undef M
+            } else if (KIND == K_ASHR) {
+#define M(k) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a[k]));
+                REP16(M)
+#undef M
+            } else if (KIND == K_MIXFM) {
+                // one issue port or two units side by side?  32 FMAs and 32 max per 64: 3.25 cycles per instruction if their times add, 2.1 if they overlap
+#define M(k) if ((k) & 1) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[k]) : "v"(x)); else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[k]) : "v"(x), "v"(y));
+                REP16(M)
+#undef M
+            } else if (KIND == K_MIXFC) {
+#define M(k) if ((k) & 1) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(a[k])); else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[k]) : "v"(x), "v"(y));
+                REP16(M)
+#undef M
+            } else if (KIND == K_LSHR) {
+#define M(k) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(a[k]));
+                REP16(M)
+#undef M
             } else if (KIND == K_CVTFP8) {
 #define M(k) asm volatile("v_cvt_pk_f32_fp8 %0, %1" : "+v"(q[k]) : "v"(x));
                 REP16(M)
@@ -194,6 +231,15 @@ int main() {
         run<K_FMAMIX>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
         run<K_CVTF16>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
         run<K_CVTFP8>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
+        run<K_MAD64>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
+        run<K_LSHLADD64>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
+        run<K_LSHL64>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
+        run<K_MULLO>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
+        run<K_MULHI>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
+        run<K_ASHR>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
+        run<K_LSHR>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
+        run<K_MIXFM>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
+        run<K_MIXFC>(ncu, w, iters, ~0ull, "all 64", d_out, d_st);
     }
     return 0;
 }
