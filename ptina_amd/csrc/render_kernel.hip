@@ -36,6 +36,9 @@
 #define MPT_SPEC_POP 1        // the stack entry a step may pop is read together with the step's node / triangle record
 #endif
 
+#ifndef MPT_SPEC_POP4
+#define MPT_SPEC_POP4 1       // ... and so does the 4-wide step of the LDS-resident kernel
+#endif
 #ifndef MPT_ONE_START
 #define MPT_ONE_START 1       // one ray-start block per shading pass (0: each stage starts its own lanes' rays, as before)
 #endif
@@ -496,6 +499,12 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     float t0, t1, t2, t3;
     bool h0, h1, h2, h3;
     if (COUNT) { cnt.n_node++; cnt.n_box += 4; }
+#if MPT_SPEC_POP4
+    // the entry a step without a hit pops is asked for together with the node record: some lane of the wave pops in nearly every
+    // step, and the wave then waited a second LDS round trip behind the sort (pushes go to level sp and above, never to sp - 1)
+    int spec = 0;
+    if constexpr (STACK::SP_ADDR) spec = STACK::ld(L.sp - STACK::SP_STEP);
+#endif
     if constexpr (SCENE::QUANT) {
         MptVec4 ra, rb, rc, idv;
         sc.node4q(L.curr, ra, rb, rc, idv);
@@ -576,21 +585,14 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
         typedef typename STACK::entry_t entry_t;
         int sp = L.sp;
         if constexpr (STACK::SP_ADDR) {                                               // (sp: the address of the slot, Stack16W)
-#if MPT_X_ASM_PUSH
-            // A/B: "k != MISS" as the carry of k + 1 (a full-rate add) instead of a half-rate compare
-#define MPT_PUSH_INC(k, inc) asm("v_add_co_u32 %0, vcc, 1, %1\n\tv_cndmask_b32_e64 %0, %2, 0, vcc" : "=&v"(inc) : "v"(k), "v"((int)STACK::SP_STEP) : "vcc");
-            int inc3, inc2, inc1;
-            MPT_PUSH_INC(k3, inc3) MPT_PUSH_INC(k2, inc2) MPT_PUSH_INC(k1, inc1)
-#undef MPT_PUSH_INC
-            STACK::st(sp, id3); sp += inc3;
-            STACK::st(sp, id2); sp += inc2;
-            STACK::st(sp, id1); sp += inc1;
-#else
             STACK::st(sp, id3); sp += k3 != MISS ? STACK::SP_STEP : 0;
             STACK::st(sp, id2); sp += k2 != MISS ? STACK::SP_STEP : 0;
             STACK::st(sp, id1); sp += k1 != MISS ? STACK::SP_STEP : 0;
-#endif
+#if MPT_SPEC_POP4
+            if (k0 == MISS) { sp -= STACK::SP_STEP; next = spec; }
+#else
             if (k0 == MISS) { sp -= STACK::SP_STEP; next = STACK::ld(sp); }
+#endif
         } else {
             stk.base[sp * STACK::STRIDE] = (entry_t)id3; sp += k3 != MISS ? 1 : 0;
             stk.base[sp * STACK::STRIDE] = (entry_t)id2; sp += k2 != MISS ? 1 : 0;
@@ -805,9 +807,18 @@ DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(by
 #define MPT_STAMP_END(acc)
 #endif
 DEV int wave_count(bool pred) { return (int)__builtin_popcountll(__ballot(pred)); }
-DEV int wave_count32(bool pred) {            // the same in two 32-bit halves: stays on the scalar unit when compared
+#ifndef MPT_BCNT64
+#define MPT_BCNT64 1
+#endif
+DEV int wave_count32(bool pred) {            // a count that stays on the scalar unit when compared
     unsigned long long m = __ballot(pred);
+#if MPT_BCNT64
+    int n;                                   // one s_bcnt1_i32_b64, written out: the compiler's own 64-bit popcount ends up compared on the VALU, and
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");     // two 32-bit ones are three scalar instructions in the chain in front of every step
+    return n;                                // (MI355X: 2.462 / 2.464 / 2.463 ms per launch -> 2.449 / 2.453 / 2.460)
+#else
     return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
+#endif
 }
 
 // (SCENE::OCT is only ever true in the A/B build with the 8-wide kernel: render_oct.h)
@@ -922,7 +933,9 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                     else stage_node<COUNT>(sc, stk, L, cnt);
                 }
                 // further steps for the lanes that are still at a node, without counting again: the three ballots
-                // and the decision chain in front of every step cost a wave about as many cycles as half a step
+                // and the decision chain in front of every step cost a wave about as many cycles as half a step.
+                // (Measured and not kept, tools/scratch/r05_node_prefetch_attempt.patch: the second step's node record asked for
+                //  the moment the first knows where the lane goes, before its pushes and the ballot in between: +1.6 % per launch.)
 #pragma unroll
                 for (int rep = 0; rep < SCENE::NODE_REP; rep++) {
                     if (__ballot(L.st == ST_NODE) == 0ull) break;
