@@ -630,7 +630,8 @@ struct LdsWideScene {
 #endif
 struct Stack16W {
     static constexpr bool ODD_IDS = MPT_LDS4_IDS != 0;
-    static constexpr int SENTINEL = ODD_IDS ? 0xffff : -32768;      // (ODD_IDS: the id of leaf slot 4095, which no scene that fits has)
+    static constexpr int SENTINEL = ODD_IDS ? 2 : -32768;           // (ODD_IDS: the two low bits of an entry are the lane's next state --
+                                                                    //  0 a node, ST_NODE; 1 a leaf, ST_LEAF; 2 only this, ST_DONE)
     static constexpr int PLANE_OFF = MPT_LDS4_PLANE_OFF;
     static constexpr int CAP = 1 << 20, STRIDE = MPT_LDS_BLOCK;
     static constexpr bool NO_SPILL = true;

@@ -333,7 +333,7 @@ DEV void store_sample(const MptRenderParams &p, int frame, int pix, V3 radiance)
 // popping the sentinel means the traversal is over
 template <class STACK>
 DEV int classify(int v) {      // what a popped / chosen entry means for the lane's state
-    if constexpr (STACK::ODD_IDS) return v == STACK::SENTINEL ? ST_DONE : (v & 1);      // (ST_LEAF == 1, ST_NODE == 0)
+    if constexpr (STACK::ODD_IDS) return v & 3;      // node ids are multiples of 16 (ST_NODE == 0), leaf ids 16 * slot + 1 (ST_LEAF == 1), the sentinel is 2 (ST_DONE)
     else return v == STACK::SENTINEL ? ST_DONE : (v < 0 ? ST_LEAF : ST_NODE);
 }
 
