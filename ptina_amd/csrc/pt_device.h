@@ -466,6 +466,8 @@ struct OctStack {
     static constexpr int SENTINEL = 0x40000000;        // the b word of the bottom entry: traversal over
     static constexpr int PLANE_OFF = 0;
     static constexpr bool PEEK = false;
+    static constexpr bool SP_ADDR = false, ODD_IDS = false, T_SCALED = false;
+    static constexpr int SP_STEP = 1;
 #ifndef MPT_OCT_CAP
 #define MPT_OCT_CAP 14
 #endif
@@ -604,7 +606,9 @@ struct LdsWideScene {
     int mat_last, mat_default;
     DEV void node4(int i, int ox, int oy, int oz, MptVec4 &nx, MptVec4 &fx, MptVec4 &ny, MptVec4 &fy, MptVec4 &nz, MptVec4 &fz,
                    MptVec4 &id) const {
-        LdsBytePtr nd = (LdsBytePtr)wnode + (ODD_IDS ? i : (i << 3));
+        // (ODD_IDS: the id is the record's LDS address -- the records start at the workgroup's LDS address 0, which the kernel checks;
+        //  written as wnode + i the compiler keeps a v_add_u32 of the constant 0 in every step)
+        LdsBytePtr nd = ODD_IDS ? (LdsBytePtr)(unsigned long long)(unsigned)i : (LdsBytePtr)wnode + (i << 3);
         nx = lds_ld((LdsVec4Ptr)(nd + ox));      fx = lds_ld((LdsVec4Ptr)(nd + (ox ^ 16)));
         ny = lds_ld((LdsVec4Ptr)(nd + 32 + oy)); fy = lds_ld((LdsVec4Ptr)(nd + 32 + (oy ^ 16)));
         nz = lds_ld((LdsVec4Ptr)(nd + 64 + oz)); fz = lds_ld((LdsVec4Ptr)(nd + 64 + (oz ^ 16)));
@@ -624,6 +628,9 @@ struct LdsWideScene {
 // step's three pushes are plain stores, nothing spills
 #ifndef MPT_SP_ADDR
 #define MPT_SP_ADDR 1              // LaneState::sp of the 4-wide LDS kernel is the LDS address of the next free slot (0: the level, as everywhere else)
+#endif
+#ifndef MPT_SP_TOP
+#define MPT_SP_TOP 1
 #endif
 #ifndef MPT_LDS4_PLANE_OFF
 #define MPT_LDS4_PLANE_OFF 0       // 16: the ray carries the offsets of its entry planes (three registers); 0: the step reads the signs off 1/d
@@ -661,8 +668,11 @@ struct Stack16W {
         if constexpr (ODD_IDS) return (int)*(LdsUShortPtr)(unsigned long long)(unsigned)sp;
         else return (int)*(LdsShortPtr)(unsigned long long)(unsigned)sp;
     }
+    // ... the address of the TOP entry, in fact (MPT_SP_TOP): the entry a step may pop is then read at the register itself, and a push
+    // goes to the register + SP_STEP -- the instruction's offset field -- where the next free slot asked for an add in front of every peek
+    static constexpr int SP_BIAS = MPT_SP_TOP ? SP_STEP : 0;
 #else
-    static constexpr int SP_STEP = 1;
+    static constexpr int SP_STEP = 1, SP_BIAS = 0;
     DEV int sp_at(int level) const { return level; }
     DEV void st(int sp, int v) const { base[sp * MPT_LDS_BLOCK] = (short)v; }
     DEV int ld(int sp) const { return ODD_IDS ? (int)(unsigned short)base[sp * MPT_LDS_BLOCK] : (int)base[sp * MPT_LDS_BLOCK]; }

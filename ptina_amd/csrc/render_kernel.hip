@@ -39,6 +39,9 @@
 #ifndef MPT_SPEC_POP4
 #define MPT_SPEC_POP4 1       // ... and so does the 4-wide step of the LDS-resident kernel
 #endif
+#ifndef MPT_LEAF_ONE_TEST
+#define MPT_LEAF_ONE_TEST 1   // one depth test in the LEAF step for both kinds of ray (lane_start_ray)
+#endif
 #ifndef MPT_ONE_START
 #define MPT_ONE_START 1       // one ray-start block per shading pass (0: each stage starts its own lanes' rays, as before)
 #endif
@@ -349,11 +352,16 @@ DEV void lane_start_ray(LaneState &L, STACK &stk, V3 o, V3 d, float tmax, bool s
         L.offy = __float_as_int(L.inv.y) < 0 ? STACK::PLANE_OFF : 0;
         L.offz = __float_as_int(L.inv.z) < 0 ? STACK::PLANE_OFF : 0;
     }
+#if MPT_LEAF_ONE_TEST
+    // a shadow ray takes any occluder with depth <= li.dis (path.py:51), a closest-hit ray a strictly nearer hit (lbvh.py:331): with
+    // the shadow ray's bound moved up to the next float the LEAF step asks both the same question, depth < tbest
+    if (shadow) { const int b = __float_as_int(tmax); tmax = __int_as_float(b + (b < 0x7f800000 ? 1 : 0)); }
+#endif
     L.tbest = tmax; L.shadow = shadow ? 1 : 0; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f;
     stk.sp = 0;
     stk.push(STACK::SENTINEL);
     L.curr = 0;
-    if constexpr (STACK::SP_ADDR) L.sp = stk.sp_at(1); else L.sp = 1;
+    if constexpr (STACK::SP_ADDR) L.sp = stk.sp_at(1) - STACK::SP_BIAS; else L.sp = 1;
     if (COUNT) cnt.rays++;
     L.st = ST_NODE;
 }
@@ -503,7 +511,7 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     // the entry a step without a hit pops is asked for together with the node record: some lane of the wave pops in nearly every
     // step, and the wave then waited a second LDS round trip behind the sort (pushes go to level sp and above, never to sp - 1)
     int spec = 0;
-    if constexpr (STACK::SP_ADDR) spec = STACK::ld(L.sp - STACK::SP_STEP);
+    if constexpr (STACK::SP_ADDR) spec = STACK::ld(L.sp - STACK::SP_STEP + STACK::SP_BIAS);
 #endif
     if constexpr (SCENE::QUANT) {
         MptVec4 ra, rb, rc, idv;
@@ -585,13 +593,13 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
         typedef typename STACK::entry_t entry_t;
         int sp = L.sp;
         if constexpr (STACK::SP_ADDR) {                                               // (sp: the address of the slot, Stack16W)
-            STACK::st(sp, id3); sp += k3 != MISS ? STACK::SP_STEP : 0;
-            STACK::st(sp, id2); sp += k2 != MISS ? STACK::SP_STEP : 0;
-            STACK::st(sp, id1); sp += k1 != MISS ? STACK::SP_STEP : 0;
+            STACK::st(sp + STACK::SP_BIAS, id3); sp += k3 != MISS ? STACK::SP_STEP : 0;
+            STACK::st(sp + STACK::SP_BIAS, id2); sp += k2 != MISS ? STACK::SP_STEP : 0;
+            STACK::st(sp + STACK::SP_BIAS, id1); sp += k1 != MISS ? STACK::SP_STEP : 0;
 #if MPT_SPEC_POP4
             if (k0 == MISS) { sp -= STACK::SP_STEP; next = spec; }
 #else
-            if (k0 == MISS) { sp -= STACK::SP_STEP; next = STACK::ld(sp); }
+            if (k0 == MISS) { sp -= STACK::SP_STEP; next = STACK::ld(sp + STACK::SP_BIAS); }
 #endif
         } else {
             stk.base[sp * STACK::STRIDE] = (entry_t)id3; sp += k3 != MISS ? 1 : 0;
@@ -624,7 +632,7 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     if (COUNT) cnt.n_tri += (SCENE::AVOID_IN_LEAF && L.curr == L.navoid) ? 0u : 1u;
 #if MPT_SPEC_POP
     int spec = 0;
-    if constexpr (STACK::SP_ADDR) spec = STACK::ld(L.sp - STACK::SP_STEP);
+    if constexpr (STACK::SP_ADDR) spec = STACK::ld(L.sp - STACK::SP_STEP + STACK::SP_BIAS);
     else if constexpr (STACK::PEEK) spec = stk.peek(L.sp - 1);      // a leaf step always pops: asked for with the triangle record
 #endif
     MptVec4 g0, g1, g2;
@@ -633,6 +641,12 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     bool hit = tri_test_fast(g0, g1, g2, L.to, L.td, &dd, &su, &sv);
     if constexpr (STACK::T_SCALED) dd *= stk.ts;                            // (L.tbest is held scaled while the ray is traversed)
     if constexpr (SCENE::AVOID_IN_LEAF) hit = hit && L.curr != L.navoid;    // the triangle the ray left from (lbvh.py:329): the NODE step let it through
+#if MPT_LEAF_ONE_TEST
+    if (hit && dd < L.tbest) {                                              // lbvh.py:331; path.py:51 (lane_start_ray)
+        L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv;
+        stop = L.shadow != 0;
+    }
+#else
     if (hit) {
         if (L.shadow) {
             if (dd <= L.tbest) { L.hidx = slot; stop = true; }              // path.py:51: any occluder within li.dis
@@ -640,6 +654,7 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
             L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv;
         }
     }
+#endif
     int next;
 #if MPT_SPEC_POP
     if constexpr (STACK::PEEK) { next = spec; L.sp = L.sp - (STACK::SP_ADDR ? STACK::SP_STEP : 1); } else
@@ -1439,6 +1454,12 @@ __global__ __launch_bounds__(MPT_LDS_BLOCK) void render_kernel_lds4(const MptRen
 
     LdsWideScene sc;
     sc.wnode = (LdsVec4Ptr)(void *)smem;
+    if (LdsWideScene::ODD_IDS && (unsigned)(unsigned long long)(LdsBytePtr)sc.wnode != 0u) {
+        // node ids are LDS addresses counted from 0: the dynamic LDS must be all the LDS this kernel has (it is; a static __shared__
+        // object added to it one day would move smem)
+        if (threadIdx.x == 0) __hip_atomic_store(p.watchdog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     sc.tgeo = (LdsVec4Ptr)(void *)(smem + nnode4);
     sc.mats = (LdsVec4Ptr)(void *)(smem + nnode4 + ntri4);
     sc.mtl = (LdsU8Ptr)(void *)(smem + nnode4 + ntri4 + nmat4);
