@@ -168,26 +168,24 @@ def committed_pmc(kernel):
     return None, 'no counters available'
 
 
-# Cycles per wave64 instruction per SIMD by class, measured on MI355X with tools/microbench/valu_microbench (profiles/r05_valu_microbench.log,
-# 4 waves per SIMD): add / mul / fma 2.3-2.4; compare and select 3.3; min / max (f32 and integer), v_perm, three-operand min / max and every
-# packed form 4.1-4.2; transcendentals 8.1.  The hardware counts add, mul, fma, 32-bit integer, conversion and transcendental instructions
-# separately; what is left of SQ_INSTS_VALU (compares, selects, f32 min / max, moves, v_perm) is priced at 3.5, integer at 3.0 (adds and
-# shifts at 2.3, integer min / max at 4.1).  An ESTIMATE of how busy the vector issue port is: valu_issue_frac prices every instruction at 2.
-CLASS_CYCLES = {'SQ_INSTS_VALU_ADD_F32': 2.35, 'SQ_INSTS_VALU_MUL_F32': 2.35, 'SQ_INSTS_VALU_FMA_F32': 2.4, 'SQ_INSTS_VALU_INT32': 3.0,
-                'SQ_INSTS_VALU_CVT': 3.3, 'SQ_INSTS_VALU_TRANS_F32': 8.1, 'other': 3.5}
+# What a wave64 VALU instruction costs a SIMD, measured on MI355X (tools/microbench/valu_microbench, exec_microbench; profiles/r05_*_microbench.log):
+# the issue port takes one instruction per 2.2-2.3 cycles whatever its kind -- a stream that alternates v_fma_f32 with v_max_f32 or
+# v_cvt_f32_ubyte runs at the pure FMA stream's rate -- while compares, min / max, conversions, v_perm, three-operand and 64-bit integer
+# forms keep a second unit busy for 4.1-4.2 cycles each (a stream of those alone runs at half rate), transcendentals for 8.1.  A mix
+# is therefore bound by max(all instructions x 2.25, half-rate ones x 4.2), not by the sum (round 5 first priced it by the sum:
+# DESIGN.md 3.1).  The hardware counts add, mul, fma, 32-bit integer, conversion and transcendental instructions separately; the
+# half-rate share cannot be read off those classes, so the line reports the port alone.
+ISSUE_CYCLES = 2.25
+MIX_COUNTERS = ('SQ_INSTS_VALU_ADD_F32', 'SQ_INSTS_VALU_MUL_F32', 'SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_INT32', 'SQ_INSTS_VALU_CVT',
+                'SQ_INSTS_VALU_TRANS_F32')
 
 
-def issue_time_by_class(g, insts, concurrent, clock_hz, avg_kernel_s):
+def instruction_mix(g, insts):
     if g('SQ_INSTS_VALU_FMA_F32') is None:
         return None
-    mix = {k: g(k) or 0.0 for k in CLASS_CYCLES if k != 'other'}
+    mix = {k: g(k) or 0.0 for k in MIX_COUNTERS}
     mix['other'] = max(insts - sum(mix.values()), 0.0)
-    cycles = sum(mix[k] * CLASS_CYCLES[k] for k in mix)
-    return {'frac': round(cycles * concurrent / (N_SIMD * clock_hz * avg_kernel_s), 4),
-            'mix': {k.replace('SQ_INSTS_VALU_', '').lower(): round(v / insts, 4) for k, v in mix.items()},
-            'cycles_per_instruction': CLASS_CYCLES,
-            'note': 'estimate: instruction counts by class x the cycles per wave64 instruction per SIMD the micro-benchmark measures for the class '
-                    '(profiles/r05_valu_microbench.log), over the SIMD-cycles of the launch'}
+    return {k.replace('SQ_INSTS_VALU_', '').lower(): round(v / insts, 4) for k, v in mix.items()}
 
 
 def roofline_blocks(pmc, source, kernel, avg_kernel_s, clock_hz, concurrent):
@@ -198,8 +196,9 @@ def roofline_blocks(pmc, source, kernel, avg_kernel_s, clock_hz, concurrent):
       lane occupancy         = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
       achieved lane-ops/s    = SQ_INSTS_VALU * 64 * lane occupancy / kernel time
       peak lane-ops/s        = 1024 SIMD-32 x 32 lanes x clock (= 157.3 TFLOP/s / 2 at 2.4 GHz)
-      issue fraction         = SQ_INSTS_VALU * 2 cycles / (1024 SIMDs * clock * kernel time)
-    (2 cycles per wave64 VALU instruction on a SIMD-32: tools/valu_microbench.hip, profiles/)'''
+      issue fraction         = SQ_INSTS_VALU * 2.25 cycles / (1024 SIMDs * clock * kernel time)
+      LDS pipe fraction      = SQ_LDS_IDX_ACTIVE / (256 CUs * clock * kernel time)
+    (2.25 cycles per wave64 VALU instruction of any kind at the issue port: ISSUE_CYCLES above)'''
     peak = N_SIMD * SIMD_LANES * clock_hz
     if not pmc or 'SQ_INSTS_VALU' not in pmc:
         return ({'bound': 'valu', 'achieved': None, 'peak': round(peak / 1e12, 3), 'unit': 'Tlane-op/s', 'frac': None,
@@ -218,12 +217,13 @@ def roofline_blocks(pmc, source, kernel, avg_kernel_s, clock_hz, concurrent):
         'kernel': kernel, 'avg_kernel_ms': round(avg_kernel_s * 1e3, 4), 'concurrent_launches': concurrent,
         'clock_ghz': round(clock_hz / 1e9, 3),
         'valu_insts_per_launch': int(insts), 'lane_occupancy': round(occ, 4),
-        'valu_issue_frac': round(insts * 2.0 * concurrent / (N_SIMD * clock_hz * avg_kernel_s), 4),
+        'valu_issue_frac': round(insts * ISSUE_CYCLES * concurrent / (N_SIMD * clock_hz * avg_kernel_s), 4),
+        'lds_pipe_frac': round(g('SQ_LDS_IDX_ACTIVE') * concurrent / (N_SIMD / 4 * clock_hz * avg_kernel_s), 4) if g('SQ_LDS_IDX_ACTIVE') else None,
         'salu_per_valu': round(g('SQ_INSTS_SALU') / insts, 3) if g('SQ_INSTS_SALU') else None,
         'wave_cycles_valu_frac': round(g('SQ_ACTIVE_INST_VALU') / g('SQ_WAVE_CYCLES'), 3) if g('SQ_WAVE_CYCLES') else None,
         'wave_cycles_wait_inst_frac': round(g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'), 3) if g('SQ_WAVE_CYCLES') and g('SQ_WAIT_INST_ANY') else None,
         'counters_from': source,
-        'issue_time_by_class': issue_time_by_class(g, insts, concurrent, clock_hz, avg_kernel_s),
+        'instruction_mix': instruction_mix(g, insts),
         'note': 'f32 vector lane-operations per second against 256 CU x 4 SIMD-32 x clock; the node and triangle records '
                 'are LDS-resident, so HBM is not the binding limit (see "hbm") and there is no contraction '
                 'for MFMA',
