@@ -68,16 +68,17 @@ C3_N = 2048                  # BASELINE.json configs[2]: 2048 x 2048 film ...
 C3_SPP = 256                 # ... at 256 spp: one c3 step = render(256) (eight launches of 32 frames, pipelined) + gather + get_image()
 # the launch model of DESIGN.md section 6, measured on ONE MI355X (tools/gpu_diag.py shares_sync): a launch of 1/N of
 # a film costs a / N + b -- b = the end-of-launch drain, independent of N
-MODEL = {'headline': {'a_ms': 2.42, 'b_ms': 0.19}, 'c3': {'a_ms': 38.8, 'b_ms': 0.19},
-         'from': 'one-GPU share measurements, DESIGN.md section 6 (rounds 4 and 5, render_kernel_lds4: 2.61 / 1.42 / 0.80 / 0.49 ms per launch for N = 1 / 2 / 4 / 8; profiles/r05_shares_sync.json)'}
+MODEL = {'headline': {'a_ms': 2.22, 'b_ms': 0.17}, 'c3': {'a_ms': 34.3, 'b_ms': 0.17},
+         'from': 'one-GPU share measurements, DESIGN.md section 6 (round 5, render_kernel_lds4: 2.39 / 1.32 / 0.74 / 0.45 ms per launch for N = 1 / 2 / 4 / 8; profiles/r05_shares_sync.json)'}
 
 PMC_PASSES = [
     ['SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES',
      'SQ_BUSY_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY'],
     ['FETCH_SIZE', 'GRBM_GUI_ACTIVE'],
     ['WRITE_SIZE', 'TCC_HIT_sum', 'TCC_MISS_sum'],
-    # the instruction mix (round 5): add / mul / fma issue at one wave64 instruction per ~2.35 cycles per SIMD, everything else slower
-    ['SQ_INSTS_VALU_ADD_F32', 'SQ_INSTS_VALU_MUL_F32', 'SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_INT32', 'SQ_INSTS_VALU_CVT', 'SQ_INSTS_VALU_TRANS_F32'],
+    # the instruction mix, and how busy the LDS pipe is (round 5)
+    ['SQ_INSTS_VALU_ADD_F32', 'SQ_INSTS_VALU_MUL_F32', 'SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_INT32', 'SQ_INSTS_VALU_CVT', 'SQ_INSTS_VALU_TRANS_F32',
+     'SQ_LDS_IDX_ACTIVE', 'SQ_LDS_BANK_CONFLICT'],
 ]
 
 
