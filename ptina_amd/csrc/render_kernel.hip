@@ -226,8 +226,10 @@ struct LaneState {
     // ray being traversed (closest: the path ray; shadow: hitpos -> light)
     V3 to, td, inv, oinv;
     int offx, offy, offz;      // byte offset of the entry planes of each axis in a node record (LDS and wide kernels)
-    float tbest;               // closest: best depth so far; shadow: li.dis
-    int curr, sp, hidx;        // hidx: leaf slot of the hit so far, -1 = none (closest) / any occluder found (shadow)
+    float tbest;               // closest: best depth so far; shadow: li.dis moved up one float (MPT_LEAF_ONE_TEST); x t_scale while traversed (T_SCALED)
+    int curr, sp, hidx;        // hidx: leaf slot of the hit so far, -1 = none (closest) / any occluder found (shadow); in the 4-wide LDS kernel
+                               // curr / hidx hold ids as its LDS node records do (LdsWideScene::ODD_IDS) and sp is the LDS address of the
+                               // lane's top stack entry (Stack16W::SP_ADDR), everywhere else a level
     float hu, hv;
     int shadow;                // 1: the ray in flight is a shadow ray.  An int in a VGPR on purpose: as a bool the
                                // compiler keeps it in a scalar lane mask and re-merges that mask (s_andn2 / s_and /
@@ -592,7 +594,7 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
         // that is not wanted lands on the slot the next one overwrites -- instead of three divergent regions with a spill test each
         typedef typename STACK::entry_t entry_t;
         int sp = L.sp;
-        if constexpr (STACK::SP_ADDR) {                                               // (sp: the address of the slot, Stack16W)
+        if constexpr (STACK::SP_ADDR) {                                               // (sp: the address of the top entry, Stack16W)
             STACK::st(sp + STACK::SP_BIAS, id3); sp += k3 != MISS ? STACK::SP_STEP : 0;
             STACK::st(sp + STACK::SP_BIAS, id2); sp += k2 != MISS ? STACK::SP_STEP : 0;
             STACK::st(sp + STACK::SP_BIAS, id1); sp += k1 != MISS ? STACK::SP_STEP : 0;
