@@ -683,6 +683,11 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     if (c->nx <= 0) return fail("film size not set: call set_size() first");
     if (!c->sV) return fail("sobol sampler not initialised");
     if (!c->tree_valid) return fail("BVH not built: call build_tree() after load_model()");
+    // the production kernels address a frame's Sobol row and a triangle's shading record by 32-bit offsets from a scalar base, and
+    // multiply frame x dimension in 24 bits (lane_draws, shade_rec_load)
+    if ((long long)nframes * c->sdim >= (1ll << 30) || nframes >= (1 << 24) || c->sdim >= (1 << 24))
+        return fail("%d frames of %d Sobol dimensions in one launch exceed the kernels' 32-bit row offsets", nframes, c->sdim);
+    if (c->nfaces >= (1 << 26)) return fail("%d faces exceed the kernels' 32-bit record offsets", c->nfaces);
     memset(&p, 0, sizeof p);
     p.nx = c->nx; p.ny = c->ny; p.x0 = c->x0; p.x1 = c->x1;
     p.nframes = nframes; p.n = c->nfaces;

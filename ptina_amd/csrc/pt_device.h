@@ -1490,8 +1490,12 @@ DEV void get_geometries(const MptRenderParams &p, const Hit &hit, V3 ro, V3 rd, 
 // round trip to L2 then overlaps the light tests instead of following them), the material comes from the scene
 // (LDS-resident kernel) or from the record's material id
 struct ShadeRec { MptVec4 s0, s1, s2, s3; };
+// OFF32 (the LDS-resident kernels): a 32-bit byte offset from the (scalar) base -- one shift and the instruction's own address add, where
+// base + (size_t)slot * 4 is a 64-bit shift and a 64-bit add per lane (slots are below 2^26: fill_params refuses more faces).  The
+// gather kernels keep the 64-bit form: with the short one their 96-register allocation comes out 5-13 % slower (profiles/r05_ab_experiments.json)
+template <bool OFF32>
 DEV ShadeRec shade_rec_load(const MptRenderParams &p, int slot) {
-    const MptVec4 *s = p.tshade + (size_t)slot * 4;
+    const MptVec4 *s = OFF32 ? (const MptVec4 *)((const char *)p.tshade + ((unsigned)slot << 6)) : p.tshade + (size_t)slot * 4;
     ShadeRec r; r.s0 = s[0]; r.s1 = s[1]; r.s2 = s[2]; r.s3 = s[3];
     return r;
 }

@@ -259,22 +259,26 @@ DEV int reduce_mod_dim(int h, int dim, float inv_dim) {
 // that the reference reduces mod dim (floor-mod) at every draw; unless the counter is about to wrap
 // (probability ~N/2^32 per pixel) the N indices are k, k+1, ... with one wrap at dim: the lane carries k
 // along with the counter, so a draw costs a load and a compare.  The wrapping case takes the literal path.
-template <int N>
+template <int N, bool OFF32 = false>
 DEV void lane_draws(const MptRenderParams &p, LaneState &L, float *out) {
-    const float *P = p.P + (size_t)L.frame * p.sobol_dim;
+    // OFF32 (the LDS-resident kernels): the frame's row as a 32-bit word offset from the scalar base (frames x dim stays below 2^30,
+    // fill_params checks) instead of 64-bit arithmetic per lane; the gather kernels keep the long form (pt_device.h shade_rec_load)
+#define MPT_ROW(k_) (OFF32 ? (const float *)((const char *)p.P + ((__umul24((unsigned)L.frame, (unsigned)p.sobol_dim) + (unsigned)(k_)) << 2)) \
+                           : p.P + (size_t)L.frame * p.sobol_dim + (k_))
+    const float *P = MPT_ROW(0);
     const int dim = p.sobol_dim;
     if (L.rng_i <= 0x7fffffff - N && L.rng_k + N <= dim) {
         // the N numbers are consecutive words (no wrap at dim inside them): two 16-byte gathers (any 4-byte
         // alignment) instead of six -- a gather instruction costs the big scenes the same whatever its width
         struct __attribute__((packed, aligned(4))) W4 { float a, b, c, d; };
         struct __attribute__((packed, aligned(4))) W2 { float a, b; };
-        const float *q = P + L.rng_k;
+        const float *q = MPT_ROW(L.rng_k);
         static_assert(N == 2 || N == 6, "lane_draws: two (jitter) or six (light + BSDF triples) numbers");
         if constexpr (N == 6) {
             const W4 v = *(const W4 *)q;
             int k2 = L.rng_k + 2;
             asm("" : "+v"(k2));                                              // (or the compiler turns it into two 4-byte gathers)
-            const W4 w = *(const W4 *)(P + k2);                              // overlaps the first: no read past the six
+            const W4 w = *(const W4 *)MPT_ROW(k2);                           // overlaps the first: no read past the six
             out[0] = v.a; out[1] = v.b; out[2] = v.c; out[3] = v.d; out[4] = w.c; out[5] = w.d;
         } else {
             const W2 w = *(const W2 *)q;
@@ -304,6 +308,7 @@ DEV void lane_draws(const MptRenderParams &p, LaneState &L, float *out) {
         L.rng_i = rng.i;
         L.rng_k = pymod(L.rng_i, dim);
     }
+#undef MPT_ROW
 }
 
 // One sample's radiance into the launch's slab, path.py:93 (the combine pass or the tail finalisation adds the frames in order).
@@ -704,13 +709,16 @@ DEV int shade_core(const MptRenderParams &p, const SCENE &sc, LaneState &L, Cnt 
     // everything the stage gathers from L2 is asked for first: the shading record of the triangle and the six
     // Sobol numbers of the bounce (path.py:48,58: light triple, then BSDF triple) -- one round trip, under the
     // light tests, instead of three in a row
-    ShadeRec rec = {};
-    float u[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    // (the LDS-resident kernels: no initialisers -- both are read by lanes with a hit only, and "= {}" was 21 v_mov_b32 per stage; the
+    //  gather kernels keep them: without, their register allocation spills 16 bytes more and loses 2 %)
+    ShadeRec rec;
+    float u[6];
+    if constexpr (!SCENE::LDS_MATS) { rec = ShadeRec{}; for (int k = 0; k < 6; k++) u[k] = 0.0f; }
     MPT_SEG_BEGIN
     const int hslot = SCENE::ODD_IDS ? (L.hidx >> 4) : L.hidx;
     if (was_hit) {
-        rec = shade_rec_load(p, hslot);
-        lane_draws<6>(p, L, u);
+        rec = shade_rec_load<SCENE::LDS_MATS>(p, hslot);
+        lane_draws<6, SCENE::LDS_MATS>(p, L, u);
     }
     MPT_SEG(pl_trips)            // (the entry of the stage -- reloads of what the traversal loop had parked -- and the issue of its gathers)
     LightHit lit = lights_hit(p, ro, rd);
