@@ -114,3 +114,14 @@ for src in sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', 'diag_*.json'))):
         continue
     shutil.copy(src, os.path.join(dst, f'{tag}_{key}.json'))
     print('diagnostic ->', f'{tag}_{key}.json')
+
+# tools/run_configs.py's table of every single-GPU configuration (a run restricted to some of them writes configs_subset.json)
+f = os.path.join(ROOT, 'gpurun_out', 'configs.json')
+if os.path.exists(f):
+    try:
+        if len(json.load(open(f))) >= 5:
+            shutil.copy(f, os.path.join(dst, f'{tag}_configs.json'))
+            print('configs ->', f'{tag}_configs.json')
+    except Exception as e:
+        print('configs.json not copied:', e)
+

@@ -74,5 +74,7 @@ for title, name, kw, n, spp, world in CONFIGS:
                   'mrays_s': round(cnt['rays'] / cnt['samples'] * ms, 1),
                   'tree_depth': [c.get_option('tree_depth'), c.get_option('fast_depth'), c.get_option('wide_depth')]}
     print(title, json.dumps(out[title]), flush=True)
-    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', os.environ.get('CONFIGS_OUT', 'configs.json')), 'w'), indent=1)
+    # (a run restricted to some configurations -- the profiler passes name C4 C5 -- does not overwrite the table of all of them)
+    default_out = 'configs.json' if len(sys.argv) <= 1 else 'configs_subset.json'
+    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', os.environ.get('CONFIGS_OUT', default_out)), 'w'), indent=1)
 common.reset_all()
