@@ -252,6 +252,7 @@ DEV bool box_strict(V3 lo, V3 hi, V3 ro, V3 rd, float *near_ = nullptr, float *f
 // dwords (conflict-free); replaces GlobalStack's [thread][level] rows in global memory, stack.py:10-60
 struct Stack {
     static constexpr int SENTINEL = (int)0x80000000;   // bottom-of-stack marker (never a node or leaf id)
+    static constexpr bool ONE_TEST = false;
     static constexpr int PLANE_OFF = 0;                // (the binary gather kernel takes min / max of both planes)
     int *base;                 // &lds[threadIdx.x]
     int sp;
@@ -409,6 +410,7 @@ struct QuantScene {
 // levels live in LDS like Stack's, the (rare) rest in a per-lane strip of global memory
 struct SpillStack {
     static constexpr int SENTINEL = (int)0x80000000;
+    static constexpr bool ONE_TEST = false;
     static constexpr int PLANE_OFF = 0;                // (the 4-wide steps pick the entry planes by the sign of L.inv themselves: no per-ray offsets to carry)
 #ifndef MPT_X_SPILL_CAP
 #define MPT_X_SPILL_CAP 24     // (a test build sets it to a handful of levels so that every ray uses the global strip)
@@ -464,6 +466,7 @@ struct OctScene {
 // [level][lane] each, the (rare) levels beyond CAP in a per-lane strip of global memory like SpillStack's
 struct OctStack {
     static constexpr int SENTINEL = 0x40000000;        // the b word of the bottom entry: traversal over
+    static constexpr bool ONE_TEST = false;
     static constexpr int PLANE_OFF = 0;
     static constexpr bool PEEK = false;
     static constexpr bool SP_ADDR = false, ODD_IDS = false, T_SCALED = false;
@@ -567,8 +570,12 @@ typedef LdsSceneT<MPT_LDS_PRESCALED != 0> LdsSceneP;
 
 // 16-bit LIFO for the LDS-resident kernel (node ids fit in int16 there), [level][lane of 1024]
 #define MPT_LDS_BLOCK 1024
+#ifndef MPT_LEAF_ONE_TEST
+#define MPT_LEAF_ONE_TEST 1        // the LDS-resident kernels ask one depth question in the LEAF step for both kinds of ray
+#endif
 struct Stack16 {
     static constexpr int SENTINEL = -32768;            // leaf ids are ~slot >= -32767 (n < 32768)
+    static constexpr bool ONE_TEST = MPT_LEAF_ONE_TEST != 0;     // (render_kernel.hip lane_start_ray / stage_leaf)
     static constexpr int PLANE_OFF = 8;                // bytes between the {lo, lo} and {hi, hi} pairs of an axis in LDS
     LdsShortPtr base;          // &lds16[threadIdx.x]
     int sp;
@@ -637,6 +644,7 @@ struct LdsWideScene {
 #endif
 struct Stack16W {
     static constexpr bool ODD_IDS = MPT_LDS4_IDS != 0;
+    static constexpr bool ONE_TEST = MPT_LEAF_ONE_TEST != 0;     // (render_kernel.hip lane_start_ray / stage_leaf)
     static constexpr int SENTINEL = ODD_IDS ? 2 : -32768;           // (ODD_IDS: the two low bits of an entry are the lane's next state --
                                                                     //  0 a node, ST_NODE; 1 a leaf, ST_LEAF; 2 only this, ST_DONE)
     static constexpr int PLANE_OFF = MPT_LDS4_PLANE_OFF;
@@ -682,6 +690,7 @@ struct Stack16W {
 // the same LIFO for the tracer waves of the pooled kernel: [level][tracer lane], the lane count a launch parameter
 struct Stack16V {
     static constexpr int SENTINEL = -32768;
+    static constexpr bool ONE_TEST = MPT_LEAF_ONE_TEST != 0;     // (render_kernel.hip lane_start_ray / stage_leaf)
     static constexpr int PLANE_OFF = 8;
     LdsShortPtr base;          // &lds16[tracer lane]
     int stride;                // tracer lanes of the workgroup (wave-uniform)

@@ -39,9 +39,6 @@
 #ifndef MPT_SPEC_POP4
 #define MPT_SPEC_POP4 1       // ... and so does the 4-wide step of the LDS-resident kernel
 #endif
-#ifndef MPT_LEAF_ONE_TEST
-#define MPT_LEAF_ONE_TEST 1   // one depth test in the LEAF step for both kinds of ray (lane_start_ray)
-#endif
 #ifndef MPT_ONE_START
 #define MPT_ONE_START 1       // one ray-start block per shading pass (0: each stage starts its own lanes' rays, as before)
 #endif
@@ -226,7 +223,7 @@ struct LaneState {
     // ray being traversed (closest: the path ray; shadow: hitpos -> light)
     V3 to, td, inv, oinv;
     int offx, offy, offz;      // byte offset of the entry planes of each axis in a node record (LDS and wide kernels)
-    float tbest;               // closest: best depth so far; shadow: li.dis moved up one float (MPT_LEAF_ONE_TEST); x t_scale while traversed (T_SCALED)
+    float tbest;               // closest: best depth so far; shadow: li.dis, moved up one float where STACK::ONE_TEST; x t_scale while traversed (T_SCALED)
     int curr, sp, hidx;        // hidx: leaf slot of the hit so far, -1 = none (closest) / any occluder found (shadow); in the 4-wide LDS kernel
                                // curr / hidx hold ids as its LDS node records do (LdsWideScene::ODD_IDS) and sp is the LDS address of the
                                // lane's top stack entry (Stack16W::SP_ADDR), everywhere else a level
@@ -359,11 +356,12 @@ DEV void lane_start_ray(LaneState &L, STACK &stk, V3 o, V3 d, float tmax, bool s
         L.offy = __float_as_int(L.inv.y) < 0 ? STACK::PLANE_OFF : 0;
         L.offz = __float_as_int(L.inv.z) < 0 ? STACK::PLANE_OFF : 0;
     }
-#if MPT_LEAF_ONE_TEST
     // a shadow ray takes any occluder with depth <= li.dis (path.py:51), a closest-hit ray a strictly nearer hit (lbvh.py:331): with
-    // the shadow ray's bound moved up to the next float the LEAF step asks both the same question, depth < tbest
-    if (shadow) { const int b = __float_as_int(tmax); tmax = __int_as_float(b + (b < 0x7f800000 ? 1 : 0)); }
-#endif
+    // the shadow ray's bound moved up to the next float the LEAF step asks both the same question, depth < tbest (STACK::ONE_TEST: the
+    // LDS-resident kernels, -0.5 %; the gather kernels lose 1-2 % with it and keep the two tests)
+    if constexpr (STACK::ONE_TEST) {
+        if (shadow) { const int b = __float_as_int(tmax); tmax = __int_as_float(b + (b < 0x7f800000 ? 1 : 0)); }
+    }
     L.tbest = tmax; L.shadow = shadow ? 1 : 0; L.hidx = -1; L.hu = 0.0f; L.hv = 0.0f;
     stk.sp = 0;
     stk.push(STACK::SENTINEL);
@@ -648,20 +646,18 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     bool hit = tri_test_fast(g0, g1, g2, L.to, L.td, &dd, &su, &sv);
     if constexpr (STACK::T_SCALED) dd *= stk.ts;                            // (L.tbest is held scaled while the ray is traversed)
     if constexpr (SCENE::AVOID_IN_LEAF) hit = hit && L.curr != L.navoid;    // the triangle the ray left from (lbvh.py:329): the NODE step let it through
-#if MPT_LEAF_ONE_TEST
-    if (hit && dd < L.tbest) {                                              // lbvh.py:331; path.py:51 (lane_start_ray)
-        L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv;
-        stop = L.shadow != 0;
-    }
-#else
-    if (hit) {
+    if constexpr (STACK::ONE_TEST) {
+        if (hit && dd < L.tbest) {                                          // lbvh.py:331; path.py:51 (lane_start_ray)
+            L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv;
+            stop = L.shadow != 0;
+        }
+    } else if (hit) {
         if (L.shadow) {
             if (dd <= L.tbest) { L.hidx = slot; stop = true; }              // path.py:51: any occluder within li.dis
         } else if (dd < L.tbest) {                                          // lbvh.py:331
             L.tbest = dd; L.hidx = slot; L.hu = su; L.hv = sv;
         }
     }
-#endif
     int next;
 #if MPT_SPEC_POP
     if constexpr (STACK::PEEK) { next = spec; L.sp = L.sp - (STACK::SP_ADDR ? STACK::SP_STEP : 1); } else
