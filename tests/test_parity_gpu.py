@@ -1974,6 +1974,53 @@ def test_headline_film_is_the_same_over_4wide_and_binary_nodes(fresh):
     assert_parity(films[1][1], films[0][1], *FAST, what='headline film: 4-wide vs binary nodes in LDS')
 
 
+@pytest.mark.gpu
+def test_scaled_ray_distances_do_not_show(fresh):
+    '''render_kernel_lds4 holds 1/d, o/d and tbest multiplied by a power of two while a ray is traversed (MptRenderParams::t_scale,
+    from the scene's bounding sphere and the camera's near plane: DESIGN 3.1 step 33) so that an FMA's clamp bit stands for
+    max(t, 0).  The scale must not show: a camera 2 000 units away behind a 0.2 degree lens, a camera inside the box, and the
+    scene shrunk / blown up by 1 024 (a power of two: the same bits up to the exponent) give the film of the LDS-resident
+    kernel over the binary nodes, which keeps distances unscaled -- bit for bit up to a tie or two'''
+    from helpers import assert_parity
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd.tools.matrix import perspective, lookat, translate
+    base = scenes.scene_s978()
+
+    def scaled(k):
+        v = base[0].copy()
+        v[..., :3] *= k                                                      # positions; normals and texcoords stay
+        return (v,) + tuple(base[1:])
+    far_dir = np.array([0.25, 0.2, 1.0]); far_dir /= np.linalg.norm(far_dir)
+    target = np.array([0.0, 1.6, 0.0])
+    cases = {
+        'far tele': (base, perspective(fov=0.2, aspect=1, near=1.0, far=5000) @
+                     lookat(pos=tuple(target), back=tuple(target + 2000.0 * far_dir)), None),
+        'inside': (base, perspective(fov=80, aspect=1, near=0.05, far=50) @ lookat(pos=(-2.0, 2.0, 0.0), back=(2.9, 0.3, 1.0)), None),
+        'scene / 1024': (scaled(1.0 / 1024), None, 1.0 / 1024),
+        'scene x 1024': (scaled(1024.0), None, 1024.0),
+    }
+    for what, (scene, cam, k) in cases.items():
+        if cam is None:                                                       # the benchmark view, moved with the scene
+            from ptina_amd.tools.matrix import scale as _scale_matrix
+            cam = scenes.BENCH_CAMERA @ _scale_matrix(1.0 / k)
+        films = {}
+        for lds_wide in (1, 0):
+            reset_all()
+            # (the default light -- POINT at (1, 2, 3), radius 0.5, colour 32 -- moved and dimmed with the scene: the same irradiance)
+            lights = None if k is None else [(translate([1.0 * k, 2.0 * k, 3.0 * k]), np.array([32.0, 32.0, 32.0]) * k * k, 0.5 * k, 'POINT')]
+            eng = _engine(None, scene, 96, 96, mode='fast', camera=cam, lights=lights)
+            ctx().set_option('lds_wide', lds_wide)
+            eng.render(8)
+            films[lds_wide] = (FilmTable().get_raw().copy(), FilmTable().get_image().copy())
+            assert ctx().get_option('last_kernel') == (5 if lds_wide else 1), what
+        same = (films[1][0].view(np.uint32) == films[0][0].view(np.uint32)).all(axis=-1).mean()
+        assert np.isfinite(films[1][1]).all() and films[1][1][..., :3].max() > 0.01, what
+        assert same >= 0.999, (what, same)
+        assert_parity(films[1][1], films[0][1], *FAST, what='scaled ray distances: ' + what)
+    reset_all()
+
+
 def test_kernel_ladder_by_scene_size(fresh):
     '''which kernel serves a scene is decided by what fits a CU's 160 KiB of LDS beside the stacks (miptina.cpp): the 4-wide
     nodes with exact boxes (112 B a node, about half a node per triangle) and the triangles, else the 4-wide 8-bit nodes gathered
