@@ -817,9 +817,8 @@ extern "C" int mpt_flush(mpt_ctx *c) {
     const size_t lds4_bytes = ((size_t)c->wide_nodes * (MPT_LDS4_NODE_STRIDE / 16) + ((size_t)c->nfaces + 1) * 3 + (size_t)(lds4_nmats + 1) * 6) * sizeof(MptVec4) +
                               (((size_t)c->nfaces + 15) & ~(size_t)15) + (size_t)c->wide_stack * 1024 * sizeof(short);
     const bool lds4_kernel = fast && c->use_lds && c->lds_wide && c->use_wide && !c->use_pool && c->wide_nodes > 0 && c->wide_stack > 0 && c->wnode &&
-                             c->nfaces >= 2 && c->nfaces < (MPT_LDS4_IDS ? 4095 : 32767) && lds4_nmats < 255 && lds4_bytes <= 160 * 1024 &&
-                             (MPT_LDS4_IDS ? (size_t)c->wide_nodes * MPT_LDS4_NODE_STRIDE < 65536     // (16-bit ids: mpt_types.h MPT_LDS4_IDS)
-                                           : (size_t)c->wide_nodes * (MPT_LDS4_NODE_STRIDE / 8) < 32768);
+                             c->nfaces >= 2 && c->nfaces < 4095 && lds4_nmats < 255 && lds4_bytes <= 160 * 1024 &&
+                             (size_t)c->wide_nodes * MPT_LDS4_NODE_STRIDE < 65536;   // (16-bit ids: a node's is its record's LDS address, a leaf's 16 * slot + 1)
     const bool lds_kernel = lds4_kernel ||
                             (fast && c->use_lds && c->nfaces >= 2 && c->nfaces < 32768 && c->caps.max_materials < 256 &&
                              lds_bytes <= 160 * 1024 &&

@@ -96,12 +96,6 @@ struct MptImage { int32_t nx, ny, base, pad; };   // image.py:14-16
 #ifndef MPT_LDS_NODE_STRIDE
 #define MPT_LDS_NODE_STRIDE 72
 #endif
-#ifndef MPT_LDS4_IDS
-#define MPT_LDS4_IDS 1               // ids in the LDS copy of the 4-wide nodes (pt_device.h LdsWideScene::ODD_IDS): 1: a node's is its record's byte offset, a
-#endif                               // leaf's (slot << 4) | 1, 16 bits unsigned; 0: byte offset / 8 and ~slot, 16 bits signed
-#ifndef MPT_T_SCALED
-#define MPT_T_SCALED 1               // render_kernel_lds4: ray distances scaled by MptRenderParams::t_scale during traversal
-#endif
 #ifndef MPT_LDS4_NODE_STRIDE
 #define MPT_LDS4_NODE_STRIDE 112     // bytes between the 4-wide node records in LDS (render_kernel_lds4: seven float4 of a wnode record)
 #endif
@@ -160,7 +154,7 @@ struct MptRenderParams {
     uint32_t slab_tag;                       // MPT_TAG_COMBINE, or MPT_TAG_FIRST + launch number mod MPT_TAG_PERIOD
     // render_kernel_lds4 measures distances along a ray in units of 1 / t_scale (a power of two, so every comparison comes out as it
     // would unscaled): no box of the scene is entered farther than 1 / t_scale from any ray origin, which lets the clamp bit of an
-    // FMA stand for max(t, 0) (pt_device.h MPT_T_SCALED).  t_unscale = 1 / t_scale
+    // FMA stand for max(t, 0) (pt_device.h Stack16W::T_SCALED).  t_unscale = 1 / t_scale
     float t_scale, t_unscale;
     int32_t pad3;
     unsigned long long *timeline;            // diagnostics: per wave {start, scene ready, queue empty, exit} in

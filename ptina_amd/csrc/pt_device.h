@@ -570,12 +570,9 @@ typedef LdsSceneT<MPT_LDS_PRESCALED != 0> LdsSceneP;
 
 // 16-bit LIFO for the LDS-resident kernel (node ids fit in int16 there), [level][lane of 1024]
 #define MPT_LDS_BLOCK 1024
-#ifndef MPT_LEAF_ONE_TEST
-#define MPT_LEAF_ONE_TEST 1        // the LDS-resident kernels ask one depth question in the LEAF step for both kinds of ray
-#endif
 struct Stack16 {
     static constexpr int SENTINEL = -32768;            // leaf ids are ~slot >= -32767 (n < 32768)
-    static constexpr bool ONE_TEST = MPT_LEAF_ONE_TEST != 0;     // (render_kernel.hip lane_start_ray / stage_leaf)
+    static constexpr bool ONE_TEST = true;             // one depth question in the LEAF step for both kinds of ray (render_kernel.hip lane_start_ray / stage_leaf)
     static constexpr int PLANE_OFF = 8;                // bytes between the {lo, lo} and {hi, hi} pairs of an axis in LDS
     LdsShortPtr base;          // &lds16[threadIdx.x]
     int sp;
@@ -606,8 +603,8 @@ struct LdsWideScene {
     // ids as the LDS copy of the node records holds them (render_kernel_lds4 rewrites them while it copies): a node's is its record's
     // byte offset in LDS -- the address itself, no shift -- and a leaf's (slot << 4) | 1; records are 16-byte aligned, so bit 0 tells
     // them apart with a full-rate v_and where the sign needed a shift or a sign extension (half rate on gfx950)
-    static constexpr bool ODD_IDS = MPT_LDS4_IDS != 0;
-    static constexpr bool T_SCALED = MPT_T_SCALED != 0;     // (Stack16W::ts)
+    static constexpr bool ODD_IDS = true;
+    static constexpr bool T_SCALED = true;                  // (Stack16W::ts)
     LdsVec4Ptr wnode, tgeo, mats;
     LdsU8Ptr mtl;
     int mat_last, mat_default;
@@ -633,20 +630,14 @@ struct LdsWideScene {
 
 // its LIFO: 16-bit entries, [level][lane of 1024], as many levels as the tree can ask for (3 x depth + 2, the host checks): a
 // step's three pushes are plain stores, nothing spills
-#ifndef MPT_SP_ADDR
-#define MPT_SP_ADDR 1              // LaneState::sp of the 4-wide LDS kernel is the LDS address of the next free slot (0: the level, as everywhere else)
-#endif
-#ifndef MPT_SP_TOP
-#define MPT_SP_TOP 1
-#endif
 #ifndef MPT_LDS4_PLANE_OFF
 #define MPT_LDS4_PLANE_OFF 0       // 16: the ray carries the offsets of its entry planes (three registers); 0: the step reads the signs off 1/d
 #endif
 struct Stack16W {
-    static constexpr bool ODD_IDS = MPT_LDS4_IDS != 0;
-    static constexpr bool ONE_TEST = MPT_LEAF_ONE_TEST != 0;     // (render_kernel.hip lane_start_ray / stage_leaf)
-    static constexpr int SENTINEL = ODD_IDS ? 2 : -32768;           // (ODD_IDS: the two low bits of an entry are the lane's next state --
-                                                                    //  0 a node, ST_NODE; 1 a leaf, ST_LEAF; 2 only this, ST_DONE)
+    static constexpr bool ODD_IDS = true;              // entries are ids as LdsWideScene holds them (16 bits, unsigned)
+    static constexpr bool ONE_TEST = true;             // (render_kernel.hip lane_start_ray / stage_leaf)
+    static constexpr int SENTINEL = 2;                 // the two low bits of an entry are the lane's next state: 0 a node (ST_NODE), 1 a leaf
+                                                       // (ST_LEAF), 2 -- only this -- the bottom of the stack (ST_DONE)
     static constexpr int PLANE_OFF = MPT_LDS4_PLANE_OFF;
     static constexpr int CAP = 1 << 20, STRIDE = MPT_LDS_BLOCK;
     static constexpr bool NO_SPILL = true;
@@ -658,39 +649,27 @@ struct Stack16W {
     // (so is every comparison between them), and the entry side's max(t, 0) becomes the clamp bit of one of its FMAs -- four
     // half-rate v_max_f32 less per step.  (A t beyond 1 / ts -- a plane nearly parallel to the ray -- clamps to 1: the box test
     // can only pass where it failed, never fail where it passed.)
-    static constexpr bool T_SCALED = MPT_T_SCALED != 0;
+    static constexpr bool T_SCALED = true;
     float ts;
-    DEV void push(int v) { base[sp * MPT_LDS_BLOCK] = (short)v; sp++; }
+    DEV void push(int v) { base[sp * MPT_LDS_BLOCK] = (short)v; sp++; }        // (by level: the sentinel at a ray's start)
     DEV int pop() { sp--; return (int)base[sp * MPT_LDS_BLOCK]; }
     static constexpr bool PEEK = true;                 // (the LEAF step reads the entry it will pop together with its triangle)
     DEV int peek(int at) const { return (int)base[at * MPT_LDS_BLOCK]; }
-    static constexpr bool SP_ADDR = MPT_SP_ADDR != 0;
-#if MPT_SP_ADDR
-    // The lane's stack pointer as the LDS byte ADDRESS of its next free slot (LaneState::sp in the 4-wide LDS kernel): a push or pop
-    // is a ds access at that register and a full-rate add of SP_STEP -- level * 2048 + base is a v_lshl_add_u32 per access, and
-    // shifts issue at half the rate of adds on gfx950 (tools/microbench/exec_microbench)
-    static constexpr int SP_STEP = MPT_LDS_BLOCK * 2;
+    // SP_ADDR: LaneState::sp is the LDS byte ADDRESS of the lane's TOP entry, not a level: the entry a step may pop is read at the
+    // register itself, a push goes to the register + SP_STEP -- the instruction's offset field -- and moving it is a full-rate add of
+    // SP_STEP, where level * 2048 + base was a v_lshl_add_u32 per access (shifts and three-operand integer forms issue at half the
+    // rate of adds on gfx950: tools/microbench/exec_microbench)
+    static constexpr bool SP_ADDR = true;
+    static constexpr int SP_STEP = MPT_LDS_BLOCK * 2, SP_BIAS = SP_STEP;       // st / ld address the slot at (sp + SP_BIAS - SP_STEP * k)
     DEV int sp_at(int level) const { return (int)(unsigned)(unsigned long long)(base + level * MPT_LDS_BLOCK); }
     DEV static void st(int sp, int v) { *(LdsShortPtr)(unsigned long long)(unsigned)sp = (short)v; }
-    DEV static int ld(int sp) {
-        if constexpr (ODD_IDS) return (int)*(LdsUShortPtr)(unsigned long long)(unsigned)sp;
-        else return (int)*(LdsShortPtr)(unsigned long long)(unsigned)sp;
-    }
-    // ... the address of the TOP entry, in fact (MPT_SP_TOP): the entry a step may pop is then read at the register itself, and a push
-    // goes to the register + SP_STEP -- the instruction's offset field -- where the next free slot asked for an add in front of every peek
-    static constexpr int SP_BIAS = MPT_SP_TOP ? SP_STEP : 0;
-#else
-    static constexpr int SP_STEP = 1, SP_BIAS = 0;
-    DEV int sp_at(int level) const { return level; }
-    DEV void st(int sp, int v) const { base[sp * MPT_LDS_BLOCK] = (short)v; }
-    DEV int ld(int sp) const { return ODD_IDS ? (int)(unsigned short)base[sp * MPT_LDS_BLOCK] : (int)base[sp * MPT_LDS_BLOCK]; }
-#endif
+    DEV static int ld(int sp) { return (int)*(LdsUShortPtr)(unsigned long long)(unsigned)sp; }
 };
 
 // the same LIFO for the tracer waves of the pooled kernel: [level][tracer lane], the lane count a launch parameter
 struct Stack16V {
     static constexpr int SENTINEL = -32768;
-    static constexpr bool ONE_TEST = MPT_LEAF_ONE_TEST != 0;     // (render_kernel.hip lane_start_ray / stage_leaf)
+    static constexpr bool ONE_TEST = true;             // one depth question in the LEAF step for both kinds of ray (render_kernel.hip lane_start_ray / stage_leaf)
     static constexpr int PLANE_OFF = 8;
     LdsShortPtr base;          // &lds16[tracer lane]
     int stride;                // tracer lanes of the workgroup (wave-uniform)

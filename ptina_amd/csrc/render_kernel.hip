@@ -36,9 +36,6 @@
 #define MPT_SPEC_POP 1        // the stack entry a step may pop is read together with the step's node / triangle record
 #endif
 
-#ifndef MPT_SPEC_POP4
-#define MPT_SPEC_POP4 1       // ... and so does the 4-wide step of the LDS-resident kernel
-#endif
 #ifndef MPT_ONE_START
 #define MPT_ONE_START 1       // one ray-start block per shading pass (0: each stage starts its own lanes' rays, as before)
 #endif
@@ -482,22 +479,13 @@ DEV void stage_node(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
 // input that is not a signalling NaN, and nothing in the kernel makes one.  MI355X, same box, alternated three times
 // (profiles/r05_ab_experiments.json): 2.593 / 2.566 / 2.554 ms per launch -> 2.560 / 2.537 / 2.526.  (The 8-bit step of the
 // gather kernels, which wait for their gathers as much as for the issue port, did not move with it: C4 1547 / 1543 against 1546 / 1549.)
-#ifndef MPT_ASM_MIN
-#define MPT_ASM_MIN 1
-#endif
 DEV float exit_min_asm(float a, float b, float c, float tbest) {
     float m, r;
     asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(c), "v"(tbest));
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
     return r;
 }
-DEV float exit_min(float a, float b, float c, float tbest) {
-#if MPT_ASM_MIN
-    return exit_min_asm(a, b, c, tbest);
-#else
-    return fminf(fminf(a, b), fminf(c, tbest));
-#endif
-}
+DEV float exit_min(float a, float b, float c, float tbest) { return exit_min_asm(a, b, c, tbest); }
 
 // The same step through a 4-wide node: four slab tests (planes picked by the ray's direction signs) on one 128-B
 // record, the children that are hit sorted
@@ -512,12 +500,10 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     float t0, t1, t2, t3;
     bool h0, h1, h2, h3;
     if (COUNT) { cnt.n_node++; cnt.n_box += 4; }
-#if MPT_SPEC_POP4
     // the entry a step without a hit pops is asked for together with the node record: some lane of the wave pops in nearly every
-    // step, and the wave then waited a second LDS round trip behind the sort (pushes go to level sp and above, never to sp - 1)
+    // step, and the wave then waited a second LDS round trip behind the sort (pushes go above the top entry, never onto it)
     int spec = 0;
     if constexpr (STACK::SP_ADDR) spec = STACK::ld(L.sp - STACK::SP_STEP + STACK::SP_BIAS);
-#endif
     if constexpr (SCENE::QUANT) {
         MptVec4 ra, rb, rc, idv;
         sc.node4q(L.curr, ra, rb, rc, idv);
@@ -601,11 +587,7 @@ DEV void stage_node4(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
             STACK::st(sp + STACK::SP_BIAS, id3); sp += k3 != MISS ? STACK::SP_STEP : 0;
             STACK::st(sp + STACK::SP_BIAS, id2); sp += k2 != MISS ? STACK::SP_STEP : 0;
             STACK::st(sp + STACK::SP_BIAS, id1); sp += k1 != MISS ? STACK::SP_STEP : 0;
-#if MPT_SPEC_POP4
             if (k0 == MISS) { sp -= STACK::SP_STEP; next = spec; }
-#else
-            if (k0 == MISS) { sp -= STACK::SP_STEP; next = STACK::ld(sp + STACK::SP_BIAS); }
-#endif
         } else {
             stk.base[sp * STACK::STRIDE] = (entry_t)id3; sp += k3 != MISS ? 1 : 0;
             stk.base[sp * STACK::STRIDE] = (entry_t)id2; sp += k2 != MISS ? 1 : 0;
@@ -828,18 +810,11 @@ DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(by
 #define MPT_STAMP_END(acc)
 #endif
 DEV int wave_count(bool pred) { return (int)__builtin_popcountll(__ballot(pred)); }
-#ifndef MPT_BCNT64
-#define MPT_BCNT64 1
-#endif
 DEV int wave_count32(bool pred) {            // a count that stays on the scalar unit when compared
     unsigned long long m = __ballot(pred);
-#if MPT_BCNT64
     int n;                                   // one s_bcnt1_i32_b64, written out: the compiler's own 64-bit popcount ends up compared on the VALU, and
     asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");     // two 32-bit ones are three scalar instructions in the chain in front of every step
-    return n;                                // (MI355X: 2.462 / 2.464 / 2.463 ms per launch -> 2.449 / 2.453 / 2.460)
-#else
-    return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
-#endif
+    return n;                                // (MI355X: 2.462 / 2.464 / 2.463 ms per launch -> 2.449 / 2.453 / 2.460; the gather kernels +0.8 %)
 }
 
 // (SCENE::OCT is only ever true in the A/B build with the 8-wide kernel: render_oct.h)
