@@ -125,3 +125,8 @@ if os.path.exists(f):
     except Exception as e:
         print('configs.json not copied:', e)
 
+# (VERDICT r04 asked for the share measurements under this name)
+f = os.path.join(dst, f'{tag}_shares_sync.json')
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(dst, f'{tag}_shares.json'))
+
