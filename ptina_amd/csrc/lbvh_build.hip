@@ -30,18 +30,19 @@ __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i
 
 __device__ __forceinline__ const float *vpos(const float *verts, int f, int k) { return verts + ((size_t)f * 3 + k) * 8; }
 
-// lbvh.py:161-165,173-177: centre = (v0 + v1 + v2) / 3; bmin/bmax over centres
+// lbvh.py:161-165,173-177: centre = (v0 + v1 + v2) / 3; bmin/bmax over centres.  At most 1024 workgroups stride over the
+// triangles: six same-line atomics per WAVE of a million triangles took 1.07 ms of the build (profiles/r06_build_kernel_stats_c5_before.csv)
 __global__ __launch_bounds__(LB_BLOCK) void centroid_bounds_kernel(const float *__restrict__ verts, int n,
                                                                    float *__restrict__ cen, int *__restrict__ bounds) {
-    int f = blockIdx.x * LB_BLOCK + threadIdx.x;
-    float c[3] = { 0.f, 0.f, 0.f };
+    __shared__ int red[LB_BLOCK / 64][6];
     int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { (int)0x80000000, (int)0x80000000, (int)0x80000000 };
-    if (f < n) {
+    for (int f = blockIdx.x * LB_BLOCK + threadIdx.x; f < n; f += gridDim.x * LB_BLOCK) {
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            c[a] = ((vpos(verts, f, 0)[a] + vpos(verts, f, 1)[a]) + vpos(verts, f, 2)[a]) / 3.0f;
-            cen[(size_t)f * 3 + a] = c[a];
-            lo[a] = hi[a] = f2ord(c[a]);
+            const float c = ((vpos(verts, f, 0)[a] + vpos(verts, f, 1)[a]) + vpos(verts, f, 2)[a]) / 3.0f;
+            cen[(size_t)f * 3 + a] = c;
+            const int o = f2ord(c);
+            lo[a] = min(lo[a], o); hi[a] = max(hi[a], o);
         }
     }
 #pragma unroll
@@ -51,10 +52,13 @@ __global__ __launch_bounds__(LB_BLOCK) void centroid_bounds_kernel(const float *
             lo[a] = min(lo[a], __shfl_xor(lo[a], off));
             hi[a] = max(hi[a], __shfl_xor(hi[a], off));
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(bounds + a, lo[a]);
-            atomicMax(bounds + 3 + a, hi[a]);
-        }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][a] = lo[a]; red[threadIdx.x >> 6][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int v = red[0][threadIdx.x];
+        for (int w = 1; w < LB_BLOCK / 64; w++) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(bounds + threadIdx.x, v); else atomicMax(bounds + threadIdx.x, v);
     }
 }
 
@@ -144,27 +148,32 @@ __device__ __forceinline__ void leaf_box(const float *verts, int f, float *lo, f
 // Bottom-up fit.  Boxes and flags cross workgroups inside one launch, so every word that is handed
 // over is written and read with agent-scope atomics and ordered by agent-scope fences around the
 // arrival counter (a CU's L1 is never refreshed by another CU's plain stores).
+// The arrival word of a node also carries the height of the subtree that arrived first (height << 2 | 1): the second arrival
+// knows both children's heights, and the lane that finishes the root knows the tree's depth.  (Rounds 1-5 sent every FIRST
+// arrival on up to the root just to count levels -- a chain of ~24 dependent loads per leaf, 3.4 of the build's 39 ms at a
+// million triangles.)
 __global__ __launch_bounds__(LB_BLOCK) void fit_boxes_kernel(const float *__restrict__ verts, const int *__restrict__ leaf,
                                                              const int *__restrict__ child, const int *__restrict__ parent,
                                                              int n, float *bmin, float *bmax, unsigned *arrive,
                                                              int *__restrict__ depth_out) {
     int slot = blockIdx.x * LB_BLOCK + threadIdx.x;
     if (slot >= n) return;
-    int node = slot, levels = 0;
+    int node = slot;
+    unsigned height = 0;                 // internal nodes on the longest way down from `node`
     for (;;) {
         int p = parent[node];
-        if (p < 0) break;
-        levels++;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        unsigned prev = __hip_atomic_fetch_add(arrive + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == 0) {
-            // first child to arrive: the sibling will finish this node.  Still count the remaining
-            // levels for the depth (walk up without touching boxes).
-            int q = p;
-            while ((q = parent[q + n]) >= 0) levels++;
-            break;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (p < 0) { atomicMax(depth_out, (int)height); break; }      // `node` is the root: the tree's depth
+        // Every word that crosses between lanes here (boxes, arrival words) is written and read with agent-scope ATOMIC
+        // accesses, which go to the memory side (sc1) and never sit in a CU's L1 or an XCD's L2.  What the hand-over needs on
+        // top is order: this lane's box stores complete before its arrival is counted (s_waitcnt vmcnt(0)), and the loads of
+        // the sibling's box are issued after the arrival word came back (they depend on it).  An agent-scope release / acquire
+        // FENCE pair gives that too, but on a part with eight L2s it also writes back and invalidates the whole L2 each time,
+        // for plain stores this kernel does not have: 3.4 ms at a million triangles against 0.3 (profiles/r06_build_*).
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned prev = __hip_atomic_fetch_add(arrive + p, (height << 2) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 0) break;            // first child to arrive: the sibling will finish this node
+        __asm__ volatile("" ::: "memory");
+        height = max(height, prev >> 2) + 1;
         float lo[3], hi[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) { lo[a] = 1e30f; hi[a] = -1e30f; }
@@ -190,11 +199,6 @@ __global__ __launch_bounds__(LB_BLOCK) void fit_boxes_kernel(const float *__rest
         }
         node = p + n;
     }
-    // levels = number of internal nodes on the path from this leaf to the root
-    int m = levels;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(depth_out, m);
 }
 
 __device__ __forceinline__ float asf(int v) { return __int_as_float(v); }
@@ -275,7 +279,7 @@ MPT_KERNEL_API hipError_t mpt_lbvh_build(const MptLbvhBuffers *b, hipStream_t st
     hipError_t e;
     static const int init_bounds[6] = { 0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000 };
     if ((e = hipMemcpyAsync(b->bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(centroid_bounds_kernel, dim3(gl), dim3(LB_BLOCK), 0, stream, b->verts, n, b->cen, b->bounds);
+    hipLaunchKernelGGL(centroid_bounds_kernel, dim3(std::min(gl, 1024)), dim3(LB_BLOCK), 0, stream, b->verts, n, b->cen, b->bounds);
     hipLaunchKernelGGL(morton_keys_kernel, dim3(gl), dim3(LB_BLOCK), 0, stream, b->cen, b->bounds, n, b->keys_in);
     size_t tmp = b->sort_tmp_bytes;
     if ((e = rocprim::radix_sort_keys(b->sort_tmp, tmp, b->keys_in, b->keys_out, (size_t)n, 0, 62, stream)) != hipSuccess) return e;

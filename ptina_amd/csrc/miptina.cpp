@@ -315,7 +315,9 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         if (value < 0) return fail("launch_seq must be >= 0");
         if (mpt_flush(c)) return 1;
         c->launch_seq = (unsigned)value;
-        c->tag_epoch = c->launch_seq / (unsigned)MPT_TAG_PERIOD;
+        // the slabs may hold entries with any tag of the old numbering: an epoch no launch number maps to makes the next
+        // finalising launch zero them all (round-5 ADVICE: a jump inside an epoch, or to one whose tags overlap, met stale entries)
+        c->tag_epoch = 0xffffffffu;
     } else if (k == "pool") {
 #if !MPT_WITH_POOL
         if (value) return fail("this library is built without the pooled LDS kernel (an A/B build: make -C ptina_amd/csrc pool)");
@@ -363,6 +365,8 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         if ((value ? 1 : 0) != c->gpu_build) { c->gpu_build = value ? 1 : 0; c->tree_valid = false; }
     } else if (k == "sah_inject_fail") {
         c->sah_inject_fail = value != 0; c->tree_valid = false;
+    } else if (k == "build_phases") {
+        c->build_phases = value ? 1 : 0;
     } else if (k == "sah_max") {
         c->sah_max = value; c->tree_valid = false;
     } else {
@@ -411,6 +415,8 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "wide_build") *value = c->wide_build;
     else if (k == "sah_build") *value = c->sah_build;
     else if (k == "sah_fallback") *value = c->sah_fallback;
+    else if (k == "build_phases") *value = c->build_phases;
+    else if (k.rfind("build_phase_us_", 0) == 0 && k.size() == 16 && k[15] >= '0' && k[15] <= '5') *value = (int)(c->build_phase_us[k[15] - '0'] + 0.5);
     else if (k == "wide_nodes") *value = c->wide_nodes;
     else if (k == "wide_stack") *value = c->wide_stack;
     else if (k == "wide_ratio_permille") *value = (int)(c->wide_ratio * 1000.f + 0.5f);
@@ -999,13 +1005,16 @@ extern "C" int mpt_flush(mpt_ctx *c) {
         // the 16-bit tag both halves of every sample entry of this launch carry (film_ops.h): never 0 (fresh memory) or 1 (a launch
         // that keeps the combine pass).  When the tags come round again no entry of any slab may still carry an old one: every slab
         // is zeroed -- behind whatever still reads one (the ring is idle here, so only a combine pass of an earlier batch on the main
-        // stream can be pending: round-4 ADVICE), and in front of this launch (same stream)
+        // stream can be pending: round-4 ADVICE), and in front of this launch AND of every later one: the next pipelined launch runs
+        // on another stream and writes another slab, which nothing would order behind that slab's memset, so the host waits for the
+        // memsets here (round-5 ADVICE; a wrap comes once in 65 534 launches)
         const unsigned phase = c->launch_seq % (unsigned)MPT_TAG_PERIOD, epoch = c->launch_seq / (unsigned)MPT_TAG_PERIOD;
         if (epoch != c->tag_epoch) {             // (told by the epoch, not by phase == 0: the launch with that number may have kept the combine pass)
             c->tag_epoch = epoch;
             HIP_TRY(hipStreamSynchronize(c->stream));
             for (int q = 0; q < MPT_MAX_PIPE; q++)
                 if (c->partial2[q]) HIP_TRY(hipMemsetAsync(c->partial2[q], 0, c->partial2_cap[q] * sizeof(MptVec4), rs));
+            HIP_TRY(hipStreamSynchronize(rs));
             c->tag_wraps++;
         }
         p.fin_counter = c->d_work2[k] + 8 * MPT_QUEUE_STRIDE;

@@ -57,9 +57,12 @@ struct MptLbvhBuffers {
     MptVec4 *snode, *fnode, *tgeo, *tshade;
 };
 MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n);
-MPT_KERNEL_API size_t mpt_sah_seg_words(int n);
-MPT_KERNEL_API size_t mpt_sah_level_words(size_t nseg, int *nb_out);
-MPT_KERNEL_API hipError_t mpt_sah_scan_bytes(int n, size_t *bytes);
+MPT_KERNEL_API size_t mpt_sah_chunk_capacity(int n);
+MPT_KERNEL_API size_t mpt_sah_task_capacity(int n);
+MPT_KERNEL_API size_t mpt_sah_part_words(int n);
+MPT_KERNEL_API size_t mpt_sah_segbin_words(int n);
+MPT_KERNEL_API size_t mpt_sah_level_words(int n, size_t nseg, int *nb_out);
+MPT_KERNEL_API int mpt_sah_task_max(void);
 MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipStream_t stream);
 MPT_KERNEL_API hipError_t mpt_wide_scan_bytes(int ni, size_t *bytes);
 MPT_KERNEL_API hipError_t mpt_wide_build(const MptVec4 *fnode, int n, MptVec4 *wnode, MptVec4 *qnode, int *bin_of, int *ncount,
@@ -150,6 +153,8 @@ struct mpt_ctx {
     float wide_ratio = 1.f;                           // expected fetches per ray, wide / binary (surface-area sums)
     int sah_exact_max = 8192;                         // host SAH pass: ranges up to this size are swept exactly (diagnostics)
     int sah_inject_fail = 0;                          // test door: treat the device SAH pass as failed after it ran
+    int build_phases = 0;                             // diagnostics: synchronise at the end of every phase of mpt_build_tree and time it
+    double build_phase_us[6] = { 0, 0, 0, 0, 0, 0 };   // upload | LBVH | SAH pass | triangle records | 4-wide collapse | total (host clock)
     int sah_fallback = 0;                             // last build: the device SAH pass gave up (1: error, 2: depth) and the host pass ran
     int sah_build = -1;                               // SAH re-partition: 1 on the device (sah_build.hip), 0 host pass, -1 auto
                                                       // (device above 131072 faces: the host's exact sweep is the better tree

@@ -72,19 +72,17 @@ struct MptLight {              // light/__init__.py:14-18
 // one contiguous float4 range of the film gather's pack / unpack (comm.cpp): count elements from src to dst
 struct MptPiece { long long src, dst, count; };
 
-// device workspace of the SAH re-partition (sah_build.hip); capacities: n leaf slots, SC = mpt_sah_seg_capacity(n) segments
+// device workspace of the SAH re-partition (sah_build.hip); capacities from mpt_sah_*_capacity(n)
 struct MptSahBuffers {
     const float *verts; const int *leaf; int n;          // the LBVH build's inputs / leaf order, on the device
-    float *plo, *phi, *pct;                              // [n][3] box and centre per leaf slot
-    int *idx[2], *seg[2];                                // [n] slot permutation and segment of every position (double-buffered)
-    int *pred, *pscan;                                   // [n]
-    int *sb[2], *se[2], *snode[2];                       // [SC] segment tables (double-buffered)
-    int *segw; size_t seg_words;                         // [seg_words = mpt_sah_seg_words(n)] per-segment bounds + bins of one level
-    int *dec, *flag, *foff;                              // [SC][4], [2 SC], [2 SC]
-    int *small;                                          // [n / 2 + 1][4]
-    int *counters;                                       // [4]: small segments, depth
-    int *child; float *blo, *bhi;                        // [n-1][2], [n-1][3], [n-1][3]
-    void *scan_tmp; size_t scan_bytes;
+    MptVec4 *prim[2];                                    // [n][2]: {box lo, slot} {box hi, -} per position (ping-pong)
+    int *seg[2]; size_t seg_cap;                         // [seg_cap][16] segment tables (this level / the next)
+    int *dec;                                            // [seg_cap][8] this level's decisions
+    int *ch_seg, *ch_left; size_t chunk_cap;             // [2][chunk_cap] chunk -> segment (this level / the next), [chunk_cap] left counts
+    int *part; size_t part_words;                        // chunk bins of one level
+    int *segbins; size_t segbin_words;                   // the bins of the segments that have several chunks
+    int *tasks; size_t task_cap;                         // [task_cap][8] ranges the finish kernel takes
+    int *meta;                                           // [8]
     MptVec4 *fnode;                                      // out: [n-1][4]
 };
 

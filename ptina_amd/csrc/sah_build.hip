@@ -1,257 +1,161 @@
-// sah_build.hip -- the SAH re-partition of the fast build's leaves, on the device.
+// sah_build.hip -- the SAH re-partition of the fast build's leaves, on the device (round 6: rewritten).
 //
 // The production traversal walks a better tree than the reference's LBVH over the SAME leaf slots (the image does not
-// depend on the tree's shape, only on which of two equal-depth hits wins).  Round 2 built it on the host (a threaded
-// recursive pass: 0.22 s at 1 M triangles, plus the leaf order down and 64 MB of node records up).  Here it is built on
-// the device, top-down and level by level:
-//   prims     per leaf slot: box and box centre of its triangle
-//   per level, for the segments (ranges of the slot permutation) with more than 32 triangles:
-//     bounds   per segment: bounds of the centres and of the boxes (wave-reduced ordered-int atomics)
-//     bin      32 bins per axis over the centre bounds: count and box per bin (atomics)
-//     choose   one lane per segment: SAH cost of the 3 x 31 splits (area x count on both sides), best one; the node's
-//              number follows from the range sizes (DFS pre-order: left child me + 1, right child me + left size), so no
-//              counter is shared; children with <= 32 triangles go to the small list, single triangles become leaves
-//     scatter  stable partition of every segment by its split (one global prefix sum of the predicates)
-//   small     one lane per small segment: the exact sweep (every split of every axis, sorted by centre) of the host pass,
-//              down to the leaves
-//   pack      the 64-byte traversal records (both children's boxes + ids)
-// Same cost function and tie rules as the host pass (tree_build.cpp SahBuild).  Segments between 33 and 8192 triangles are
-// binned here where the host sweeps them exactly; what that costs depends on the scene and on the bin count (see SB_MAXBINS),
-// so the bins are spent where they matter: as many per axis as a fixed budget divided by the level's segment count allows.
-// Films agree up to equal-depth ties like any two trees (tests).  Deterministic: every
-// decision is a function of sums of integers and min / max of floats.
+// depend on the tree's shape, only on which of two equal-depth hits wins).  Same cost function and tie rules as the host
+// pass (tree_build.cpp SahBuild): area x count on both sides, lowest cost, then lowest axis, then lowest split.
+//
+// Round 3-5 ran every level of the tree as nine launches over all n positions with global atomics per triangle and
+// finished the <= 32-triangle ranges one lane each: 31 ms at a million triangles (profiles/r06_build_kernel_stats_c5_before.csv:
+// bin 10.9 ms, small 8.5 ms, bounds 7.5 ms).  Now:
+//
+//   TOP PHASE, level by level, only for the ranges ("segments") of more than SB_K = 512 triangles.  The triangles' 32-byte
+//   records {box, slot} themselves are moved (ping-pong), so every pass streams.  A level's segments are cut into chunks of
+//   2048 ... 16384 positions, one workgroup each:
+//     bin      a chunk's bins (3 axes x nb x {count, box}) in LDS, written out once, no global atomics; nb = 32 ... 1024 per
+//              axis, as many as a budget divided by the level's segment count allows (bins matter near the root)
+//     choose   one workgroup per segment: sums its chunks' bins, one wave per axis scans them for the cheapest split; the
+//              node's box goes into its PARENT's record (a node record holds its two children's boxes), the chunks' left
+//              counts follow from the chunks' own bin counts (no counting pass), children of <= 512 triangles become tasks
+//     plan     one workgroup: next level's segment table and chunk list (two prefix sums)
+//     scatter  stable partition of every chunk's records into the other buffer; single triangles write themselves into
+//              their parent's record; the centre bounds of the children that go on as segments are reduced on the way
+//   One 16-byte read-back per level (grid sizes of the next one).
+//
+//   FINISH: one wave per task (<= 512 triangles), everything in 29 KB of LDS: the task's triangles are sorted once on each
+//   axis by (centre, slot); then level by level over all of the task's ranges at once: segmented suffix / prefix scans of
+//   the boxes along each sorted order give every split of every axis its exact cost (the host pass's exact sweep), a
+//   segmented minimum picks each range's split, and a stable partition of all three orders keeps them sorted inside the
+//   children.  For n <= 512 the whole tree is this kernel's and is the host pass's tree node for node (tests).
+//
+// Node numbers follow from range sizes (DFS pre-order: left child me + 1, right child me + left size): nothing is shared
+// between ranges.  Deterministic: every decision is a function of sums of integers and min / max of floats, partitions are
+// stable, ties go to the lowest slot.  This file is compiled with -ffp-contract=off.
 
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 #include <cmath>
 #include "mpt_types.h"
 
 #define SB_BLOCK 256
+#ifndef SB_K
+#define SB_K 512               // a range of at most this many triangles is finished by one wave in LDS (exact sweep)
+#endif
+#define SB_E (SB_K / 64)       // positions per lane
 #ifndef SB_MINBINS
-#define SB_MINBINS 32          // bins per axis at the deep levels (many small segments) ...
+#define SB_MINBINS 32          // bins per axis at the levels with many segments ...
 #endif
 #ifndef SB_MAXBINS
-#define SB_MAXBINS 1024        // ... and near the root: as many as SB_BIN_BUDGET / segments allows.  Measured on the 99 382-triangle
-#endif                         // scene of BASELINE config 4 (a dense mesh inside ten huge wall triangles): 32 bins everywhere 10.5
-#ifndef SB_BIN_BUDGET          // node fetches per ray, 128 everywhere 9.97, the host pass (exact sweep up to 8192 leaves) 9.44
-#define SB_BIN_BUDGET (1 << 20)
+#define SB_MAXBINS 1024        // ... and near the root: as many as SB_BIN_BUDGET / (2 x segments) allows
 #endif
-#ifndef SB_SMALL
-#define SB_SMALL 32            // segments of at most this many triangles are finished by one lane (exact sweep)
+#ifndef SB_BIN_BUDGET
+#define SB_BIN_BUDGET (1 << 17)
 #endif
-#define SB_LDS_BINS 64         // up to this many bins a segment-uniform workgroup bins into LDS first
-// words per segment at nb bins: bounds (12) | counts [3][nb] | boxes [3][nb][6] | suffix areas [3][nb] | suffix counts [3][nb]
-#define SB_SEG_WORDS(nb) (12 + 27 * (nb))
+#define SB_CHUNK_MIN 2048      // positions per chunk (workgroup): max(SB_CHUNK_MIN, 16 x bins), so a chunk's bins stay below its records' bytes
+#define SB_SEG_INTS 16         // segment record: b, e, node, parent * 2 + side, centre bounds [6] (ordered ints), first chunk, chunks
+#define SB_DEC_INTS 8          // decision record: axis (-1: halve the range), first bin of the right side, m, child segments [2] (-1: none)
+#define SB_TASK_INTS 8         // task record: b, e, node, parent * 2 + side, level, buffer
+
+enum { SEG_B = 0, SEG_E, SEG_NODE, SEG_PAR, SEG_CB, SEG_CHUNK0 = 10, SEG_NCHUNK = 11 };
+enum { DEC_AXIS = 0, DEC_Q, DEC_M, DEC_CHILD0, DEC_CHILD1 };
+enum { META_NSEG = 0, META_NCHUNK, META_NB, META_CH, META_NTASK, META_DEPTH, META_BAD };
+
+__host__ __device__ __forceinline__ int sb_bins_for(long long nseg) {
+    int nb = SB_MINBINS;
+    while (nb < SB_MAXBINS && nseg * 2 * nb <= (long long)SB_BIN_BUDGET) nb *= 2;
+    return nb;
+}
+__host__ __device__ __forceinline__ int sb_chunk_for(int nb) { return 16 * nb > SB_CHUNK_MIN ? 16 * nb : SB_CHUNK_MIN; }
 
 __device__ __forceinline__ int sb_f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float sb_ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
-
+__device__ __forceinline__ float sb_scale(int nb, float cl, float ch) { return ch > cl ? nb / (ch - cl) : 0.f; }
+__device__ __forceinline__ int sb_bin_of(float c, float cl, float scale, int nb) {
+    return min(nb - 1, max(0, (int)((c - cl) * scale)));
+}
 __device__ __forceinline__ float sb_half_area(const float *l, const float *h) {
     const float dx = fmaxf(h[0] - l[0], 0.f), dy = fmaxf(h[1] - l[1], 0.f), dz = fmaxf(h[2] - l[2], 0.f);
     return dx * dy + dy * dz + dz * dx;
 }
+// child k (0 / 1) of node `par` has this box and id: the 64-byte record is {c0.lo.x, c1.lo.x, c0.hi.x, c1.hi.x} {y} {z} {id0, id1, 0, 0}
+__device__ __forceinline__ void sb_write_child(MptVec4 *__restrict__ fnode, int par2, const float *l, const float *h, int id) {
+    float *r = (float *)(fnode + (size_t)(par2 >> 1) * 4);
+    const int k = par2 & 1;
+    for (int a = 0; a < 3; a++) { r[a * 4 + k] = l[a]; r[a * 4 + 2 + k] = h[a]; }
+    r[12 + k] = __int_as_float(id);
+}
 
-// per leaf slot: box and centre of its triangle (verts [3n][8], leaf: slot -> face)
+// ------------------------------------------------------------------ records of the leaf slots + the root's centre bounds
+// verts [3n][8], leaf: slot -> face.  prim[slot] = {lo.xyz, slot} {hi.xyz, 0}
 __global__ __launch_bounds__(SB_BLOCK) void sb_prims_kernel(const float *__restrict__ verts, const int *__restrict__ leaf, int n,
-                                                           float *__restrict__ plo, float *__restrict__ phi, float *__restrict__ pct,
-                                                           int *__restrict__ idx, int *__restrict__ seg) {
-    const int slot = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (slot >= n) return;
-    const float *p0 = verts + (size_t)leaf[slot] * 24, *p1 = p0 + 8, *p2 = p0 + 16;
-    for (int a = 0; a < 3; a++) {
-        const float l = fminf(fminf(p0[a], p1[a]), p2[a]), h = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
-        plo[(size_t)slot * 3 + a] = l; phi[(size_t)slot * 3 + a] = h; pct[(size_t)slot * 3 + a] = 0.5f * (l + h);
-    }
-    idx[slot] = slot; seg[slot] = 0;
-}
-
-// per-segment words: [0..5] centre bounds lo3 hi3, [6..11] box bounds lo3 hi3 (ordered ints), then bin counts [3][32],
-// then bin boxes [3][32][6] (ordered ints)
-__global__ __launch_bounds__(SB_BLOCK) void sb_reset_kernel(int nseg, int nb, int *__restrict__ sw) {
-    const size_t sws = SB_SEG_WORDS(nb);
-    const size_t t = (size_t)blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (t >= (size_t)nseg * sws) return;
-    const int w = (int)(t % sws);
-    int v = 0;
-    if (w < 12) v = (w % 6) < 3 ? 0x7fffffff : (int)0x80000000;
-    else if (w >= 12 + 3 * nb && w < 12 + 21 * nb) v = ((w - 12 - 3 * nb) % 6) < 3 ? 0x7fffffff : (int)0x80000000;
-    sw[t] = v;
-}
-
-__global__ __launch_bounds__(SB_BLOCK) void sb_bounds_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
-                                                            const float *__restrict__ pct, const float *__restrict__ plo,
-                                                            const float *__restrict__ phi, int nb, int *__restrict__ sw) {
-    const size_t sws = SB_SEG_WORDS(nb);
-    const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
-    const int s = i < n ? seg[i] : -1;
-    int v[12];
-    if (s >= 0) {
-        const int slot = idx[i];
+                                                           MptVec4 *__restrict__ prim, int *__restrict__ seg0) {
+    int cb[6] = { 0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000 };
+    for (int slot = blockIdx.x * SB_BLOCK + threadIdx.x; slot < n; slot += gridDim.x * SB_BLOCK) {
+        const float *p0 = verts + (size_t)leaf[slot] * 24, *p1 = p0 + 8, *p2 = p0 + 16;
+        float l[3], h[3];
         for (int a = 0; a < 3; a++) {
-            const int c = sb_f2ord(pct[(size_t)slot * 3 + a]);
-            v[a] = c; v[3 + a] = c;
-            v[6 + a] = sb_f2ord(plo[(size_t)slot * 3 + a]); v[9 + a] = sb_f2ord(phi[(size_t)slot * 3 + a]);
+            l[a] = fminf(fminf(p0[a], p1[a]), p2[a]); h[a] = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
+            const int c = sb_f2ord(0.5f * (l[a] + h[a]));
+            cb[a] = min(cb[a], c); cb[3 + a] = max(cb[3 + a], c);
         }
-    } else {
-        for (int k = 0; k < 12; k++) v[k] = (k % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+        prim[(size_t)slot * 2 + 0] = { l[0], l[1], l[2], __int_as_float(slot) };
+        prim[(size_t)slot * 2 + 1] = { h[0], h[1], h[2], 0.f };
     }
-    // a wave whose lanes all belong to one segment (the rule near the root) reduces first: one atomic per word and wave
-    const int s0 = __shfl(s, 0);
-    if (__all(s == s0)) {
-        if (s0 < 0) return;
-        for (int k = 0; k < 12; k++)
-            for (int off = 32; off > 0; off >>= 1) {
-                const int o = __shfl_xor(v[k], off);
-                v[k] = (k % 6) < 3 ? min(v[k], o) : max(v[k], o);
-            }
-        if ((threadIdx.x & 63) == 0)
-            for (int k = 0; k < 12; k++) {
-                if ((k % 6) < 3) atomicMin(sw + (size_t)s0 * sws + k, v[k]);
-                else atomicMax(sw + (size_t)s0 * sws + k, v[k]);
-            }
-    } else if (s >= 0) {
-        for (int k = 0; k < 12; k++) {
-            if ((k % 6) < 3) atomicMin(sw + (size_t)s * sws + k, v[k]);
-            else atomicMax(sw + (size_t)s * sws + k, v[k]);
+    for (int k = 0; k < 6; k++)
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(cb[k], off);
+            cb[k] = k < 3 ? min(cb[k], o) : max(cb[k], o);
         }
-    }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 6; k++) {
+            if (k < 3) atomicMin(seg0 + SEG_CB + k, cb[k]); else atomicMax(seg0 + SEG_CB + k, cb[k]);
+        }
 }
 
-__device__ __forceinline__ int sb_bin_of(float c, float cl, float scale, int nb) {
-    return min(nb - 1, max(0, (int)((c - cl) * scale)));
-}
-
-__global__ __launch_bounds__(SB_BLOCK) void sb_bin_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
-                                                         const float *__restrict__ pct, const float *__restrict__ plo,
-                                                         const float *__restrict__ phi, int nb, int *__restrict__ sw) {
-    // A workgroup whose 256 positions all belong to one segment bins into LDS and merges once (with few bins a segment's
-    // lanes would otherwise hammer the same few words: 14 ms for the first level of a million triangles at 32 bins)
-    __shared__ int lb[3 * SB_LDS_BINS * 7];           // [axis][bin]{count, lo3, hi3}
-    const size_t sws = SB_SEG_WORDS(nb);
-    const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
-    const int s = i < n ? seg[i] : -2;
-    const int sfirst = seg[min((int)(blockIdx.x * SB_BLOCK), n - 1)];
-    const bool uniform = nb <= SB_LDS_BINS && __syncthreads_and(s == sfirst || s == -2) != 0;
-    if (uniform) {
-        if (sfirst < 0) return;
-        for (int k = threadIdx.x; k < 3 * nb * 7; k += SB_BLOCK) {
-            const int f = k % 7;
-            lb[k] = f == 0 ? 0 : (f < 4 ? 0x7fffffff : (int)0x80000000);
-        }
-        __syncthreads();
+// ------------------------------------------------------------------ top phase: bin
+// part[chunk][axis][bin]{count, lo3, hi3} (ordered ints); a bin nobody fell into keeps {0, MAX.., MIN..}
+__global__ __launch_bounds__(SB_BLOCK) void sb_bin_kernel(const MptVec4 *__restrict__ prim, const int *__restrict__ seg,
+                                                         const int *__restrict__ ch_seg, int nb, int CH, int *__restrict__ part) {
+    extern __shared__ int lb[];
+    const int j = blockIdx.x, s = ch_seg[j];
+    const int *S = seg + (size_t)s * SB_SEG_INTS;
+    const int b = S[SEG_B], e = S[SEG_E];
+    const int start = b + (j - S[SEG_CHUNK0]) * CH, end = min(start + CH, e);
+    float cl[3], scale[3];
+    for (int a = 0; a < 3; a++) { cl[a] = sb_ord2f(S[SEG_CB + a]); scale[a] = sb_scale(nb, cl[a], sb_ord2f(S[SEG_CB + 3 + a])); }
+    const int words = 21 * nb;
+    for (int k = threadIdx.x; k < words; k += SB_BLOCK) {
+        const int f = k % 7;
+        lb[k] = f == 0 ? 0 : (f < 4 ? 0x7fffffff : (int)0x80000000);
     }
-    if (s >= 0) {
-        const int slot = idx[i];
-        int *w = sw + (size_t)s * sws;
+    __syncthreads();
+    for (int i = start + threadIdx.x; i < end; i += SB_BLOCK) {
+        const MptVec4 lo = prim[(size_t)i * 2], hi = prim[(size_t)i * 2 + 1];
+        const float l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
         int bl[3], bh[3];
-        for (int a = 0; a < 3; a++) { bl[a] = sb_f2ord(plo[(size_t)slot * 3 + a]); bh[a] = sb_f2ord(phi[(size_t)slot * 3 + a]); }
+        for (int a = 0; a < 3; a++) { bl[a] = sb_f2ord(l[a]); bh[a] = sb_f2ord(h[a]); }
         for (int a = 0; a < 3; a++) {
-            const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
-            if (!(ch > cl)) continue;
-            const float scale = nb / (ch - cl);
-            const int q = sb_bin_of(pct[(size_t)slot * 3 + a], cl, scale, nb);
-            if (uniform) {
-                int *e = lb + (a * nb + q) * 7;
-                atomicAdd(e, 1);
-                for (int r = 0; r < 3; r++) { atomicMin(e + 1 + r, bl[r]); atomicMax(e + 4 + r, bh[r]); }
-            } else {
-                atomicAdd(w + 12 + a * nb + q, 1);
-                int *bb = w + 12 + 3 * nb + (a * nb + q) * 6;
-                for (int r = 0; r < 3; r++) { atomicMin(bb + r, bl[r]); atomicMax(bb + 3 + r, bh[r]); }
-            }
+            const int q = sb_bin_of(0.5f * (l[a] + h[a]), cl[a], scale[a], nb);
+            int *w = lb + (a * nb + q) * 7;
+            atomicAdd(w, 1);
+            for (int r = 0; r < 3; r++) { atomicMin(w + 1 + r, bl[r]); atomicMax(w + 4 + r, bh[r]); }
         }
     }
-    if (uniform) {
-        __syncthreads();
-        int *w = sw + (size_t)sfirst * sws;
-        for (int k = threadIdx.x; k < 3 * nb; k += SB_BLOCK) {
-            const int *e = lb + k * 7;
-            if (e[0] == 0) continue;
-            atomicAdd(w + 12 + k, e[0]);
-            int *bb = w + 12 + 3 * nb + k * 6;
-            for (int r = 0; r < 3; r++) { atomicMin(bb + r, e[1 + r]); atomicMax(bb + 3 + r, e[4 + r]); }
-        }
-    }
+    __syncthreads();
+    int *out = part + (size_t)j * words;
+    for (int k = threadIdx.x; k < words; k += SB_BLOCK) out[k] = lb[k];
 }
 
-__device__ __forceinline__ void sb_emit(int s, int b, int e, int me, const int *w, int best_axis, int best_k, int best_q, int level,
-                                        int *__restrict__ child, float *__restrict__ blo, float *__restrict__ bhi, int *__restrict__ dec,
-                                        int *__restrict__ flag, int *__restrict__ small, int *__restrict__ counters);
-
-// dec[s] = {axis (-1: split the range in half), first bin of the right side, m (first position of the right side), -}
-// flag[2 s + k] = 1: child k is a segment of the next level.  small: {b, e, node, level} per small segment.
-__global__ __launch_bounds__(SB_BLOCK) void sb_choose_kernel(int nseg, const int *__restrict__ sb, const int *__restrict__ se,
-                                                            const int *__restrict__ snode, int nb, int *__restrict__ sw, int level,
-                                                            int *__restrict__ child, float *__restrict__ blo, float *__restrict__ bhi,
-                                                            int *__restrict__ dec, int *__restrict__ flag, int *__restrict__ small,
-                                                            int *__restrict__ counters) {
-    const int s = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (s >= nseg) return;
-    const int b = sb[s], e = se[s], me = snode[s];
-    int *w = sw + (size_t)s * SB_SEG_WORDS(nb);
-    float best = INFINITY;
-    int best_axis = -1, best_k = -1, best_q = 0;
-    for (int a = 0; a < 3; a++) {
-        const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
-        if (!(ch > cl)) continue;
-        const int *bc = w + 12 + a * nb;
-        const int *bb = w + 12 + 3 * nb + a * nb * 6;
-        float *ra = (float *)(w + 12 + 21 * nb + a * nb);         // suffix areas / counts: the segment's own scratch words
-        int *rc = w + 12 + 24 * nb + a * nb;
-        float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
-        int c2 = 0;
-        for (int q = nb - 1; q > 0; q--) {
-            c2 += bc[q];
-            if (bc[q]) for (int r = 0; r < 3; r++) { l[r] = fminf(l[r], sb_ord2f(bb[q * 6 + r])); h[r] = fmaxf(h[r], sb_ord2f(bb[q * 6 + 3 + r])); }
-            ra[q] = sb_half_area(l, h); rc[q] = c2;
-        }
-        for (int r = 0; r < 3; r++) { l[r] = INFINITY; h[r] = -INFINITY; }
-        int c1 = 0;
-        for (int q = 1; q < nb; q++) {
-            c1 += bc[q - 1];
-            if (bc[q - 1]) for (int r = 0; r < 3; r++) { l[r] = fminf(l[r], sb_ord2f(bb[(q - 1) * 6 + r])); h[r] = fmaxf(h[r], sb_ord2f(bb[(q - 1) * 6 + 3 + r])); }
-            if (c1 == 0 || rc[q] == 0) continue;
-            const float cost = sb_half_area(l, h) * c1 + ra[q] * rc[q];
-            if (cost < best) { best = cost; best_axis = a; best_k = c1; best_q = q; }
-        }
-    }
-    sb_emit(s, b, e, me, w, best_axis, best_k, best_q, level, child, blo, bhi, dec, flag, small, counters);
-}
-
-// the tail of a segment's decision, shared by both choose kernels: node box, split, children
-__device__ __forceinline__ void sb_emit(int s, int b, int e, int me, const int *w, int best_axis, int best_k, int best_q, int level,
-                                        int *__restrict__ child, float *__restrict__ blo, float *__restrict__ bhi, int *__restrict__ dec,
-                                        int *__restrict__ flag, int *__restrict__ small, int *__restrict__ counters) {
-    const int cnt = e - b;
-    for (int a = 0; a < 3; a++) { blo[(size_t)me * 3 + a] = sb_ord2f(w[6 + a]); bhi[(size_t)me * 3 + a] = sb_ord2f(w[9 + a]); }
-    const int m = best_axis < 0 ? b + cnt / 2 : b + best_k;          // all centres equal: split the range in half
-    dec[s * 4 + 0] = best_axis; dec[s * 4 + 1] = best_q; dec[s * 4 + 2] = m; dec[s * 4 + 3] = 0;
-    const int node[2] = { me + 1, me + (m - b) };
-    const int lo_[2] = { b, m }, hi_[2] = { m, e };
-    for (int k = 0; k < 2; k++) {
-        const int sz = hi_[k] - lo_[k];
-        flag[2 * s + k] = 0;
-        if (sz == 1) continue;                                       // a leaf: the scatter pass writes ~slot
-        child[(size_t)me * 2 + k] = node[k];
-        if (sz <= SB_SMALL) {
-            const int at = atomicAdd(counters + 0, 1);
-            small[at * 4 + 0] = lo_[k]; small[at * 4 + 1] = hi_[k]; small[at * 4 + 2] = node[k]; small[at * 4 + 3] = level + 1;
-        } else {
-            flag[2 * s + k] = 1;
-        }
-    }
-    atomicMax(counters + 1, level);
-}
-
-// the same decision by one WAVE per segment, for the levels with many bins per axis (few, big segments: one lane walking
-// 3 x 1024 bins through global memory took 15 ms per level): lane l owns nb / 64 consecutive bins, the boxes and counts of
-// the lanes before / after it come from wave scans, and the lanes' best splits are reduced with the serial loop's tie rule
-// (lowest cost, then lowest axis, then lowest bin)
+// ------------------------------------------------------------------ top phase: choose
 struct SbAgg { int c; float l[3], h[3]; };
+__device__ __forceinline__ void sb_agg_clear(SbAgg &a) { a.c = 0; for (int r = 0; r < 3; r++) { a.l[r] = INFINITY; a.h[r] = -INFINITY; } }
 __device__ __forceinline__ void sb_agg_add(SbAgg &a, const SbAgg &b) {
     a.c += b.c;
     for (int r = 0; r < 3; r++) { a.l[r] = fminf(a.l[r], b.l[r]); a.h[r] = fmaxf(a.h[r], b.h[r]); }
+}
+__device__ __forceinline__ void sb_agg_add_bin(SbAgg &a, const int *w) {      // w: {count, lo3, hi3}, ignored when empty
+    if (w[0] == 0) return;
+    a.c += w[0];
+    for (int r = 0; r < 3; r++) { a.l[r] = fminf(a.l[r], sb_ord2f(w[1 + r])); a.h[r] = fmaxf(a.h[r], sb_ord2f(w[4 + r])); }
 }
 __device__ __forceinline__ SbAgg sb_agg_shfl_up(const SbAgg &a, int d) {
     SbAgg o; o.c = __shfl_up(a.c, d);
@@ -263,314 +167,692 @@ __device__ __forceinline__ SbAgg sb_agg_shfl_down(const SbAgg &a, int d) {
     for (int r = 0; r < 3; r++) { o.l[r] = __shfl_down(a.l[r], d); o.h[r] = __shfl_down(a.h[r], d); }
     return o;
 }
-__global__ __launch_bounds__(64) void sb_choose_wave_kernel(int nseg, const int *__restrict__ sb, const int *__restrict__ se,
-                                                           const int *__restrict__ snode, int nb, const int *__restrict__ sw, int level,
-                                                           int *__restrict__ child, float *__restrict__ blo, float *__restrict__ bhi,
-                                                           int *__restrict__ dec, int *__restrict__ flag, int *__restrict__ small,
-                                                           int *__restrict__ counters) {
-    const int s = blockIdx.x, lane = threadIdx.x;
-    if (s >= nseg) return;
-    const int b = sb[s], e = se[s], me = snode[s];
-    const int *w = sw + (size_t)s * SB_SEG_WORDS(nb);
-    const int per = nb >> 6;                          // bins per lane (nb is a multiple of 64 here, at most 16 per lane)
-    float best = INFINITY;
-    int best_axis = -1, best_k = -1, best_q = 0;
-    for (int a = 0; a < 3; a++) {
-        const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
-        if (!(ch > cl)) continue;                     // (wave-uniform)
-        const int *bc = w + 12 + a * nb;
-        const int *bb = w + 12 + 3 * nb + a * nb * 6;
-        const int q0 = lane * per;
-        SbAgg own; own.c = 0;
-        for (int r = 0; r < 3; r++) { own.l[r] = INFINITY; own.h[r] = -INFINITY; }
-        for (int t = 0; t < per; t++) {
-            const int q = q0 + t, c = bc[q];
-            if (c) {
-                own.c += c;
-                for (int r = 0; r < 3; r++) { own.l[r] = fminf(own.l[r], sb_ord2f(bb[q * 6 + r])); own.h[r] = fmaxf(own.h[r], sb_ord2f(bb[q * 6 + 3 + r])); }
+
+// one wave, one axis: the cheapest split of nb bins (in LDS at w0, 7 words each).  Lane l owns `per` consecutive bins; the
+// boxes and counts of the lanes before / after it come from wave scans; the lanes' best splits are reduced with the serial
+// loop's tie rule (lowest cost, then lowest bin).  Returns in every lane: cost (INFINITY: no split), k (left count), q.
+__device__ __forceinline__ void sb_axis_best(const int *w0, int nb, int lane, float &cost_out, int &k_out, int &q_out) {
+    const int per = nb >= 64 ? nb >> 6 : 1;           // 1 ... 16 bins per lane
+    const bool live = lane * per < nb;
+    const int q0 = lane * per;
+    SbAgg own; sb_agg_clear(own);
+    if (live)
+#pragma unroll
+        for (int t = 0; t < 16; t++) if (t < per) sb_agg_add_bin(own, w0 + (q0 + t) * 7);
+    SbAgg pre = own, suf = own;
+    for (int d = 1; d < 64; d <<= 1) {
+        SbAgg o = sb_agg_shfl_up(pre, d);
+        if (lane >= d) sb_agg_add(pre, o);
+        SbAgg u = sb_agg_shfl_down(suf, d);
+        if (lane + d < 64) sb_agg_add(suf, u);
+    }
+    SbAgg left = sb_agg_shfl_up(pre, 1), right = sb_agg_shfl_down(suf, 1);
+    if (lane == 0) sb_agg_clear(left);
+    if (lane == 63) sb_agg_clear(right);
+    // the right side of a split at the lane's bin t = its bins t .. per-1 + the lanes after it
+    float rar[16]; int rcn[16];
+    {
+        SbAgg acc = right;
+#pragma unroll
+        for (int t = 15; t >= 0; t--) {
+            rar[t] = 0.f; rcn[t] = 0;
+            if (t < per && live) {
+                sb_agg_add_bin(acc, w0 + (q0 + t) * 7);
+                rar[t] = sb_half_area(acc.l, acc.h); rcn[t] = acc.c;
             }
         }
-        // what lies in the lanes before this one (exclusive prefix) and after it (exclusive suffix)
-        SbAgg pre = own, suf = own;
-        for (int d = 1; d < 64; d <<= 1) {
-            SbAgg o = sb_agg_shfl_up(pre, d);
-            if (lane >= d) sb_agg_add(pre, o);
-            SbAgg u = sb_agg_shfl_down(suf, d);
-            if (lane + d < 64) sb_agg_add(suf, u);
-        }
-        SbAgg left = sb_agg_shfl_up(pre, 1), right = sb_agg_shfl_down(suf, 1);
-        if (lane == 0) { left.c = 0; for (int r = 0; r < 3; r++) { left.l[r] = INFINITY; left.h[r] = -INFINITY; } }
-        if (lane == 63) { right.c = 0; for (int r = 0; r < 3; r++) { right.l[r] = INFINITY; right.h[r] = -INFINITY; } }
-        // the right side of a split at the lane's bin t = its bins t .. per-1 + the lanes after it: suffixes inside the chunk
-        float ral[16][3], rah[16][3]; int rcn[16];
-        {
-            SbAgg acc = right;
-            for (int t = per - 1; t >= 0; t--) {
-                const int q = q0 + t, c = bc[q];
-                if (c) {
-                    acc.c += c;
-                    for (int r = 0; r < 3; r++) { acc.l[r] = fminf(acc.l[r], sb_ord2f(bb[q * 6 + r])); acc.h[r] = fmaxf(acc.h[r], sb_ord2f(bb[q * 6 + 3 + r])); }
-                }
-                rcn[t] = acc.c;
-                for (int r = 0; r < 3; r++) { ral[t][r] = acc.l[r]; rah[t][r] = acc.h[r]; }
-            }
-        }
-        // candidate splits: left = bins 0 .. q-1, right = bins q .. nb-1, for q = q0 + t (q >= 1)
-        float lbest = INFINITY; int lk = -1, lq = 0;
+    }
+    float lbest = INFINITY; int lk = -1, lq = 0;
+    {
         SbAgg acc = left;
-        for (int t = 0; t < per; t++) {
-            const int q = q0 + t;
-            if (q >= 1 && acc.c != 0 && rcn[t] != 0) {
-                const float cost = sb_half_area(acc.l, acc.h) * acc.c + sb_half_area(ral[t], rah[t]) * rcn[t];
-                if (cost < lbest) { lbest = cost; lk = acc.c; lq = q; }
-            }
-            const int c = bc[q];
-            if (c) {
-                acc.c += c;
-                for (int r = 0; r < 3; r++) { acc.l[r] = fminf(acc.l[r], sb_ord2f(bb[q * 6 + r])); acc.h[r] = fmaxf(acc.h[r], sb_ord2f(bb[q * 6 + 3 + r])); }
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            if (t < per && live) {
+                const int q = q0 + t;
+                if (q >= 1 && acc.c != 0 && rcn[t] != 0) {
+                    const float cost = sb_half_area(acc.l, acc.h) * acc.c + rar[t] * rcn[t];
+                    if (cost < lbest) { lbest = cost; lk = acc.c; lq = q; }
+                }
+                sb_agg_add_bin(acc, w0 + q * 7);
             }
         }
-        // wave argmin: lowest cost, ties to the lowest bin (= the serial loop's first strict minimum)
-        for (int d = 32; d > 0; d >>= 1) {
-            const float oc = __shfl_xor(lbest, d); const int ok = __shfl_xor(lk, d), oq = __shfl_xor(lq, d);
-            if (oc < lbest || (oc == lbest && ok >= 0 && (lk < 0 || oq < lq))) { lbest = oc; lk = ok; lq = oq; }
-        }
-        if (lk >= 0 && lbest < best) { best = lbest; best_axis = a; best_k = lk; best_q = lq; }
     }
-    if (lane == 0) sb_emit(s, b, e, me, w, best_axis, best_k, best_q, level, child, blo, bhi, dec, flag, small, counters);
+    for (int d = 32; d > 0; d >>= 1) {
+        const float oc = __shfl_xor(lbest, d); const int ok = __shfl_xor(lk, d), oq = __shfl_xor(lq, d);
+        if (ok >= 0 && (lk < 0 || oc < lbest || (oc == lbest && oq < lq))) { lbest = oc; lk = ok; lq = oq; }
+    }
+    cost_out = lk >= 0 ? lbest : INFINITY; k_out = lk; q_out = lq;
 }
 
-__global__ __launch_bounds__(SB_BLOCK) void sb_newseg_kernel(int nseg, const int *__restrict__ sb, const int *__restrict__ se,
-                                                            const int *__restrict__ snode, const int *__restrict__ dec,
-                                                            const int *__restrict__ flag, const int *__restrict__ foff,
-                                                            int *__restrict__ sb2, int *__restrict__ se2, int *__restrict__ snode2) {
-    const int s = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (s >= nseg) return;
-    const int b = sb[s], e = se[s], me = snode[s], m = dec[s * 4 + 2];
-    if (flag[2 * s + 0]) { const int ns = foff[2 * s + 0]; sb2[ns] = b; se2[ns] = m; snode2[ns] = me + 1; }
-    if (flag[2 * s + 1]) { const int ns = foff[2 * s + 1]; sb2[ns] = m; se2[ns] = e; snode2[ns] = me + (m - b); }
+// a segment's bins = the sum / min / max of its chunks' bins, one lane per word (a workgroup per segment doing this alone took
+// 250 us per level near the root, where one segment has 60 chunks of 21 504 words).  Segments of one chunk are skipped: the
+// choose kernel reads that chunk's bins directly.
+__global__ __launch_bounds__(SB_BLOCK) void sb_reduce_kernel(const int *__restrict__ seg, int nb, const int *__restrict__ part,
+                                                            int *__restrict__ segbins) {
+    const int s = blockIdx.y, words = 21 * nb, k = blockIdx.x * SB_BLOCK + threadIdx.x;
+    const int *S = seg + (size_t)s * SB_SEG_INTS;
+    const int chunk0 = S[SEG_CHUNK0], nchunk = S[SEG_NCHUNK];
+    if (nchunk < 2 || k >= words) return;
+    const int f = k % 7;
+    const int *p = part + (size_t)chunk0 * words + k;
+    int acc = p[0];
+    for (int c = 1; c < nchunk; c++) {
+        const int v = p[(size_t)c * words];
+        acc = f == 0 ? acc + v : (f < 4 ? min(acc, v) : max(acc, v));
+    }
+    segbins[(size_t)s * words + k] = acc;
 }
 
-__global__ __launch_bounds__(SB_BLOCK) void sb_pred_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
-                                                          const float *__restrict__ pct, int nb, const int *__restrict__ sw,
-                                                          const int *__restrict__ dec, int *__restrict__ pred) {
-    const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int s = seg[i];
-    int p = 0;
-    if (s >= 0) {
-        const int a = dec[s * 4 + 0];
-        if (a < 0) p = i < dec[s * 4 + 2];
+__global__ __launch_bounds__(SB_BLOCK) void sb_choose_kernel(const int *__restrict__ seg, int nb, int CH, const int *__restrict__ part,
+                                                            const int *__restrict__ segbins, int level, int nextbuf, int *__restrict__ dec,
+                                                            int *__restrict__ ch_left, int *__restrict__ tasks, int *__restrict__ meta,
+                                                            MptVec4 *__restrict__ fnode) {
+    extern __shared__ int lb[];                       // the segment's bins [3][nb][7], then (same words) the chunks' left counts
+    __shared__ float w_cost[3];
+    __shared__ int w_k[3], w_q[3], w_dec[3];          // w_dec: axis, q, m
+    const int s = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int *S = seg + (size_t)s * SB_SEG_INTS;
+    const int b = S[SEG_B], e = S[SEG_E], me = S[SEG_NODE], par = S[SEG_PAR], chunk0 = S[SEG_CHUNK0], nchunk = S[SEG_NCHUNK];
+    const int words = 21 * nb;
+    {
+        const int *src = nchunk == 1 ? part + (size_t)chunk0 * words : segbins + (size_t)s * words;
+        for (int k = tid; k < words; k += SB_BLOCK) lb[k] = src[k];
+    }
+    __syncthreads();
+    if (wave < 3) {
+        float cost; int k, q;
+        sb_axis_best(lb + wave * nb * 7, nb, lane, cost, k, q);
+        if (lane == 0) { w_cost[wave] = cost; w_k[wave] = k; w_q[wave] = q; }
+    } else if (par >= 0) {
+        // the node's own box (every triangle is in exactly one bin of axis 0) goes into its parent's record
+        SbAgg own; sb_agg_clear(own);
+        for (int q = lane; q < nb; q += 64) sb_agg_add_bin(own, lb + q * 7);
+        for (int d = 32; d > 0; d >>= 1)
+            for (int r = 0; r < 3; r++) { own.l[r] = fminf(own.l[r], __shfl_xor(own.l[r], d)); own.h[r] = fmaxf(own.h[r], __shfl_xor(own.h[r], d)); }
+        if (lane == 0) sb_write_child(fnode, par, own.l, own.h, me);
+    }
+    __syncthreads();
+    const int cnt = e - b;
+    if (tid == 0) {
+        float best = INFINITY; int axis = -1, bk = 0, bq = 0;
+        for (int a = 0; a < 3; a++)
+            if (w_k[a] >= 0 && w_cost[a] < best) { best = w_cost[a]; axis = a; bk = w_k[a]; bq = w_q[a]; }
+        const int m = axis < 0 ? b + cnt / 2 : b + bk;          // all centres equal (or no finite cost): halve the range
+        w_dec[0] = axis; w_dec[1] = bq; w_dec[2] = m;
+        int *D = dec + (size_t)s * SB_DEC_INTS;
+        D[DEC_AXIS] = axis; D[DEC_Q] = bq; D[DEC_M] = m;
+        const int node[2] = { me + 1, me + (m - b) }, lo_[2] = { b, m }, hi_[2] = { m, e };
+        for (int k = 0; k < 2; k++) {
+            const int sz = hi_[k] - lo_[k];
+            int flag = 0;
+            if (sz > SB_K) flag = 1;                             // a segment of the next level (numbered by the plan kernel)
+            else if (sz >= 2) {
+                const int t = atomicAdd(meta + META_NTASK, 1);
+                int *T = tasks + (size_t)t * SB_TASK_INTS;
+                T[0] = lo_[k]; T[1] = hi_[k]; T[2] = node[k]; T[3] = me * 2 + k; T[4] = level + 1; T[5] = nextbuf; T[6] = 0; T[7] = 0;
+            }
+            D[DEC_CHILD0 + k] = flag;
+        }
+        // ids of the children that are nodes; a child that is a single triangle writes ~slot over its id in the scatter pass
+        fnode[(size_t)me * 4 + 3] = { __int_as_float(node[0]), __int_as_float(node[1]), 0.f, 0.f };
+        atomicMax(meta + META_DEPTH, level);
+    }
+    __syncthreads();
+    // how many of every chunk's positions go left: from the chunk's own bin counts; ch_left = their exclusive prefix sum
+    const int axis = w_dec[0], bq = w_dec[1], m = w_dec[2];
+    int *lc = lb;                                                // (the bins are done with)
+    const bool in_lds = nchunk <= words;
+    __syncthreads();
+    for (int c = wave; c < nchunk; c += SB_BLOCK / 64) {
+        const int cstart = b + c * CH, ccnt = min(CH, e - cstart);
+        int left = 0;
+        if (axis < 0) left = min(max(m - cstart, 0), ccnt);
         else {
-            const int *w = sw + (size_t)s * SB_SEG_WORDS(nb);
-            const float cl = sb_ord2f(w[a]), ch = sb_ord2f(w[3 + a]);
-            const float scale = nb / (ch - cl);
-            p = sb_bin_of(pct[(size_t)idx[i] * 3 + a], cl, scale, nb) < dec[s * 4 + 1];
+            const int *p = part + (size_t)(chunk0 + c) * words + (size_t)axis * nb * 7;
+            for (int q = lane; q < bq; q += 64) left += p[q * 7];
+            for (int d = 32; d > 0; d >>= 1) left += __shfl_xor(left, d);
         }
+        if (lane == 0) { if (in_lds) lc[c] = left; else ch_left[chunk0 + c] = left; }
     }
-    pred[i] = p;
-}
-
-__global__ __launch_bounds__(SB_BLOCK) void sb_scatter_kernel(int n, const int *__restrict__ idx, const int *__restrict__ seg,
-                                                             const int *__restrict__ pred, const int *__restrict__ pscan,
-                                                             const int *__restrict__ sb, const int *__restrict__ se,
-                                                             const int *__restrict__ snode, const int *__restrict__ dec,
-                                                             const int *__restrict__ flag, const int *__restrict__ foff,
-                                                             int *__restrict__ child, int *__restrict__ idx2, int *__restrict__ seg2) {
-    const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int s = seg[i], slot = idx[i];
-    if (s < 0) { idx2[i] = slot; seg2[i] = -1; return; }
-    const int b = sb[s], e = se[s], m = dec[s * 4 + 2], me = snode[s];
-    const int left_before = pscan[i] - pscan[b];
-    const int k = pred[i] ? 0 : 1;
-    const int dest = k == 0 ? b + left_before : m + ((i - b) - left_before);
-    idx2[dest] = slot;
-    const int sz = k == 0 ? m - b : e - m;
-    if (sz == 1) child[(size_t)me * 2 + k] = ~slot;
-    seg2[dest] = flag[2 * s + k] ? foff[2 * s + k] : -1;
-}
-
-// one lane per small segment: exact sweep SAH (tree_build.cpp SahBuild::split, the path for ranges <= 8192) down to the leaves
-__global__ __launch_bounds__(64) void sb_small_kernel(int nsmall, const int *__restrict__ small, int *__restrict__ idx,
-                                                     const float *__restrict__ pct, const float *__restrict__ plo,
-                                                     const float *__restrict__ phi, int *__restrict__ child, float *__restrict__ blo,
-                                                     float *__restrict__ bhi, int *__restrict__ counters) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= nsmall) return;
-    const int b0 = small[t * 4 + 0], e0 = small[t * 4 + 1];
-    int ids[SB_SMALL];
-    for (int k = 0; k < e0 - b0; k++) ids[k] = idx[b0 + k];
-    int stb[SB_SMALL], ste[SB_SMALL], stn[SB_SMALL], std_[SB_SMALL];
-    int sp = 0, maxdep = 0;
-    stb[0] = 0; ste[0] = e0 - b0; stn[0] = small[t * 4 + 2]; std_[0] = small[t * 4 + 3]; sp = 1;
-    while (sp > 0) {
-        sp--;
-        const int b = stb[sp], e = ste[sp], me = stn[sp], dep = std_[sp], cnt = e - b;
-        maxdep = max(maxdep, dep);
-        float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
-        float cl[3] = { INFINITY, INFINITY, INFINITY }, ch[3] = { -INFINITY, -INFINITY, -INFINITY };
-        for (int q = b; q < e; q++)
-            for (int a = 0; a < 3; a++) {
-                l[a] = fminf(l[a], plo[(size_t)ids[q] * 3 + a]); h[a] = fmaxf(h[a], phi[(size_t)ids[q] * 3 + a]);
-                cl[a] = fminf(cl[a], pct[(size_t)ids[q] * 3 + a]); ch[a] = fmaxf(ch[a], pct[(size_t)ids[q] * 3 + a]);
-            }
-        for (int a = 0; a < 3; a++) { blo[(size_t)me * 3 + a] = l[a]; bhi[(size_t)me * 3 + a] = h[a]; }
-        float best = INFINITY;
-        int best_axis = -1, best_k = -1;
-        int ord[SB_SMALL];
-        float rarea[SB_SMALL];
-        for (int a = 0; a < 3; a++) {
-            if (!(ch[a] > cl[a])) continue;
-            for (int q = 0; q < cnt; q++) {                        // insertion sort by (centre, slot): std::sort on pairs
-                const int s = ids[b + q];
-                const float key = pct[(size_t)s * 3 + a];
-                int p = q;
-                while (p > 0) {
-                    const int o = ord[p - 1];
-                    const float ko = pct[(size_t)o * 3 + a];
-                    if (ko < key || (ko == key && o < s)) break;
-                    ord[p] = o; p--;
-                }
-                ord[p] = s;
-            }
-            float rl[3] = { INFINITY, INFINITY, INFINITY }, rh[3] = { -INFINITY, -INFINITY, -INFINITY };
-            for (int q = cnt - 1; q > 0; q--) {
-                const int s = ord[q];
-                for (int r = 0; r < 3; r++) { rl[r] = fminf(rl[r], plo[(size_t)s * 3 + r]); rh[r] = fmaxf(rh[r], phi[(size_t)s * 3 + r]); }
-                rarea[q] = sb_half_area(rl, rh);
-            }
-            for (int r = 0; r < 3; r++) { rl[r] = INFINITY; rh[r] = -INFINITY; }
-            for (int k = 1; k < cnt; k++) {
-                const int s = ord[k - 1];
-                for (int r = 0; r < 3; r++) { rl[r] = fminf(rl[r], plo[(size_t)s * 3 + r]); rh[r] = fmaxf(rh[r], phi[(size_t)s * 3 + r]); }
-                const float cost = sb_half_area(rl, rh) * k + rarea[k] * (cnt - k);
-                if (cost < best) { best = cost; best_axis = a; best_k = k; }
-            }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < nchunk; c++) {
+            const int v = in_lds ? lc[c] : ch_left[chunk0 + c];
+            ch_left[chunk0 + c] = run; run += v;
         }
-        int m = b + cnt / 2;
-        if (best_axis >= 0) {
-            const int a = best_axis;
-            for (int q = 0; q < cnt; q++) {
-                const int s = ids[b + q];
-                const float key = pct[(size_t)s * 3 + a];
-                int p = q;
-                while (p > 0) {
-                    const int o = ord[p - 1];
-                    const float ko = pct[(size_t)o * 3 + a];
-                    if (ko < key || (ko == key && o < s)) break;
-                    ord[p] = o; p--;
-                }
-                ord[p] = s;
-            }
-            for (int q = 0; q < cnt; q++) ids[b + q] = ord[q];
-            m = b + best_k;
-        }
-        const int left = me + 1, right = me + (m - b);
-        if (m - b == 1) child[(size_t)me * 2 + 0] = ~ids[b];
-        else { child[(size_t)me * 2 + 0] = left; stb[sp] = b; ste[sp] = m; stn[sp] = left; std_[sp] = dep + 1; sp++; }
-        if (e - m == 1) child[(size_t)me * 2 + 1] = ~ids[m];
-        else { child[(size_t)me * 2 + 1] = right; stb[sp] = m; ste[sp] = e; stn[sp] = right; std_[sp] = dep + 1; sp++; }
+        if (run != m - b) atomicOr(meta + META_BAD, 1);          // (cannot happen: the bins and the split count the same triangles)
     }
-    atomicMax(counters + 1, maxdep);
 }
 
-// the 64-byte traversal record: {c0.lo.x, c1.lo.x, c0.hi.x, c1.hi.x} {y} {z} {id0, id1, 0, 0}
-__global__ __launch_bounds__(SB_BLOCK) void sb_pack_kernel(int ni, const int *__restrict__ child, const float *__restrict__ blo,
-                                                          const float *__restrict__ bhi, const float *__restrict__ plo,
-                                                          const float *__restrict__ phi, MptVec4 *__restrict__ fnode) {
-    const int i = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (i >= ni) return;
-    float l[2][3], h[2][3];
-    int id[2];
+// ------------------------------------------------------------------ top phase: plan
+// exclusive prefix sum over the 1024 threads of the (only) workgroup; returns the total in every thread
+__device__ __forceinline__ int sb_block_scan_1024(int v, int *total, int *wsum /* [16] LDS */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 16; w++) { const int x = wsum[w]; if (w < wave) base += x; tot += x; }
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void sb_plan_kernel(int nseg, const int *__restrict__ seg, int *__restrict__ dec,
+                                                      int *__restrict__ seg_next, int *__restrict__ ch_seg, int *__restrict__ meta) {
+    __shared__ int wsum[16];
+    __shared__ int sh_nb, sh_ch;
+    const int tid = threadIdx.x;
+    // 1. number the children that go on as segments: parents in order, left before right
+    int carry = 0;
+    for (int base = 0; base < nseg; base += 1024) {
+        const int s = base + tid;
+        int f0 = 0, f1 = 0;
+        if (s < nseg) { f0 = dec[(size_t)s * SB_DEC_INTS + DEC_CHILD0]; f1 = dec[(size_t)s * SB_DEC_INTS + DEC_CHILD1]; }
+        int tot;
+        const int at = carry + sb_block_scan_1024(f0 + f1, &tot, wsum);
+        if (s < nseg) {
+            const int *S = seg + (size_t)s * SB_SEG_INTS;
+            const int b = S[SEG_B], e = S[SEG_E], me = S[SEG_NODE], m = dec[(size_t)s * SB_DEC_INTS + DEC_M];
+            dec[(size_t)s * SB_DEC_INTS + DEC_CHILD0] = f0 ? at : -1;
+            dec[(size_t)s * SB_DEC_INTS + DEC_CHILD1] = f1 ? at + f0 : -1;
+            for (int k = 0; k < 2; k++) {
+                if (!(k ? f1 : f0)) continue;
+                int *N = seg_next + (size_t)(at + (k ? f0 : 0)) * SB_SEG_INTS;
+                N[SEG_B] = k ? m : b; N[SEG_E] = k ? e : m; N[SEG_NODE] = k ? me + (m - b) : me + 1; N[SEG_PAR] = me * 2 + k;
+                for (int r = 0; r < 6; r++) N[SEG_CB + r] = r < 3 ? 0x7fffffff : (int)0x80000000;
+            }
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    const int nnext = carry;
+    if (tid == 0) { sh_nb = sb_bins_for(nnext); sh_ch = sb_chunk_for(sh_nb); }
+    __syncthreads();
+    const int CH = sh_ch;
+    // 2. chunks of every new segment
+    carry = 0;
+    for (int base = 0; base < nnext; base += 1024) {
+        const int s = base + tid;
+        int nch = 0;
+        if (s < nnext) nch = (seg_next[(size_t)s * SB_SEG_INTS + SEG_E] - seg_next[(size_t)s * SB_SEG_INTS + SEG_B] + CH - 1) / CH;
+        int tot;
+        const int at = carry + sb_block_scan_1024(nch, &tot, wsum);
+        if (s < nnext) { seg_next[(size_t)s * SB_SEG_INTS + SEG_CHUNK0] = at; seg_next[(size_t)s * SB_SEG_INTS + SEG_NCHUNK] = nch; }
+        carry += tot;
+        __syncthreads();
+    }
+    const int nchunks = carry;
+    __threadfence_block();
+    __syncthreads();
+    // 3. chunk -> segment: the last segment whose first chunk is not after it
+    for (int j = tid; j < nchunks; j += 1024) {
+        int lo = 0, hi = nnext - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seg_next[(size_t)mid * SB_SEG_INTS + SEG_CHUNK0] <= j) lo = mid; else hi = mid - 1;
+        }
+        ch_seg[j] = lo;
+    }
+    if (tid == 0) { meta[META_NSEG] = nnext; meta[META_NCHUNK] = nchunks; meta[META_NB] = sh_nb; meta[META_CH] = CH; }
+}
+
+// ------------------------------------------------------------------ top phase: scatter
+__global__ __launch_bounds__(SB_BLOCK) void sb_scatter_kernel(const MptVec4 *__restrict__ src, MptVec4 *__restrict__ dst,
+                                                             const int *__restrict__ seg, const int *__restrict__ ch_seg,
+                                                             const int *__restrict__ dec, const int *__restrict__ ch_left, int nb, int CH,
+                                                             int *__restrict__ seg_next, MptVec4 *__restrict__ fnode) {
+    __shared__ int wtot[2][SB_BLOCK / 64];
+    const int j = blockIdx.x, s = ch_seg[j], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *S = seg + (size_t)s * SB_SEG_INTS, *D = dec + (size_t)s * SB_DEC_INTS;
+    const int b = S[SEG_B], e = S[SEG_E], me = S[SEG_NODE];
+    const int axis = D[DEC_AXIS], bq = D[DEC_Q], m = D[DEC_M];
+    const int child[2] = { D[DEC_CHILD0], D[DEC_CHILD1] }, sz[2] = { m - b, e - m };
+    const int start = b + (j - S[SEG_CHUNK0]) * CH, end = min(start + CH, e);
+    float cl = 0.f, scale = 0.f;
+    if (axis >= 0) { cl = sb_ord2f(S[SEG_CB + axis]); scale = sb_scale(nb, cl, sb_ord2f(S[SEG_CB + 3 + axis])); }
+    const int lbase = ch_left[j];
+    int run = 0, it = 0;
+    int cb[2][6];
+    for (int k = 0; k < 2; k++) for (int r = 0; r < 6; r++) cb[k][r] = r < 3 ? 0x7fffffff : (int)0x80000000;
+    for (int t0 = start; t0 < end; t0 += SB_BLOCK, it ^= 1) {
+        const int i = t0 + tid;
+        const bool valid = i < end;
+        MptVec4 lo = { 0.f, 0.f, 0.f, 0.f }, hi = lo;
+        bool left = false;
+        if (valid) {
+            lo = src[(size_t)i * 2]; hi = src[(size_t)i * 2 + 1];
+            if (axis < 0) left = i < m;
+            else {
+                const float c = axis == 0 ? 0.5f * (lo.x + hi.x) : (axis == 1 ? 0.5f * (lo.y + hi.y) : 0.5f * (lo.z + hi.z));
+                left = sb_bin_of(c, cl, scale, nb) < bq;
+            }
+        }
+        const unsigned long long bal = __ballot(left);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[it][wave] = __popcll(bal);
+        __syncthreads();
+        int wbase = 0, tile = 0;
+        for (int w = 0; w < SB_BLOCK / 64; w++) { const int x = wtot[it][w]; if (w < wave) wbase += x; tile += x; }
+        if (valid) {
+            const int lr = lbase + run + wbase + before;           // positions of this segment before i that go left
+            const int k = left ? 0 : 1;
+            const int dest = left ? b + lr : m + (i - b) - lr;
+            dst[(size_t)dest * 2] = lo; dst[(size_t)dest * 2 + 1] = hi;
+            const float l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
+            if (sz[k] == 1) sb_write_child(fnode, me * 2 + k, l, h, ~__float_as_int(lo.w));
+            else if (child[k] >= 0)
+                for (int a = 0; a < 3; a++) {
+                    const int c = sb_f2ord(0.5f * (l[a] + h[a]));
+                    cb[k][a] = min(cb[k][a], c); cb[k][3 + a] = max(cb[k][3 + a], c);
+                }
+        }
+        run += tile;
+    }
+    // centre bounds of the children that go on as segments (a wave's lanes, then one atomic per word and wave)
     for (int k = 0; k < 2; k++) {
-        id[k] = child[(size_t)i * 2 + k];
-        const float *sl = id[k] < 0 ? plo + (size_t)(~id[k]) * 3 : blo + (size_t)id[k] * 3;
-        const float *sh = id[k] < 0 ? phi + (size_t)(~id[k]) * 3 : bhi + (size_t)id[k] * 3;
-        for (int a = 0; a < 3; a++) { l[k][a] = sl[a]; h[k][a] = sh[a]; }
+        if (child[k] < 0) continue;                                // (uniform over the workgroup)
+        for (int r = 0; r < 6; r++)
+            for (int off = 32; off > 0; off >>= 1) {
+                const int o = __shfl_xor(cb[k][r], off);
+                cb[k][r] = r < 3 ? min(cb[k][r], o) : max(cb[k][r], o);
+            }
+        if (lane == 0) {
+            int *N = seg_next + (size_t)child[k] * SB_SEG_INTS + SEG_CB;
+            for (int r = 0; r < 6; r++) {
+                if (r < 3) { if (cb[k][r] != 0x7fffffff) atomicMin(N + r, cb[k][r]); }
+                else if (cb[k][r] != (int)0x80000000) atomicMax(N + r, cb[k][r]);
+            }
+        }
     }
-    for (int a = 0; a < 3; a++) fnode[(size_t)i * 4 + a] = { l[0][a], l[1][a], h[0][a], h[1][a] };
-    fnode[(size_t)i * 4 + 3] = { __int_as_float(id[0]), __int_as_float(id[1]), 0.f, 0.f };
 }
 
-MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n) { return (size_t)n / (SB_SMALL + 1) + 2; }
-// words of segment workspace: enough for every level's (segments x words at that level's bin count)
-// A level with more than SB_MINBINS bins keeps segments x bins within SB_BIN_BUDGET (the rule in mpt_sah_build); once the
-// segments outnumber SB_BIN_BUDGET / (2 SB_MINBINS) the bin count stays at SB_MINBINS and the level needs segments x
-// SB_SEG_WORDS(SB_MINBINS) words, up to the segment capacity: the larger of the two bounds (round-3 ADVICE: the first alone
-// is too small above ~1.08 M faces).
-MPT_KERNEL_API size_t mpt_sah_level_words(size_t nseg, int *nb_out) {
-    int nb = SB_MINBINS;
-    while (nb < SB_MAXBINS && nseg * (size_t)(2 * nb) <= (size_t)SB_BIN_BUDGET) nb *= 2;
-    if (nb_out) *nb_out = nb;
-    return nseg * SB_SEG_WORDS(nb);
+// ------------------------------------------------------------------ finish: one wave per task, exact sweep in LDS
+struct SfBox { float l[3], h[3]; };
+__device__ __forceinline__ void sf_clear(SfBox &b) { for (int r = 0; r < 3; r++) { b.l[r] = INFINITY; b.h[r] = -INFINITY; } }
+__device__ __forceinline__ void sf_add(SfBox &a, const SfBox &b) {
+    for (int r = 0; r < 3; r++) { a.l[r] = fminf(a.l[r], b.l[r]); a.h[r] = fmaxf(a.h[r], b.h[r]); }
 }
-MPT_KERNEL_API size_t mpt_sah_seg_words(int n) {
-    const size_t sc = mpt_sah_seg_capacity(n);
-    const size_t binned = 12 * sc + 27 * (size_t)SB_BIN_BUDGET + SB_SEG_WORDS(SB_MAXBINS);
-    const size_t deep = sc * SB_SEG_WORDS(SB_MINBINS);
-    return binned > deep ? binned : deep;
+__device__ __forceinline__ SfBox sf_shfl_up(const SfBox &a, int d) {
+    SfBox o; for (int r = 0; r < 3; r++) { o.l[r] = __shfl_up(a.l[r], d); o.h[r] = __shfl_up(a.h[r], d); } return o;
 }
-MPT_KERNEL_API hipError_t mpt_sah_scan_bytes(int n, size_t *bytes) {
-    int *p = nullptr;
-    return rocprim::exclusive_scan(nullptr, *bytes, p, p, 0, (size_t)std::max(n, 2), rocprim::plus<int>());
+__device__ __forceinline__ SfBox sf_shfl_down(const SfBox &a, int d) {
+    SfBox o; for (int r = 0; r < 3; r++) { o.l[r] = __shfl_down(a.l[r], d); o.h[r] = __shfl_down(a.h[r], d); } return o;
+}
+// Segmented scans over the wave's lanes.  A lane's aggregate is (f, v): v = the union over its positions from its end of the
+// lane up to the first segment boundary inside it, f = there is such a boundary.  The carry a lane receives is what the
+// positions between its near end and its first boundary still miss.
+__device__ __forceinline__ SfBox sf_carry_from_below(bool f, SfBox v, int lane) {       // prefix direction: from the lower lanes
+    for (int d = 1; d < 64; d <<= 1) {
+        const SfBox ov = sf_shfl_up(v, d);
+        const int of = __shfl_up((int)f, d);
+        if (lane >= d && !f) { sf_add(v, ov); f = of != 0; }
+    }
+    SfBox c = sf_shfl_up(v, 1);
+    if (lane == 0) sf_clear(c);
+    return c;
+}
+__device__ __forceinline__ SfBox sf_carry_from_above(bool f, SfBox v, int lane) {       // suffix direction: from the higher lanes
+    for (int d = 1; d < 64; d <<= 1) {
+        const SfBox ov = sf_shfl_down(v, d);
+        const int of = __shfl_down((int)f, d);
+        if (lane + d < 64 && !f) { sf_add(v, ov); f = of != 0; }
+    }
+    SfBox c = sf_shfl_down(v, 1);
+    if (lane == 63) sf_clear(c);
+    return c;
 }
 
-// verts [3n][8] and leaf [n] on the device (the LBVH build's); writes fnode [n-1][4] and *depth.  Needs n > SB_SMALL.
-MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipStream_t stream) {
-    const int n = B->n, ni = n - 1;
-    if (n <= SB_SMALL) return hipErrorInvalidValue;
-    hipError_t e;
-    const int gp = (n + SB_BLOCK - 1) / SB_BLOCK;
-    if ((e = hipMemsetAsync(B->counters, 0, 4 * sizeof(int), stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(sb_prims_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, B->verts, B->leaf, n, B->plo, B->phi, B->pct, B->idx[0], B->seg[0]);
-    int seed[3] = { 0, n, 0 };
-    if ((e = hipMemcpyAsync(B->sb[0], &seed[0], sizeof(int), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(B->se[0], &seed[1], sizeof(int), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(B->snode[0], &seed[2], sizeof(int), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    int nseg = 1, cur = 0, level = 1;
-    size_t scan_bytes = B->scan_bytes;
-    while (nseg > 0) {
-        if (level > 62) return hipErrorInvalidValue;
-        const int gs = (nseg + SB_BLOCK - 1) / SB_BLOCK;
-        // bins per axis at this level: as many as the budget allows for this many segments
-        int nb = SB_MINBINS;
-        const size_t words = mpt_sah_level_words((size_t)nseg, &nb);
-        if (words > B->seg_words) return hipErrorOutOfMemory;     // (cannot happen with a workspace of mpt_sah_seg_words(n))
-        hipLaunchKernelGGL(sb_reset_kernel, dim3((unsigned)((words + SB_BLOCK - 1) / SB_BLOCK)), dim3(SB_BLOCK), 0, stream, nseg, nb, B->segw);
-        hipLaunchKernelGGL(sb_bounds_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->plo, B->phi, nb, B->segw);
-        hipLaunchKernelGGL(sb_bin_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, B->plo, B->phi, nb, B->segw);
-        if (nb > 64)
-            hipLaunchKernelGGL(sb_choose_wave_kernel, dim3(nseg), dim3(64), 0, stream, nseg, B->sb[cur], B->se[cur], B->snode[cur], nb, B->segw,
-                               level, B->child, B->blo, B->bhi, B->dec, B->flag, B->small, B->counters);
-        else
-            hipLaunchKernelGGL(sb_choose_kernel, dim3(gs), dim3(SB_BLOCK), 0, stream, nseg, B->sb[cur], B->se[cur], B->snode[cur], nb, B->segw,
-                               level, B->child, B->blo, B->bhi, B->dec, B->flag, B->small, B->counters);
-        if ((e = rocprim::exclusive_scan(B->scan_tmp, scan_bytes, B->flag, B->foff, 0, (size_t)(2 * nseg), rocprim::plus<int>(), stream)) != hipSuccess) return e;
-        int last[2] = { 0, 0 };
-        if ((e = hipMemcpyAsync(&last[0], B->foff + (2 * nseg - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(&last[1], B->flag + (2 * nseg - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(sb_newseg_kernel, dim3(gs), dim3(SB_BLOCK), 0, stream, nseg, B->sb[cur], B->se[cur], B->snode[cur], B->dec, B->flag,
-                           B->foff, B->sb[cur ^ 1], B->se[cur ^ 1], B->snode[cur ^ 1]);
-        hipLaunchKernelGGL(sb_pred_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pct, nb, B->segw, B->dec, B->pred);
-        if ((e = rocprim::exclusive_scan(B->scan_tmp, scan_bytes, B->pred, B->pscan, 0, (size_t)n, rocprim::plus<int>(), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(sb_scatter_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, n, B->idx[cur], B->seg[cur], B->pred, B->pscan, B->sb[cur],
-                           B->se[cur], B->snode[cur], B->dec, B->flag, B->foff, B->child, B->idx[cur ^ 1], B->seg[cur ^ 1]);
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        nseg = last[0] + last[1];
-        if ((size_t)nseg > mpt_sah_seg_capacity(n)) return hipErrorInvalidValue;
+struct SfLds {
+    float lo[3][SB_K], hi[3][SB_K];          // boxes by local triangle number
+    int slot[SB_K];
+    unsigned short ord[2][3][SB_K];          // per axis: local triangle numbers sorted by (centre, slot), ranges kept contiguous
+    unsigned short pb[SB_K];                 // per position: first position of its range
+    unsigned short se[SB_K];                 // per range start: end of the range
+    int snode[SB_K];                         // per range start: node number; during the sort: the keys
+    int spar[SB_K];                          // per range start: parent * 2 + side
+    int sdec[SB_K];                          // per range start: axis << 16 | left count
+    unsigned char side[SB_K];                // per local triangle: 1 = goes left
+};
+
+__device__ __forceinline__ unsigned sf_key(float c) {           // order-preserving, -0 == +0
+    const unsigned u = (unsigned)__float_as_int(c + 0.0f);
+    return (u & 0x80000000u) ? ~u : u | 0x80000000u;
+}
+
+__global__ __launch_bounds__(64) void sb_finish_kernel(int ntasks, const int *__restrict__ tasks, const MptVec4 *__restrict__ prim0,
+                                                      const MptVec4 *__restrict__ prim1, MptVec4 *__restrict__ fnode,
+                                                      int *__restrict__ meta) {
+    __shared__ SfLds L;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= ntasks) return;
+    const int *T = tasks + (size_t)blockIdx.x * SB_TASK_INTS;
+    const int b0 = T[0], c = T[1] - T[0], node0 = T[2], par0 = T[3], level0 = T[4];
+    const MptVec4 *prim = T[5] ? prim1 : prim0;
+    int kp = 64;                                                  // positions that take part (a power of two >= c, >= 64)
+    while (kp < c) kp <<= 1;
+    for (int i = lane; i < SB_K; i += 64) {
+        float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
+        int sl = 0x7fffffff;
+        if (i < c) {
+            const MptVec4 lo = prim[(size_t)(b0 + i) * 2], hi = prim[(size_t)(b0 + i) * 2 + 1];
+            l[0] = lo.x; l[1] = lo.y; l[2] = lo.z; h[0] = hi.x; h[1] = hi.y; h[2] = hi.z; sl = __float_as_int(lo.w);
+        }
+        for (int a = 0; a < 3; a++) { L.lo[a][i] = l[a]; L.hi[a][i] = h[a]; }
+        L.slot[i] = sl;
+        L.pb[i] = (unsigned short)(i < c ? 0 : i);               // positions past the task's triangles: ranges of one, inert
+        L.se[i] = (unsigned short)(i + 1);
+    }
+    if (lane == 0) { L.se[0] = (unsigned short)c; L.snode[0] = node0; L.spar[0] = par0; }
+    __syncthreads();
+    // ---- the three sorted orders: bitonic over kp positions, keys (centre, slot); the padding sorts last
+    unsigned *key = (unsigned *)L.sdec;
+    for (int a = 0; a < 3; a++) {
+        unsigned short *od = L.ord[0][a];
+        for (int i = lane; i < kp; i += 64) {
+            key[i] = i < c ? sf_key(0.5f * (L.lo[a][i] + L.hi[a][i])) : 0xffffffffu;
+            od[i] = (unsigned short)i;
+        }
+        __syncthreads();
+        for (int k = 2; k <= kp; k <<= 1)
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                for (int t = lane; t < (kp >> 1); t += 64) {
+                    const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), l2 = i | jj;
+                    const bool up = (i & k) == 0;
+                    const unsigned ka = key[i], kb = key[l2];
+                    const unsigned short ia = od[i], ib = od[l2];
+                    const bool gt = ka > kb || (ka == kb && L.slot[ia] > L.slot[ib]);
+                    if (gt == up) { key[i] = kb; key[l2] = ka; od[i] = ib; od[l2] = ia; }
+                }
+                __syncthreads();
+            }
+        for (int i = kp + lane; i < SB_K; i += 64) od[i] = (unsigned short)i;
+        __syncthreads();
+    }
+    // ---- level by level
+    int cur = 0, level = level0, deepest = 0;
+    const int i0 = lane * SB_E;
+    for (;;) {
+        // the ranges of this lane's positions
+        int pb[SB_E], pe[SB_E];
+        unsigned head = 0, tail = 0, act = 0;
+#pragma unroll
+        for (int j = 0; j < SB_E; j++) {
+            pb[j] = L.pb[i0 + j]; pe[j] = L.se[pb[j]];
+            if (i0 + j == pb[j]) head |= 1u << j;
+            if (i0 + j == pe[j] - 1) tail |= 1u << j;
+            if (pe[j] - pb[j] >= 2) act |= 1u << j;
+        }
+        if (__ballot(act != 0) == 0ull) break;
+        deepest = level;
+        float best[SB_E]; int bestak[SB_E];
+#pragma unroll
+        for (int j = 0; j < SB_E; j++) { best[j] = INFINITY; bestak[j] = -1; }
+        for (int a = 0; a < 3; a++) {
+            const unsigned short *od = L.ord[cur][a];
+            SfBox bx[SB_E];
+#pragma unroll
+            for (int j = 0; j < SB_E; j++) {
+                const int p = od[i0 + j];
+                for (int r = 0; r < 3; r++) { bx[j].l[r] = L.lo[r][p]; bx[j].h[r] = L.hi[r][p]; }
+            }
+            // suffix: S(i) = union of the boxes at i .. end of the range; its area
+            float sarea[SB_E];
+            {
+                SfBox run; sf_clear(run);
+                SfBox sfx[SB_E];
+#pragma unroll
+                for (int j = SB_E - 1; j >= 0; j--) {
+                    if (tail >> j & 1) run = bx[j]; else sf_add(run, bx[j]);
+                    sfx[j] = run;
+                }
+                const SfBox carry = sf_carry_from_above(tail != 0, run, lane);
+                bool seen = false;
+#pragma unroll
+                for (int j = SB_E - 1; j >= 0; j--) {
+                    if (tail >> j & 1) seen = true;
+                    if (!seen) sf_add(sfx[j], carry);
+                    sarea[j] = sb_half_area(sfx[j].l, sfx[j].h);
+                    // a range's own box (at its first position) goes into its parent's record
+                    if (a == 0 && (head >> j & 1) && (act >> j & 1)) {
+                        const int par = L.spar[pb[j]];
+                        if (par >= 0) sb_write_child(fnode, par, sfx[j].l, sfx[j].h, L.snode[pb[j]]);
+                    }
+                }
+            }
+            // prefix (exclusive): P(i) = union of the boxes at start of the range .. i - 1; the cost of the split in front of i
+            float cost[SB_E];
+            {
+                SfBox run; sf_clear(run);
+                SfBox pfx[SB_E];
+#pragma unroll
+                for (int j = 0; j < SB_E; j++) {
+                    if (head >> j & 1) sf_clear(run);
+                    pfx[j] = run;
+                    sf_add(run, bx[j]);
+                }
+                const SfBox carry = sf_carry_from_below(head != 0, run, lane);
+                bool seen = false;
+#pragma unroll
+                for (int j = 0; j < SB_E; j++) {
+                    if (head >> j & 1) seen = true;
+                    if (!seen) sf_add(pfx[j], carry);
+                    cost[j] = INFINITY;
+                    if ((act >> j & 1) && !(head >> j & 1)) {
+                        const int k = i0 + j - pb[j];
+                        cost[j] = sb_half_area(pfx[j].l, pfx[j].h) * k + sarea[j] * (pe[j] - pb[j] - k);
+                    }
+                }
+            }
+            // the axis takes part in a range only if the range's centres differ along it (the host pass's rule)
+            // segmented minimum of (cost, position), in position order, strict: the first of equal costs stays
+            {
+                float mc = INFINITY; int mp = -1;
+                float mcs[SB_E]; int mps[SB_E];
+#pragma unroll
+                for (int j = 0; j < SB_E; j++) {
+                    if (head >> j & 1) { mc = INFINITY; mp = -1; }
+                    if (cost[j] < mc) { mc = cost[j]; mp = i0 + j; }
+                    mcs[j] = mc; mps[j] = mp;
+                }
+                bool f = head != 0;
+                float vc = mc; int vp = mp;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const float oc = __shfl_up(vc, d); const int op = __shfl_up(vp, d), of = __shfl_up((int)f, d);
+                    if (lane >= d && !f) {
+                        if (op >= 0 && (vp < 0 || oc <= vc)) { vc = oc; vp = op; }     // the lower lanes' positions come first: they win ties
+                        f = of != 0;
+                    }
+                }
+                float cc = __shfl_up(vc, 1); int cp = __shfl_up(vp, 1);
+                if (lane == 0) { cc = INFINITY; cp = -1; }
+                bool seen = false;
+#pragma unroll
+                for (int j = 0; j < SB_E; j++) {
+                    if (head >> j & 1) seen = true;
+                    if (!seen && cp >= 0 && (mps[j] < 0 || cc <= mcs[j])) { mcs[j] = cc; mps[j] = cp; }
+                    if ((tail >> j & 1) && (act >> j & 1) && mps[j] >= 0) {
+                        // (centres along this axis all equal: the axis is skipped)
+                        const int pf = od[pb[j]], pl = od[pe[j] - 1];
+                        const float cf = 0.5f * (L.lo[a][pf] + L.hi[a][pf]), cl_ = 0.5f * (L.lo[a][pl] + L.hi[a][pl]);
+                        if (cl_ > cf && mcs[j] < best[j]) { best[j] = mcs[j]; bestak[j] = (a << 16) | (mps[j] - pb[j]); }
+                    }
+                }
+            }
+        }
+        // ---- decisions (at the ranges' last positions), then the side of every triangle
+#pragma unroll
+        for (int j = 0; j < SB_E; j++)
+            if ((tail >> j & 1) && (act >> j & 1))
+                L.sdec[pb[j]] = bestak[j] >= 0 ? bestak[j] : (pe[j] - pb[j]) / 2;      // no split found: halve the range in the order of axis 0
+        __syncthreads();
+        int kk[SB_E];
+#pragma unroll
+        for (int j = 0; j < SB_E; j++) {
+            kk[j] = 0;
+            if (act >> j & 1) {
+                const int ak = L.sdec[pb[j]];
+                kk[j] = ak & 0xffff;
+                L.side[L.ord[cur][ak >> 16][i0 + j]] = (unsigned char)(i0 + j - pb[j] < kk[j]);
+            }
+        }
+        __syncthreads();
+        // ---- stable partition of the three orders
+        for (int a = 0; a < 3; a++) {
+            const unsigned short *od = L.ord[cur][a];
+            unsigned short *on = L.ord[cur ^ 1][a];
+            int p[SB_E], lr[SB_E];
+            unsigned sd = 0;
+            int run = 0;
+#pragma unroll
+            for (int j = 0; j < SB_E; j++) {
+                p[j] = od[i0 + j];
+                if (head >> j & 1) run = 0;
+                lr[j] = run;
+                if ((act >> j & 1) && L.side[p[j]]) { sd |= 1u << j; run++; }
+            }
+            bool f = head != 0;
+            int v = run;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int ov = __shfl_up(v, d), of = __shfl_up((int)f, d);
+                if (lane >= d && !f) { v += ov; f = of != 0; }
+            }
+            int carry = __shfl_up(v, 1);
+            if (lane == 0) carry = 0;
+            bool seen = false;
+#pragma unroll
+            for (int j = 0; j < SB_E; j++) {
+                if (head >> j & 1) seen = true;
+                if (!seen) lr[j] += carry;
+                int dest = i0 + j;
+                if (act >> j & 1) dest = (sd >> j & 1) ? pb[j] + lr[j] : pb[j] + kk[j] + (i0 + j - pb[j]) - lr[j];
+                on[dest] = (unsigned short)p[j];
+            }
+        }
+        __syncthreads();
+        // ---- the children: range tables for the next level, single triangles into their parent's record
+        int me[SB_E];
+#pragma unroll
+        for (int j = 0; j < SB_E; j++) me[j] = (act >> j & 1) ? L.snode[pb[j]] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SB_E; j++) {
+            if (!(act >> j & 1)) continue;
+            const int i = i0 + j, b = pb[j], e = pe[j], m = b + kk[j];
+            L.pb[i] = (unsigned short)(i < m ? b : m);
+            if (i == b || i == m) {
+                const int k = i == m ? 1 : 0, end = k ? e : m, node = k ? me[j] + kk[j] : me[j] + 1;
+                L.se[i] = (unsigned short)end;
+                if (end - i >= 2) { L.snode[i] = node; L.spar[i] = me[j] * 2 + k; }
+                else {
+                    const int q = L.ord[cur ^ 1][0][i];
+                    const float l[3] = { L.lo[0][q], L.lo[1][q], L.lo[2][q] }, h[3] = { L.hi[0][q], L.hi[1][q], L.hi[2][q] };
+                    sb_write_child(fnode, me[j] * 2 + k, l, h, ~L.slot[q]);
+                }
+                if (k == 0) {                                      // the pad words of the node's record (ids come from the children)
+                    float *r = (float *)(fnode + (size_t)me[j] * 4);
+                    r[14] = 0.f; r[15] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
         cur ^= 1; level++;
     }
-    int cnt[4] = { 0, 0, 0, 0 };
-    if ((e = hipMemcpyAsync(cnt, B->counters, sizeof cnt, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if (lane == 0 && deepest > 0) atomicMax(meta + META_DEPTH, deepest);
+}
+
+// ------------------------------------------------------------------ driver
+MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n) { return (size_t)n / (SB_K + 1) + 2; }
+MPT_KERNEL_API size_t mpt_sah_chunk_capacity(int n) { return (size_t)n / SB_CHUNK_MIN + mpt_sah_seg_capacity(n) + 2; }
+// words of chunk bins a level can need: a level of nseg segments has at most n / CH + nseg chunks of 21 nb words, with
+// nb / CH <= 1 / 16 and nb x nseg <= the budget (or 32 x nseg at the floor)
+MPT_KERNEL_API size_t mpt_sah_part_words(int n) {
+    const size_t sc = mpt_sah_seg_capacity(n);
+    const size_t segbins = std::max((size_t)SB_BIN_BUDGET, (size_t)SB_MINBINS * sc);
+    return 21 * ((size_t)n / 16 + SB_MAXBINS + segbins);
+}
+// words of per-segment bins a level can need: 21 nb nseg
+MPT_KERNEL_API size_t mpt_sah_segbin_words(int n) {
+    return 21 * std::max((size_t)SB_BIN_BUDGET, (size_t)SB_MINBINS * mpt_sah_seg_capacity(n));
+}
+MPT_KERNEL_API size_t mpt_sah_level_words(int n, size_t nseg, int *nb_out) {
+    const int nb = sb_bins_for((long long)nseg), ch = sb_chunk_for(nb);
+    if (nb_out) *nb_out = nb;
+    return (size_t)21 * nb * ((size_t)n / ch + nseg);
+}
+MPT_KERNEL_API size_t mpt_sah_task_capacity(int n) { return (size_t)n / 2 + 2; }
+// what a level of nseg segments uses: bins per axis, positions per chunk
+MPT_KERNEL_API void mpt_sah_level_shape(long long nseg, int *nb, int *ch) {
+    const int b = sb_bins_for(nseg);
+    if (nb) *nb = b;
+    if (ch) *ch = sb_chunk_for(b);
+}
+MPT_KERNEL_API int mpt_sah_task_max(void) { return SB_K; }
+
+static hipError_t sb_big_lds(const void *fn) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 21 * SB_MAXBINS * (int)sizeof(int));
+}
+
+// verts [3n][8] and leaf [n] on the device (the LBVH build's); writes fnode [n-1][4] and *depth.  Needs n >= 2.
+MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipStream_t stream) {
+    const int n = B->n;
+    if (n < 2) return hipErrorInvalidValue;
+    hipError_t e;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if ((e = sb_big_lds((const void *)sb_bin_kernel)) != hipSuccess) return e;
+        if ((e = sb_big_lds((const void *)sb_choose_kernel)) != hipSuccess) return e;
+        attr_done = true;
+    }
+    int meta[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if ((e = hipMemsetAsync(B->meta, 0, 8 * sizeof(int), stream)) != hipSuccess) return e;
+    int nb = sb_bins_for(1), CH = sb_chunk_for(nb);
+    int seg0[SB_SEG_INTS] = { 0, n, 0, -1, 0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000,
+                              0, (n + CH - 1) / CH, 0, 0, 0, 0 };
+    if ((e = hipMemcpyAsync(B->seg[0], seg0, sizeof seg0, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    const int gp = std::min((n + SB_BLOCK - 1) / SB_BLOCK, 1024);
+    hipLaunchKernelGGL(sb_prims_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, B->verts, B->leaf, n, B->prim[0], B->seg[0]);
+    int ntasks = 0;
+    if (n <= SB_K) {
+        // the whole tree is one task
+        const int task[SB_TASK_INTS] = { 0, n, 0, -1, 1, 0, 0, 0 };
+        if ((e = hipMemcpyAsync(B->tasks, task, sizeof task, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        ntasks = 1;
+    } else {
+        int nseg = 1, nchunks = seg0[SEG_NCHUNK], cur = 0, level = 1;
+        if ((e = hipMemsetAsync(B->ch_seg, 0, (size_t)nchunks * sizeof(int), stream)) != hipSuccess) return e;
+        while (nseg > 0) {
+            if (level > 60) return hipErrorInvalidValue;
+            if ((size_t)nchunks * 21 * nb > B->part_words || (size_t)nseg > B->seg_cap || (size_t)nchunks > B->chunk_cap ||
+                (size_t)nseg * 21 * nb > B->segbin_words) return hipErrorOutOfMemory;
+            const size_t lds = (size_t)21 * nb * sizeof(int);
+            // (the chunk list is double-buffered like the segment table: the plan kernel writes the next level's while the scatter
+            // pass still reads this level's)
+            int *chs_cur = B->ch_seg + (size_t)cur * B->chunk_cap, *chs_next = B->ch_seg + (size_t)(cur ^ 1) * B->chunk_cap;
+            hipLaunchKernelGGL(sb_bin_kernel, dim3(nchunks), dim3(SB_BLOCK), lds, stream, B->prim[cur], B->seg[cur], chs_cur, nb, CH, B->part);
+            if (nchunks > nseg)                          // (some segment has more than one chunk)
+                hipLaunchKernelGGL(sb_reduce_kernel, dim3((21 * nb + SB_BLOCK - 1) / SB_BLOCK, nseg), dim3(SB_BLOCK), 0, stream, B->seg[cur], nb, B->part,
+                                   B->segbins);
+            hipLaunchKernelGGL(sb_choose_kernel, dim3(nseg), dim3(SB_BLOCK), lds, stream, B->seg[cur], nb, CH, B->part, B->segbins, level, cur ^ 1,
+                               B->dec, B->ch_left, B->tasks, B->meta, B->fnode);
+            hipLaunchKernelGGL(sb_plan_kernel, dim3(1), dim3(1024), 0, stream, nseg, B->seg[cur], B->dec, B->seg[cur ^ 1], chs_next, B->meta);
+            hipLaunchKernelGGL(sb_scatter_kernel, dim3(nchunks), dim3(SB_BLOCK), 0, stream, B->prim[cur], B->prim[cur ^ 1], B->seg[cur],
+                               chs_cur, B->dec, B->ch_left, nb, CH, B->seg[cur ^ 1], B->fnode);
+            if ((e = hipMemcpyAsync(meta, B->meta, sizeof meta, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            if (meta[META_BAD]) return hipErrorInvalidValue;
+            nseg = meta[META_NSEG]; nchunks = meta[META_NCHUNK]; nb = meta[META_NB]; CH = meta[META_CH];
+            cur ^= 1; level++;
+        }
+        ntasks = meta[META_NTASK];
+        if ((size_t)ntasks > B->task_cap) return hipErrorInvalidValue;
+    }
+    if (ntasks > 0)
+        hipLaunchKernelGGL(sb_finish_kernel, dim3(ntasks), dim3(64), 0, stream, ntasks, B->tasks, B->prim[0], B->prim[1], B->fnode, B->meta);
+    if ((e = hipMemcpyAsync(meta, B->meta, sizeof meta, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-    if (cnt[0] > 0)
-        hipLaunchKernelGGL(sb_small_kernel, dim3((cnt[0] + 63) / 64), dim3(64), 0, stream, cnt[0], B->small, B->idx[cur], B->pct, B->plo, B->phi,
-                           B->child, B->blo, B->bhi, B->counters);
-    hipLaunchKernelGGL(sb_pack_kernel, dim3((ni + SB_BLOCK - 1) / SB_BLOCK), dim3(SB_BLOCK), 0, stream, ni, B->child, B->blo, B->bhi, B->plo,
-                       B->phi, B->fnode);
-    if ((e = hipMemcpyAsync(cnt, B->counters, sizeof cnt, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-    *depth = cnt[1];
+    *depth = meta[META_DEPTH];
     return hipGetLastError();
 }

@@ -7,6 +7,23 @@
 #include <system_error>
 #include <thread>
 
+// phase clock of mpt_build_tree (option "build_phases": synchronise at every mark, so a phase's time is its device work too)
+struct BuildClock {
+    mpt_ctx *c;
+    std::chrono::steady_clock::time_point t0, t;
+    explicit BuildClock(mpt_ctx *ctx) : c(ctx) {
+        for (double &v : c->build_phase_us) v = 0.0;
+        t0 = t = std::chrono::steady_clock::now();
+    }
+    void mark(int k) {
+        if (c->build_phases) (void)hipStreamSynchronize(c->stream);
+        const auto now = std::chrono::steady_clock::now();
+        c->build_phase_us[k] += std::chrono::duration<double, std::micro>(now - t).count();
+        c->build_phase_us[5] = std::chrono::duration<double, std::micro>(now - t0).count();
+        t = now;
+    }
+};
+
 // ------------------------------------------------------------------ LBVH build (tree/lbvh.py:169-305)
 // Same algorithm as the reference (30-bit Morton codes of centroids, sorted, Karras hierarchy,
 // bottom-up boxes) with two robustness changes: the sort key is (code << 32 | index), so equal
@@ -405,22 +422,19 @@ extern "C" int mpt_sah_workspace(int n, int64_t nseg, int64_t out[4]) {
     if (n < 1 || nseg < 0 || !out) return 1;
     int nb = 0;
     out[0] = (int64_t)mpt_sah_seg_capacity(n);
-    out[1] = (int64_t)mpt_sah_seg_words(n);
-    out[2] = (int64_t)mpt_sah_level_words((size_t)nseg, &nb);
+    out[1] = (int64_t)mpt_sah_part_words(n);
+    out[2] = (int64_t)mpt_sah_level_words(n, (size_t)nseg, &nb);
     out[3] = nb;
     return 0;
 }
 
 // workspace of mpt_sah_build: one device allocation carved into the arrays of MptSahBuffers
 static int build_sah_device(mpt_ctx *c) {
-    const int n = c->nfaces, ni = n - 1;
-    const size_t SC = mpt_sah_seg_capacity(n), SEGW = mpt_sah_seg_words(n);
-    size_t scan_bytes = 0;
-    HIP_TRY(mpt_sah_scan_bytes((int)std::max<size_t>((size_t)n, 2 * SC), &scan_bytes));
+    const int n = c->nfaces;
+    const size_t SC = mpt_sah_seg_capacity(n), CC = mpt_sah_chunk_capacity(n), TC = mpt_sah_task_capacity(n), PW = mpt_sah_part_words(n);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t f3 = al((size_t)n * 3 * 4), i1 = al((size_t)n * 4), s1 = al(SC * 4);
-    size_t total = 3 * f3 + 6 * i1 + 6 * s1 + al(SEGW * 4) + al(SC * 16) + 2 * al(2 * SC * 4) + al(((size_t)n / 2 + 1) * 16) + al(16) +
-                   al((size_t)ni * 8) + 2 * al((size_t)ni * 12) + al(std::max<size_t>(scan_bytes, 16));
+    const size_t SW = mpt_sah_segbin_words(n);
+    const size_t total = 2 * al((size_t)n * 32) + 2 * al(SC * 64) + al(SC * 32) + al(2 * CC * 4) + al(CC * 4) + al(PW * 4) + al(SW * 4) + al(TC * 32) + al(32);
     if (total > c->sah_ws_bytes) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         hipFree(c->sah_ws); c->sah_ws = nullptr; c->sah_ws_bytes = 0;
@@ -431,16 +445,15 @@ static int build_sah_device(mpt_ctx *c) {
     auto take = [&](size_t b) { char *r = q; q += al(b); return r; };
     MptSahBuffers B{};
     B.verts = c->d_verts; B.leaf = c->d_leaf; B.n = n;
-    B.plo = (float *)take((size_t)n * 12); B.phi = (float *)take((size_t)n * 12); B.pct = (float *)take((size_t)n * 12);
-    for (int k = 0; k < 2; k++) { B.idx[k] = (int *)take((size_t)n * 4); B.seg[k] = (int *)take((size_t)n * 4); }
-    B.pred = (int *)take((size_t)n * 4); B.pscan = (int *)take((size_t)n * 4);
-    for (int k = 0; k < 2; k++) { B.sb[k] = (int *)take(SC * 4); B.se[k] = (int *)take(SC * 4); B.snode[k] = (int *)take(SC * 4); }
-    B.segw = (int *)take(SEGW * 4); B.seg_words = SEGW;
-    B.dec = (int *)take(SC * 16); B.flag = (int *)take(2 * SC * 4); B.foff = (int *)take(2 * SC * 4);
-    B.small = (int *)take(((size_t)n / 2 + 1) * 16);
-    B.counters = (int *)take(16);
-    B.child = (int *)take((size_t)ni * 8); B.blo = (float *)take((size_t)ni * 12); B.bhi = (float *)take((size_t)ni * 12);
-    B.scan_tmp = take(std::max<size_t>(scan_bytes, 16)); B.scan_bytes = scan_bytes;
+    for (int k = 0; k < 2; k++) B.prim[k] = (MptVec4 *)take((size_t)n * 32);
+    for (int k = 0; k < 2; k++) B.seg[k] = (int *)take(SC * 64);
+    B.seg_cap = SC;
+    B.dec = (int *)take(SC * 32);
+    B.ch_seg = (int *)take(2 * CC * 4); B.ch_left = (int *)take(CC * 4); B.chunk_cap = CC;
+    B.part = (int *)take(PW * 4); B.part_words = PW;
+    B.segbins = (int *)take(SW * 4); B.segbin_words = SW;
+    B.tasks = (int *)take(TC * 32); B.task_cap = TC;
+    B.meta = (int *)take(32);
     B.fnode = c->fnode;
     int depth = 0;
     hipError_t e = mpt_sah_build(&B, &depth, c->stream);
@@ -482,7 +495,7 @@ static int build_sah_host(mpt_ctx *c) {
 
 // lbvh.py:297-305 entirely on the device (lbvh_build.hip); only the depth (4 bytes) comes back,
 // plus the leaf order when the fast build wants its SAH re-partition (a host pass today)
-static int build_tree_gpu(mpt_ctx *c) {
+static int build_tree_gpu(mpt_ctx *c, BuildClock &clk) {
     const int n = c->nfaces;
     const int ni = n > 1 ? n - 1 : 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -522,6 +535,7 @@ static int build_tree_gpu(mpt_ctx *c) {
         HIP_TRY(hipMemcpyAsync(c->d_verts, c->verts.data(), (size_t)n * 24 * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_mtlids, c->mtlids.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     }
+    clk.mark(0);
     MptLbvhBuffers b{};
     b.verts = c->d_verts; b.mtlids = c->d_mtlids; b.n = n;
     b.cen = c->d_cen; b.bounds = c->d_bounds; b.keys_in = c->d_keys_in; b.keys_out = c->d_keys_out;
@@ -534,21 +548,23 @@ static int build_tree_gpu(mpt_ctx *c) {
     if (ni > 0) HIP_TRY(hipMemcpyAsync(&depth, c->d_depth, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (depth + 2 > 64) return fail("LBVH depth %d exceeds the 64-entry traversal stack", depth);
+    clk.mark(1);
     c->tree_depth = depth;
     c->fast_depth = depth;
     c->host_tree_valid = false;
-    // auto: the host pass up to 131072 faces (its exact sweep of every range up to 8192 leaves is the better tree where ranges of
-    // 33 ... 8192 triangles matter -- BASELINE config 4: 9.44 against 9.63 node fetches per ray -- and costs 44 ms there), the device
-    // pass above (38 ms at a million faces against 220)
-    const bool sah_on_device = c->sah_build == 1 || (c->sah_build < 0 && n > 131072);
+    // auto: the host pass up to 8192 faces (all of its splits are exact sweeps there and it costs a millisecond or two: the trees
+    // of the small scenes stay what they were), the device pass above (exact sweeps up to 512 triangles, up to 1024 bins per
+    // axis above: sah_build.hip)
+    const bool sah_on_device = c->sah_build == 1 || (c->sah_build < 0 && n > 8192);
     c->sah_fallback = 0;
     if (c->tree_kind == 1 && ni > 0 && n <= c->sah_max) {
         // SAH re-partition of the leaves: on the device (sah_build.hip: nothing comes back but the depth), or the host pass --
         // also when the device pass gives up (workspace, level or depth limits): both start from the LBVH's leaf order
-        int r = (sah_on_device && n > 64) ? build_sah_device(c) : 2;
+        int r = (sah_on_device && n >= 2) ? build_sah_device(c) : 2;
         if (r == 1) return 1;
         if (r == 2 && build_sah_host(c)) return 1;
     }
+    clk.mark(2);
     c->tree_valid = true;
     return 0;
 }
@@ -777,7 +793,9 @@ extern "C" int mpt_get_wide(mpt_ctx *c, float *wnode, float *qnode, int cap_node
 extern "C" int mpt_build_tree(mpt_ctx *c) {
     if (use(c)) return 1;
     c->fnode_soa_valid = false;
-    if (c->gpu_build ? build_tree_gpu(c) : build_tree_host(c)) return 1;
+    BuildClock clk(c);
+    if (c->gpu_build ? build_tree_gpu(c, clk) : build_tree_host(c)) return 1;
+    clk.mark(2);
     // the production kernels' 48-byte triangle records, from the reference-order ones
     // (+ 1: record n is all NaNs -- the leaf an unused slot of a 4-wide node names; no ray can hit it)
     const size_t nt = (size_t)std::max(c->nfaces, 1) + 1;
@@ -789,7 +807,9 @@ extern "C" int mpt_build_tree(mpt_ctx *c) {
     }
     HIP_TRY(mpt_launch_derive_tfast(c->tgeo, c->tfast, c->nfaces, c->stream));
     HIP_TRY(hipMemsetAsync(c->tfast + (size_t)c->nfaces * 3, 0xff, 3 * sizeof(MptVec4), c->stream));   // 0xffffffff: a NaN
+    clk.mark(3);
     if (make_wide(c)) return 1;
+    clk.mark(4);
     c->oct_nodes = 0; c->oct_depth = 0;
     if (c->use_wide8 && c->tree_kind == 1) return make_oct8(c);     // option "wide8": the same tree 8-wide, octant-ordered (oct_build.cpp)
     return 0;

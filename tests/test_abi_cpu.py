@@ -184,10 +184,10 @@ def test_rank_device_selection(monkeypatch):
 
 
 def test_device_sah_workspace_holds_every_level_up_to_sah_max():
-    '''round-3 ADVICE (high): the per-segment workspace of the on-device SAH pass must hold every level it can reach -- a
-    level of nseg segments writes nseg x (12 + 27 x bins) words, bins falling to 32 once the segments outnumber 16 384.
-    The pure sizing rule (mpt_sah_workspace: no GPU) is checked for models up to sah_max = 2^22 faces, every segment count
-    near the break points and a sweep up to the capacity.'''
+    '''round-3 ADVICE (high), restated for the round-6 pass: the chunk-bin workspace of the on-device SAH pass must hold every
+    level it can reach -- a level of nseg segments (each of more than 512 triangles) has at most n / chunk + nseg chunks of
+    21 x bins words, bins falling from 1024 to 32 as the segments multiply.  The pure sizing rule (mpt_sah_workspace: no GPU)
+    is checked for models up to sah_max = 2^22 faces, every segment count near the break points and a sweep up to the capacity.'''
     import ctypes as C
     from ptina_amd import _lib
     lib = _lib.load_library()
@@ -195,7 +195,7 @@ def test_device_sah_workspace_holds_every_level_up_to_sah_max():
     for n in (33, 1000, 60000, 1 << 20, 1_080_000, 1_100_000, 2_000_000, 2_600_000, 1 << 22):
         assert lib.mpt_sah_workspace(n, 1, out) == 0
         cap, ws = out[0], out[1]
-        assert cap >= n // 33 and out[3] == 1024
+        assert cap >= n // 513 + 1 and out[3] == 1024
         probe = set(range(1, min(cap, 3000) + 1)) | {cap, max(cap - 1, 1)}
         for k in range(5, 21):                              # around every change of the bin count
             probe |= {x for x in ((1 << k) - 1, 1 << k, (1 << k) + 1) if 1 <= x <= cap}
@@ -203,5 +203,6 @@ def test_device_sah_workspace_holds_every_level_up_to_sah_max():
         for nseg in sorted(probe):
             assert lib.mpt_sah_workspace(n, nseg, out) == 0
             assert out[2] <= ws, (n, nseg, out[2], ws)
-            assert out[3] in (32, 64, 128, 256, 512, 1024) and out[2] == nseg * (12 + 27 * out[3])
+            nb = out[3]
+            assert nb in (32, 64, 128, 256, 512, 1024) and out[2] == 21 * nb * (n // max(2048, 16 * nb) + nseg)
     assert lib.mpt_sah_workspace(0, 1, out) == 1 and lib.mpt_sah_workspace(10, -1, out) == 1

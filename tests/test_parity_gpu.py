@@ -292,10 +292,43 @@ def test_tail_finalisation_soak_compares_the_data(fresh):
                 eng.render(4)                               # a pipelined pair now and then: its second launch keeps the combine pass
             FilmTable().get_image()
         films[start] = FilmTable().get_raw().copy()
-        assert c.get_option('tag_wraps') == (1 if start else 0)
+        # (the launch_seq door itself makes the next finalising launch zero the slabs: one zeroing for it, one for the tags coming round)
+        assert c.get_option('tag_wraps') == (2 if start else 1)
     reset_all()
     assert np.array_equal(films[0].view(np.uint32), films[65534 - 6].view(np.uint32))
     assert np.all(films[0][:, 3] == 16 * 4)
+
+
+def test_tags_come_round_at_the_head_of_a_pipelined_pair(fresh):
+    '''ADVICE r05 (medium).  When the tags come round every sample slab is zeroed; the launch that finds this out is the first of a
+    pipelined pair here, on a 1024 x 1024 film (32-frame slabs of 512 MiB: the memsets take a while), and the second launch of the
+    pair runs on another stream and writes another slab -- which nothing ordered behind that slab's memset before the host waited
+    for the memsets: the combine pass then added zeros.  Same film as the same calls far from the wrap, bit for bit, every sample
+    counted'''
+    from ptina_amd.things import FilmTable
+    from ptina_amd.common import ctx, reset_all
+    films = {}
+    for start in (1000, 65534 - 2):
+        reset_all()
+        eng = _engine(None, scenes.scene_s978(), 1024, 1024, mode='fast', max_filmsize=1 << 20)
+        c = ctx()
+        c.set_option('batch', 32)
+        eng.render(64)                                      # both slabs exist and hold old entries
+        FilmTable().get_image()
+        FilmTable().clear()
+        c.set_option('launch_seq', start)
+        eng.render(32)                                      # (the door's own zeroing happens here)
+        FilmTable().get_image()
+        w0 = c.get_option('tag_wraps')
+        for _ in range(3):
+            eng.render(64)                                  # start = 65532: the first launch of the first pair is number 65534
+            assert c.get_option('last_finalised') == 0      # (the second launch of a pair keeps the combine pass)
+        FilmTable().get_image()
+        assert c.get_option('tag_wraps') - w0 == (1 if start > 60000 else 0)
+        films[start] = FilmTable().get_raw().copy()
+    reset_all()
+    assert np.all(films[1000][:, 3] == 32 + 3 * 64)
+    assert np.array_equal(films[1000].view(np.uint32), films[65534 - 2].view(np.uint32))
 
 
 def test_image_hint_is_advice_only(fresh):
@@ -1277,6 +1310,81 @@ def test_octant_ordered_8wide_tree_and_kernel(fresh, oracle_mod, tmp_path):
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'OCT-OK' in r.stdout
+
+
+def _sah_tree(c, n, dev):
+    from ptina_amd.things import BVHTree
+    c.set_option('sah_build', dev)
+    BVHTree().build()
+    assert c.get_option('sah_fallback') == 0
+    w, q = _wide_records(c, n)
+    return w, q, c.get_option('fast_depth'), c.get_option('wide_nodes')
+
+
+def _check_wide_tree(w, n, nw):
+    ids = w[:, 6, :].view(np.int32)
+    assert nw > 0
+    assert np.array_equal(np.sort(ids[ids > 0]), np.arange(1, nw)), 'every wide node but the root has exactly one parent'
+    assert np.array_equal(np.sort(~ids[(ids < 0) & (ids != ~n)]), np.arange(n)), 'every triangle sits in exactly one slot'
+    # every child box lies inside ... the boxes of a leaf child are its triangle's (checked against the model by the films);
+    # here: finite, lo <= hi for every used slot
+    lo = w[:, 0:6:2, :].view(np.float32)
+    hi = w[:, 1:6:2, :].view(np.float32)
+    used = np.broadcast_to((ids != ~n)[:, None, :], lo.shape)
+    assert np.all(np.isfinite(lo[used])) and np.all(np.isfinite(hi[used])) and np.all(lo[used] <= hi[used])
+
+
+@pytest.mark.parametrize('n', [2, 3, 4, 7, 33, 64, 65, 129, 300, 511, 512])
+def test_device_sah_finish_kernel_is_the_host_pass_node_for_node(fresh, n):
+    '''sah_build.hip, finish kernel: a range of at most 512 triangles is built by one wave in LDS with the host pass's exact sweep
+    (every split of every axis, sorted by (centre, slot); lowest cost, then lowest axis, then lowest split; an axis along which
+    the centres do not differ is skipped).  For n <= 512 the whole tree is that kernel's: the same records as the host pass's,
+    byte for byte (through the 4-wide collapse, which is a function of the binary records), the same depth.  With exact
+    duplicates in the model (equal centres: ties go to the lower slot)'''
+    from ptina_amd.things import init_things, ModelPool
+    from ptina_amd.common import ctx
+    v, m, _, _ = scenes.scene_random_tris(n, seed=1000 + n, edge=0.2)
+    if n >= 7:
+        v[3 * 4:3 * 6] = v[3 * 2:3 * 4]            # exact duplicates
+    init_things()
+    ModelPool().load(v, m)
+    c = ctx()
+    dev = _sah_tree(c, n, 1)
+    host = _sah_tree(c, n, 0)
+    assert dev[2] == host[2] and dev[3] == host[3]
+    assert np.array_equal(dev[0], host[0]) and np.array_equal(dev[1], host[1])
+    _check_wide_tree(dev[0], n, dev[3])
+
+
+@pytest.mark.parametrize('n', [513, 700, 1025, 2049, 5000, 20000, 99382])
+def test_device_sah_pass_is_a_valid_deterministic_tree(fresh, n):
+    '''sah_build.hip above 512 triangles: binned levels (chunks, plan, stable scatter) down to ranges of <= 512, then the finish
+    kernel.  A valid tree over the same leaf slots at sizes around the switch, one / several chunks per segment and the size of
+    BASELINE config 4; built twice: the same bytes; depth within the stack; surface-area cost (sum of the areas of the
+    boxes that are fetched) no worse than 1.1 x the host pass's'''
+    from ptina_amd.things import init_things, ModelPool
+    from ptina_amd.common import ctx
+    v, m, _, _ = scenes.scene_random_tris(n, seed=n, edge=0.05)
+    v[3 * 7:3 * 9] = v[3 * 5:3 * 7]
+    init_things(max_faces=n + 1)
+    ModelPool().load(v, m)
+    c = ctx()
+    a = _sah_tree(c, n, 1)
+    b = _sah_tree(c, n, 1)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    _check_wide_tree(a[0], n, a[3])
+    assert 2 < a[2] <= 62
+
+    def cost(w):
+        lo = w[:, 0:6:2, :].view(np.float32).astype(np.float64)
+        hi = w[:, 1:6:2, :].view(np.float32).astype(np.float64)
+        ids = w[:, 6, :].view(np.int32)
+        d = np.maximum(hi - lo, 0.0)
+        area = d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]
+        return float(area[ids != ~n].sum())
+    h = _sah_tree(c, n, 0)
+    print(f'n {n}: depth {a[2]} / host {h[2]}, wide nodes {a[3]} / {h[3]}, area cost {cost(a[0]) / cost(h[0]):.4f} x the host pass')
+    assert cost(a[0]) <= 1.1 * cost(h[0])
 
 
 def test_device_sah_pass_builds_a_tree_as_good_as_the_host_pass(fresh, oracle_mod):
