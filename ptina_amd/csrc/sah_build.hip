@@ -40,7 +40,9 @@
 #ifndef SB_K
 #define SB_K 512               // a range of at most this many triangles is finished by one wave in LDS (exact sweep)
 #endif
-#define SB_E (SB_K / 64)       // positions per lane
+#ifndef SB_K2
+#define SB_K2 1024             // ... and one of up to this many too, by the same kernel with twice the positions per lane: exact sweeps up to
+#endif                         // 1024 triangles give BASELINE config 4's grid mesh 8.56 node steps per ray, up to 512 give 8.72 (the host pass: 8.55)
 #ifndef SB_MINBINS
 #define SB_MINBINS 32          // bins per axis at the levels with many segments ...
 #endif
@@ -57,7 +59,7 @@
 
 enum { SEG_B = 0, SEG_E, SEG_NODE, SEG_PAR, SEG_CB, SEG_CHUNK0 = 10, SEG_NCHUNK = 11 };
 enum { DEC_AXIS = 0, DEC_Q, DEC_M, DEC_CHILD0, DEC_CHILD1 };
-enum { META_NSEG = 0, META_NCHUNK, META_NB, META_CH, META_NTASK, META_DEPTH, META_BAD };
+enum { META_NSEG = 0, META_NCHUNK, META_NB, META_CH, META_NTASK, META_DEPTH, META_BAD, META_NTASK2 };
 
 __host__ __device__ __forceinline__ int sb_bins_for(long long nseg) {
     int nb = SB_MINBINS;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_reduce_kernel(const int *__restri
 
 __global__ __launch_bounds__(SB_BLOCK) void sb_choose_kernel(const int *__restrict__ seg, int nb, int CH, const int *__restrict__ part,
                                                             const int *__restrict__ segbins, int level, int nextbuf, int *__restrict__ dec,
-                                                            int *__restrict__ ch_left, int *__restrict__ tasks, int *__restrict__ meta,
+                                                            int *__restrict__ ch_left, int *__restrict__ tasks, int task_cap, int *__restrict__ meta,
                                                             MptVec4 *__restrict__ fnode) {
     extern __shared__ int lb[];                       // the segment's bins [3][nb][7], then (same words) the chunks' left counts
     __shared__ float w_cost[3];
@@ -285,10 +287,11 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_choose_kernel(const int *__restri
         for (int k = 0; k < 2; k++) {
             const int sz = hi_[k] - lo_[k];
             int flag = 0;
-            if (sz > SB_K) flag = 1;                             // a segment of the next level (numbered by the plan kernel)
+            if (sz > SB_K2) flag = 1;                            // a segment of the next level (numbered by the plan kernel)
             else if (sz >= 2) {
-                const int t = atomicAdd(meta + META_NTASK, 1);
-                int *T = tasks + (size_t)t * SB_TASK_INTS;
+                // a range the finish kernels take: the small ones are filed from the front of the task array, the big ones from its end
+                int *T = sz <= SB_K ? tasks + (size_t)atomicAdd(meta + META_NTASK, 1) * SB_TASK_INTS
+                                    : tasks + ((ptrdiff_t)task_cap - 1 - atomicAdd(meta + META_NTASK2, 1)) * SB_TASK_INTS;
                 T[0] = lo_[k]; T[1] = hi_[k]; T[2] = node[k]; T[3] = me * 2 + k; T[4] = level + 1; T[5] = nextbuf; T[6] = 0; T[7] = 0;
             }
             D[DEC_CHILD0 + k] = flag;
@@ -469,7 +472,8 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_scatter_kernel(const MptVec4 *__r
     }
 }
 
-// ------------------------------------------------------------------ finish: one wave per task, exact sweep in LDS
+// ------------------------------------------------------------------ finish: one workgroup of four waves per task, exact sweep in LDS
+#define SF_W 4                 // waves per task (one wave per task was latency-bound: every step of a level hangs on LDS round trips)
 struct SfBox { float l[3], h[3]; };
 __device__ __forceinline__ void sf_clear(SfBox &b) { for (int r = 0; r < 3; r++) { b.l[r] = INFINITY; b.h[r] = -INFINITY; } }
 __device__ __forceinline__ void sf_add(SfBox &a, const SfBox &b) {
@@ -481,40 +485,98 @@ __device__ __forceinline__ SfBox sf_shfl_up(const SfBox &a, int d) {
 __device__ __forceinline__ SfBox sf_shfl_down(const SfBox &a, int d) {
     SfBox o; for (int r = 0; r < 3; r++) { o.l[r] = __shfl_down(a.l[r], d); o.h[r] = __shfl_down(a.h[r], d); } return o;
 }
-// Segmented scans over the wave's lanes.  A lane's aggregate is (f, v): v = the union over its positions from its end of the
-// lane up to the first segment boundary inside it, f = there is such a boundary.  The carry a lane receives is what the
-// positions between its near end and its first boundary still miss.
-__device__ __forceinline__ SfBox sf_carry_from_below(bool f, SfBox v, int lane) {       // prefix direction: from the lower lanes
+// what the waves hand each other in a scan: per wave a flag and up to six words
+struct SfCross { int f[SF_W]; float v[SF_W][6]; };
+
+// Segmented scans over the workgroup's lanes.  A lane's aggregate is (f, v): v = the union over its positions from its near
+// end up to the first range boundary inside it, f = there is such a boundary.  The carry a lane receives is what its
+// positions in front of its first boundary still miss: the aggregates of the lanes before it, walking away from it until
+// one with a boundary has been taken -- first inside its wave (shuffles), then over the waves before (LDS, one barrier).
+__device__ __forceinline__ SfBox sf_carry_from_below(bool f, SfBox v, int lane, int wave, SfCross &X) {      // prefix direction
     for (int d = 1; d < 64; d <<= 1) {
         const SfBox ov = sf_shfl_up(v, d);
         const int of = __shfl_up((int)f, d);
         if (lane >= d && !f) { sf_add(v, ov); f = of != 0; }
     }
+    if (lane == 63) { X.f[wave] = f; for (int r = 0; r < 3; r++) { X.v[wave][r] = v.l[r]; X.v[wave][3 + r] = v.h[r]; } }
     SfBox c = sf_shfl_up(v, 1);
-    if (lane == 0) sf_clear(c);
+    int cf = __shfl_up((int)f, 1);
+    if (lane == 0) { sf_clear(c); cf = 0; }
+    __syncthreads();
+    if (!cf)
+        for (int w = wave - 1; w >= 0; w--) {
+            for (int r = 0; r < 3; r++) { c.l[r] = fminf(c.l[r], X.v[w][r]); c.h[r] = fmaxf(c.h[r], X.v[w][3 + r]); }
+            if (X.f[w]) break;
+        }
     return c;
 }
-__device__ __forceinline__ SfBox sf_carry_from_above(bool f, SfBox v, int lane) {       // suffix direction: from the higher lanes
+__device__ __forceinline__ SfBox sf_carry_from_above(bool f, SfBox v, int lane, int wave, SfCross &X) {      // suffix direction
     for (int d = 1; d < 64; d <<= 1) {
         const SfBox ov = sf_shfl_down(v, d);
         const int of = __shfl_down((int)f, d);
         if (lane + d < 64 && !f) { sf_add(v, ov); f = of != 0; }
     }
+    if (lane == 0) { X.f[wave] = f; for (int r = 0; r < 3; r++) { X.v[wave][r] = v.l[r]; X.v[wave][3 + r] = v.h[r]; } }
     SfBox c = sf_shfl_down(v, 1);
-    if (lane == 63) sf_clear(c);
+    int cf = __shfl_down((int)f, 1);
+    if (lane == 63) { sf_clear(c); cf = 0; }
+    __syncthreads();
+    if (!cf)
+        for (int w = wave + 1; w < SF_W; w++) {
+            for (int r = 0; r < 3; r++) { c.l[r] = fminf(c.l[r], X.v[w][r]); c.h[r] = fmaxf(c.h[r], X.v[w][3 + r]); }
+            if (X.f[w]) break;
+        }
+    return c;
+}
+// (cost, position) minimum, prefix direction; equal costs: the lower position (= the lanes / waves before) wins
+__device__ __forceinline__ void sf_min_from_below(bool f, float &vc, int &vp, int lane, int wave, SfCross &X) {
+    for (int d = 1; d < 64; d <<= 1) {
+        const float oc = __shfl_up(vc, d); const int op = __shfl_up(vp, d), of = __shfl_up((int)f, d);
+        if (lane >= d && !f) {
+            if (op >= 0 && (vp < 0 || oc <= vc)) { vc = oc; vp = op; }
+            f = of != 0;
+        }
+    }
+    if (lane == 63) { X.f[wave] = f; X.v[wave][0] = vc; X.v[wave][1] = __int_as_float(vp); }
+    float cc = __shfl_up(vc, 1); int cp = __shfl_up(vp, 1), cf = __shfl_up((int)f, 1);
+    if (lane == 0) { cc = INFINITY; cp = -1; cf = 0; }
+    __syncthreads();
+    if (!cf)
+        for (int w = wave - 1; w >= 0; w--) {
+            const float oc = X.v[w][0]; const int op = __float_as_int(X.v[w][1]);
+            if (op >= 0 && (cp < 0 || oc <= cc)) { cc = oc; cp = op; }
+            if (X.f[w]) break;
+        }
+    vc = cc; vp = cp;
+}
+__device__ __forceinline__ int sf_sum_from_below(bool f, int v, int lane, int wave, SfCross &X) {
+    for (int d = 1; d < 64; d <<= 1) {
+        const int ov = __shfl_up(v, d), of = __shfl_up((int)f, d);
+        if (lane >= d && !f) { v += ov; f = of != 0; }
+    }
+    if (lane == 63) { X.f[wave] = f; X.v[wave][0] = __int_as_float(v); }
+    int c = __shfl_up(v, 1), cf = __shfl_up((int)f, 1);
+    if (lane == 0) { c = 0; cf = 0; }
+    __syncthreads();
+    if (!cf)
+        for (int w = wave - 1; w >= 0; w--) {
+            c += __float_as_int(X.v[w][0]);
+            if (X.f[w]) break;
+        }
     return c;
 }
 
-struct SfLds {
-    float lo[3][SB_K], hi[3][SB_K];          // boxes by local triangle number
-    int slot[SB_K];
-    unsigned short ord[2][3][SB_K];          // per axis: local triangle numbers sorted by (centre, slot), ranges kept contiguous
-    unsigned short pb[SB_K];                 // per position: first position of its range
-    unsigned short se[SB_K];                 // per range start: end of the range
-    int snode[SB_K];                         // per range start: node number; during the sort: the keys
-    int spar[SB_K];                          // per range start: parent * 2 + side
-    int sdec[SB_K];                          // per range start: axis << 16 | left count
-    unsigned char side[SB_K];                // per local triangle: 1 = goes left
+template <int K> struct SfLds {
+    float lo[3][K], hi[3][K];                // boxes by local triangle number
+    int slot[K];
+    unsigned short ord[2][3][K];             // per axis: local triangle numbers sorted by (centre, slot), ranges kept contiguous
+    unsigned short pb[K];                    // per position: first position of its range
+    unsigned short se[K];                    // per range start: end of the range
+    int snode[K];                            // per range start: node number
+    int spar[K];                             // per range start: parent * 2 + side
+    int sdec[K];                             // per range start: axis << 16 | left count; during the sort: the keys
+    unsigned char side[K];                   // per local triangle: 1 = goes left
+    SfCross X[12];                           // one per scan of a level
 };
 
 __device__ __forceinline__ unsigned sf_key(float c) {           // order-preserving, -0 == +0
@@ -522,18 +584,22 @@ __device__ __forceinline__ unsigned sf_key(float c) {           // order-preserv
     return (u & 0x80000000u) ? ~u : u | 0x80000000u;
 }
 
-__global__ __launch_bounds__(64) void sb_finish_kernel(int ntasks, const int *__restrict__ tasks, const MptVec4 *__restrict__ prim0,
-                                                      const MptVec4 *__restrict__ prim1, MptVec4 *__restrict__ fnode,
-                                                      int *__restrict__ meta) {
-    __shared__ SfLds L;
-    const int lane = threadIdx.x;
+// E positions per lane, 256 lanes: E = 2 for tasks of up to 512 triangles (30 KB of LDS), E = 4 for up to 1024 (58 KB).
+// `last` = 1: the tasks are counted down from the end of the task array (the choose kernel files the big ones there).
+template <int E>
+__global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const int *__restrict__ tasks, int last,
+                                                             const MptVec4 *__restrict__ prim0, const MptVec4 *__restrict__ prim1,
+                                                             MptVec4 *__restrict__ fnode, int *__restrict__ meta) {
+    constexpr int NT = 64 * SF_W, K = NT * E;
+    __shared__ SfLds<K> L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x >= ntasks) return;
-    const int *T = tasks + (size_t)blockIdx.x * SB_TASK_INTS;
+    const int *T = tasks + (last ? -(ptrdiff_t)(blockIdx.x + 1) : (ptrdiff_t)blockIdx.x) * SB_TASK_INTS;
     const int b0 = T[0], c = T[1] - T[0], node0 = T[2], par0 = T[3], level0 = T[4];
     const MptVec4 *prim = T[5] ? prim1 : prim0;
-    int kp = 64;                                                  // positions that take part (a power of two >= c, >= 64)
+    int kp = 64;                                                  // positions that take part in the sort (a power of two >= c)
     while (kp < c) kp <<= 1;
-    for (int i = lane; i < SB_K; i += 64) {
+    for (int i = tid; i < K; i += NT) {
         float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
         int sl = 0x7fffffff;
         if (i < c) {
@@ -543,22 +609,22 @@ __global__ __launch_bounds__(64) void sb_finish_kernel(int ntasks, const int *__
         for (int a = 0; a < 3; a++) { L.lo[a][i] = l[a]; L.hi[a][i] = h[a]; }
         L.slot[i] = sl;
         L.pb[i] = (unsigned short)(i < c ? 0 : i);               // positions past the task's triangles: ranges of one, inert
-        L.se[i] = (unsigned short)(i + 1);
+        L.se[i] = (unsigned short)(i == 0 ? c : i + 1);
     }
-    if (lane == 0) { L.se[0] = (unsigned short)c; L.snode[0] = node0; L.spar[0] = par0; }
+    if (tid == 0) { L.snode[0] = node0; L.spar[0] = par0; }
     __syncthreads();
     // ---- the three sorted orders: bitonic over kp positions, keys (centre, slot); the padding sorts last
     unsigned *key = (unsigned *)L.sdec;
     for (int a = 0; a < 3; a++) {
         unsigned short *od = L.ord[0][a];
-        for (int i = lane; i < kp; i += 64) {
+        for (int i = tid; i < kp; i += NT) {
             key[i] = i < c ? sf_key(0.5f * (L.lo[a][i] + L.hi[a][i])) : 0xffffffffu;
             od[i] = (unsigned short)i;
         }
         __syncthreads();
         for (int k = 2; k <= kp; k <<= 1)
             for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                for (int t = lane; t < (kp >> 1); t += 64) {
+                for (int t = tid; t < (kp >> 1); t += NT) {
                     const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), l2 = i | jj;
                     const bool up = (i & k) == 0;
                     const unsigned ka = key[i], kb = key[l2];
@@ -568,129 +634,104 @@ __global__ __launch_bounds__(64) void sb_finish_kernel(int ntasks, const int *__
                 }
                 __syncthreads();
             }
-        for (int i = kp + lane; i < SB_K; i += 64) od[i] = (unsigned short)i;
+        for (int i = kp + tid; i < K; i += NT) od[i] = (unsigned short)i;
         __syncthreads();
     }
     // ---- level by level
     int cur = 0, level = level0, deepest = 0;
-    const int i0 = lane * SB_E;
+    const int i0 = tid * E;
     for (;;) {
         // the ranges of this lane's positions
-        int pb[SB_E], pe[SB_E];
+        int pb[E], pe[E];
         unsigned head = 0, tail = 0, act = 0;
 #pragma unroll
-        for (int j = 0; j < SB_E; j++) {
+        for (int j = 0; j < E; j++) {
             pb[j] = L.pb[i0 + j]; pe[j] = L.se[pb[j]];
             if (i0 + j == pb[j]) head |= 1u << j;
             if (i0 + j == pe[j] - 1) tail |= 1u << j;
             if (pe[j] - pb[j] >= 2) act |= 1u << j;
         }
-        if (__ballot(act != 0) == 0ull) break;
+        if (!__syncthreads_or(act != 0)) break;
         deepest = level;
-        float best[SB_E]; int bestak[SB_E];
+        float best[E]; int bestak[E];
 #pragma unroll
-        for (int j = 0; j < SB_E; j++) { best[j] = INFINITY; bestak[j] = -1; }
+        for (int j = 0; j < E; j++) { best[j] = INFINITY; bestak[j] = -1; }
         for (int a = 0; a < 3; a++) {
             const unsigned short *od = L.ord[cur][a];
-            SfBox bx[SB_E];
+            SfBox bx[E];
 #pragma unroll
-            for (int j = 0; j < SB_E; j++) {
+            for (int j = 0; j < E; j++) {
                 const int p = od[i0 + j];
                 for (int r = 0; r < 3; r++) { bx[j].l[r] = L.lo[r][p]; bx[j].h[r] = L.hi[r][p]; }
             }
-            // suffix: S(i) = union of the boxes at i .. end of the range; its area
-            float sarea[SB_E];
+            // suffix: S(i) = union of the boxes at i .. end of the range; its area.  Two sweeps instead of E stored boxes:
+            // the first gives the lane's aggregate (up to its first range end), the second starts from the carry
+            float sarea[E];
             {
                 SfBox run; sf_clear(run);
-                SfBox sfx[SB_E];
 #pragma unroll
-                for (int j = SB_E - 1; j >= 0; j--) {
+                for (int j = E - 1; j >= 0; j--) { if (tail >> j & 1) run = bx[j]; else sf_add(run, bx[j]); }
+                run = sf_carry_from_above(tail != 0, run, lane, wave, L.X[a * 4 + 0]);
+#pragma unroll
+                for (int j = E - 1; j >= 0; j--) {
                     if (tail >> j & 1) run = bx[j]; else sf_add(run, bx[j]);
-                    sfx[j] = run;
-                }
-                const SfBox carry = sf_carry_from_above(tail != 0, run, lane);
-                bool seen = false;
-#pragma unroll
-                for (int j = SB_E - 1; j >= 0; j--) {
-                    if (tail >> j & 1) seen = true;
-                    if (!seen) sf_add(sfx[j], carry);
-                    sarea[j] = sb_half_area(sfx[j].l, sfx[j].h);
+                    sarea[j] = sb_half_area(run.l, run.h);
                     // a range's own box (at its first position) goes into its parent's record
                     if (a == 0 && (head >> j & 1) && (act >> j & 1)) {
                         const int par = L.spar[pb[j]];
-                        if (par >= 0) sb_write_child(fnode, par, sfx[j].l, sfx[j].h, L.snode[pb[j]]);
+                        if (par >= 0) sb_write_child(fnode, par, run.l, run.h, L.snode[pb[j]]);
                     }
                 }
             }
             // prefix (exclusive): P(i) = union of the boxes at start of the range .. i - 1; the cost of the split in front of i
-            float cost[SB_E];
+            float cost[E];
             {
                 SfBox run; sf_clear(run);
-                SfBox pfx[SB_E];
 #pragma unroll
-                for (int j = 0; j < SB_E; j++) {
+                for (int j = 0; j < E; j++) { if (head >> j & 1) sf_clear(run); sf_add(run, bx[j]); }
+                run = sf_carry_from_below(head != 0, run, lane, wave, L.X[a * 4 + 1]);
+#pragma unroll
+                for (int j = 0; j < E; j++) {
                     if (head >> j & 1) sf_clear(run);
-                    pfx[j] = run;
-                    sf_add(run, bx[j]);
-                }
-                const SfBox carry = sf_carry_from_below(head != 0, run, lane);
-                bool seen = false;
-#pragma unroll
-                for (int j = 0; j < SB_E; j++) {
-                    if (head >> j & 1) seen = true;
-                    if (!seen) sf_add(pfx[j], carry);
                     cost[j] = INFINITY;
                     if ((act >> j & 1) && !(head >> j & 1)) {
                         const int k = i0 + j - pb[j];
-                        cost[j] = sb_half_area(pfx[j].l, pfx[j].h) * k + sarea[j] * (pe[j] - pb[j] - k);
+                        cost[j] = sb_half_area(run.l, run.h) * k + sarea[j] * (pe[j] - pb[j] - k);
                     }
+                    sf_add(run, bx[j]);
                 }
             }
-            // the axis takes part in a range only if the range's centres differ along it (the host pass's rule)
             // segmented minimum of (cost, position), in position order, strict: the first of equal costs stays
             {
                 float mc = INFINITY; int mp = -1;
-                float mcs[SB_E]; int mps[SB_E];
 #pragma unroll
-                for (int j = 0; j < SB_E; j++) {
+                for (int j = 0; j < E; j++) {
                     if (head >> j & 1) { mc = INFINITY; mp = -1; }
                     if (cost[j] < mc) { mc = cost[j]; mp = i0 + j; }
-                    mcs[j] = mc; mps[j] = mp;
                 }
-                bool f = head != 0;
-                float vc = mc; int vp = mp;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const float oc = __shfl_up(vc, d); const int op = __shfl_up(vp, d), of = __shfl_up((int)f, d);
-                    if (lane >= d && !f) {
-                        if (op >= 0 && (vp < 0 || oc <= vc)) { vc = oc; vp = op; }     // the lower lanes' positions come first: they win ties
-                        f = of != 0;
-                    }
-                }
-                float cc = __shfl_up(vc, 1); int cp = __shfl_up(vp, 1);
-                if (lane == 0) { cc = INFINITY; cp = -1; }
-                bool seen = false;
+                sf_min_from_below(head != 0, mc, mp, lane, wave, L.X[a * 4 + 2]);
 #pragma unroll
-                for (int j = 0; j < SB_E; j++) {
-                    if (head >> j & 1) seen = true;
-                    if (!seen && cp >= 0 && (mps[j] < 0 || cc <= mcs[j])) { mcs[j] = cc; mps[j] = cp; }
-                    if ((tail >> j & 1) && (act >> j & 1) && mps[j] >= 0) {
-                        // (centres along this axis all equal: the axis is skipped)
+                for (int j = 0; j < E; j++) {
+                    if (head >> j & 1) { mc = INFINITY; mp = -1; }
+                    if (cost[j] < mc) { mc = cost[j]; mp = i0 + j; }
+                    if ((tail >> j & 1) && (act >> j & 1) && mp >= 0) {
+                        // the axis takes part in a range only if the range's centres differ along it (the host pass's rule)
                         const int pf = od[pb[j]], pl = od[pe[j] - 1];
                         const float cf = 0.5f * (L.lo[a][pf] + L.hi[a][pf]), cl_ = 0.5f * (L.lo[a][pl] + L.hi[a][pl]);
-                        if (cl_ > cf && mcs[j] < best[j]) { best[j] = mcs[j]; bestak[j] = (a << 16) | (mps[j] - pb[j]); }
+                        if (cl_ > cf && mc < best[j]) { best[j] = mc; bestak[j] = (a << 16) | (mp - pb[j]); }
                     }
                 }
             }
         }
         // ---- decisions (at the ranges' last positions), then the side of every triangle
 #pragma unroll
-        for (int j = 0; j < SB_E; j++)
+        for (int j = 0; j < E; j++)
             if ((tail >> j & 1) && (act >> j & 1))
                 L.sdec[pb[j]] = bestak[j] >= 0 ? bestak[j] : (pe[j] - pb[j]) / 2;      // no split found: halve the range in the order of axis 0
         __syncthreads();
-        int kk[SB_E];
+        int kk[E];
 #pragma unroll
-        for (int j = 0; j < SB_E; j++) {
+        for (int j = 0; j < E; j++) {
             kk[j] = 0;
             if (act >> j & 1) {
                 const int ak = L.sdec[pb[j]];
@@ -703,42 +744,32 @@ __global__ __launch_bounds__(64) void sb_finish_kernel(int ntasks, const int *__
         for (int a = 0; a < 3; a++) {
             const unsigned short *od = L.ord[cur][a];
             unsigned short *on = L.ord[cur ^ 1][a];
-            int p[SB_E], lr[SB_E];
+            int p[E];
             unsigned sd = 0;
             int run = 0;
 #pragma unroll
-            for (int j = 0; j < SB_E; j++) {
+            for (int j = 0; j < E; j++) {
                 p[j] = od[i0 + j];
                 if (head >> j & 1) run = 0;
-                lr[j] = run;
                 if ((act >> j & 1) && L.side[p[j]]) { sd |= 1u << j; run++; }
             }
-            bool f = head != 0;
-            int v = run;
-            for (int d = 1; d < 64; d <<= 1) {
-                const int ov = __shfl_up(v, d), of = __shfl_up((int)f, d);
-                if (lane >= d && !f) { v += ov; f = of != 0; }
-            }
-            int carry = __shfl_up(v, 1);
-            if (lane == 0) carry = 0;
-            bool seen = false;
+            run = sf_sum_from_below(head != 0, run, lane, wave, L.X[a * 4 + 3]);
 #pragma unroll
-            for (int j = 0; j < SB_E; j++) {
-                if (head >> j & 1) seen = true;
-                if (!seen) lr[j] += carry;
+            for (int j = 0; j < E; j++) {
+                if (head >> j & 1) run = 0;
                 int dest = i0 + j;
-                if (act >> j & 1) dest = (sd >> j & 1) ? pb[j] + lr[j] : pb[j] + kk[j] + (i0 + j - pb[j]) - lr[j];
+                if (act >> j & 1) dest = (sd >> j & 1) ? pb[j] + run : pb[j] + kk[j] + (i0 + j - pb[j]) - run;
                 on[dest] = (unsigned short)p[j];
+                if (sd >> j & 1) run++;
             }
         }
-        __syncthreads();
         // ---- the children: range tables for the next level, single triangles into their parent's record
-        int me[SB_E];
+        int me[E];
 #pragma unroll
-        for (int j = 0; j < SB_E; j++) me[j] = (act >> j & 1) ? L.snode[pb[j]] : 0;
+        for (int j = 0; j < E; j++) me[j] = (act >> j & 1) ? L.snode[pb[j]] : 0;
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < SB_E; j++) {
+        for (int j = 0; j < E; j++) {
             if (!(act >> j & 1)) continue;
             const int i = i0 + j, b = pb[j], e = pe[j], m = b + kk[j];
             L.pb[i] = (unsigned short)(i < m ? b : m);
@@ -760,11 +791,11 @@ __global__ __launch_bounds__(64) void sb_finish_kernel(int ntasks, const int *__
         __syncthreads();
         cur ^= 1; level++;
     }
-    if (lane == 0 && deepest > 0) atomicMax(meta + META_DEPTH, deepest);
+    if (tid == 0 && deepest > 0) atomicMax(meta + META_DEPTH, deepest);
 }
 
 // ------------------------------------------------------------------ driver
-MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n) { return (size_t)n / (SB_K + 1) + 2; }
+MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n) { return (size_t)n / (SB_K2 + 1) + 2; }
 MPT_KERNEL_API size_t mpt_sah_chunk_capacity(int n) { return (size_t)n / SB_CHUNK_MIN + mpt_sah_seg_capacity(n) + 2; }
 // words of chunk bins a level can need: a level of nseg segments has at most n / CH + nseg chunks of 21 nb words, with
 // nb / CH <= 1 / 16 and nb x nseg <= the budget (or 32 x nseg at the floor)
@@ -789,7 +820,7 @@ MPT_KERNEL_API void mpt_sah_level_shape(long long nseg, int *nb, int *ch) {
     if (nb) *nb = b;
     if (ch) *ch = sb_chunk_for(b);
 }
-MPT_KERNEL_API int mpt_sah_task_max(void) { return SB_K; }
+MPT_KERNEL_API int mpt_sah_task_max(void) { return SB_K2; }
 
 static hipError_t sb_big_lds(const void *fn) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 21 * SB_MAXBINS * (int)sizeof(int));
@@ -814,12 +845,13 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
     if ((e = hipMemcpyAsync(B->seg[0], seg0, sizeof seg0, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     const int gp = std::min((n + SB_BLOCK - 1) / SB_BLOCK, 1024);
     hipLaunchKernelGGL(sb_prims_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, B->verts, B->leaf, n, B->prim[0], B->seg[0]);
-    int ntasks = 0;
-    if (n <= SB_K) {
+    int ntasks = 0, ntasks2 = 0;
+    if (n <= SB_K2) {
         // the whole tree is one task
         const int task[SB_TASK_INTS] = { 0, n, 0, -1, 1, 0, 0, 0 };
-        if ((e = hipMemcpyAsync(B->tasks, task, sizeof task, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-        ntasks = 1;
+        int *where = n <= SB_K ? B->tasks : B->tasks + (B->task_cap - 1) * SB_TASK_INTS;
+        if ((e = hipMemcpyAsync(where, task, sizeof task, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        (n <= SB_K ? ntasks : ntasks2) = 1;
     } else {
         int nseg = 1, nchunks = seg0[SEG_NCHUNK], cur = 0, level = 1;
         if ((e = hipMemsetAsync(B->ch_seg, 0, (size_t)nchunks * sizeof(int), stream)) != hipSuccess) return e;
@@ -836,7 +868,7 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
                 hipLaunchKernelGGL(sb_reduce_kernel, dim3((21 * nb + SB_BLOCK - 1) / SB_BLOCK, nseg), dim3(SB_BLOCK), 0, stream, B->seg[cur], nb, B->part,
                                    B->segbins);
             hipLaunchKernelGGL(sb_choose_kernel, dim3(nseg), dim3(SB_BLOCK), lds, stream, B->seg[cur], nb, CH, B->part, B->segbins, level, cur ^ 1,
-                               B->dec, B->ch_left, B->tasks, B->meta, B->fnode);
+                               B->dec, B->ch_left, B->tasks, (int)B->task_cap, B->meta, B->fnode);
             hipLaunchKernelGGL(sb_plan_kernel, dim3(1), dim3(1024), 0, stream, nseg, B->seg[cur], B->dec, B->seg[cur ^ 1], chs_next, B->meta);
             hipLaunchKernelGGL(sb_scatter_kernel, dim3(nchunks), dim3(SB_BLOCK), 0, stream, B->prim[cur], B->prim[cur ^ 1], B->seg[cur],
                                chs_cur, B->dec, B->ch_left, nb, CH, B->seg[cur ^ 1], B->fnode);
@@ -846,11 +878,15 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
             nseg = meta[META_NSEG]; nchunks = meta[META_NCHUNK]; nb = meta[META_NB]; CH = meta[META_CH];
             cur ^= 1; level++;
         }
-        ntasks = meta[META_NTASK];
-        if ((size_t)ntasks > B->task_cap) return hipErrorInvalidValue;
+        ntasks = meta[META_NTASK]; ntasks2 = meta[META_NTASK2];
+        if ((size_t)ntasks + (size_t)ntasks2 > B->task_cap) return hipErrorInvalidValue;
     }
+    // (the big tasks first: they take longer)
+    if (ntasks2 > 0)
+        hipLaunchKernelGGL(sb_finish_kernel<SB_K2 / (64 * SF_W)>, dim3(ntasks2), dim3(64 * SF_W), 0, stream, ntasks2, B->tasks + B->task_cap * SB_TASK_INTS, 1,
+                           B->prim[0], B->prim[1], B->fnode, B->meta);
     if (ntasks > 0)
-        hipLaunchKernelGGL(sb_finish_kernel, dim3(ntasks), dim3(64), 0, stream, ntasks, B->tasks, B->prim[0], B->prim[1], B->fnode, B->meta);
+        hipLaunchKernelGGL(sb_finish_kernel<SB_K / (64 * SF_W)>, dim3(ntasks), dim3(64 * SF_W), 0, stream, ntasks, B->tasks, 0, B->prim[0], B->prim[1], B->fnode, B->meta);
     if ((e = hipMemcpyAsync(meta, B->meta, sizeof meta, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     *depth = meta[META_DEPTH];

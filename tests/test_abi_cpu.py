@@ -185,7 +185,7 @@ def test_rank_device_selection(monkeypatch):
 
 def test_device_sah_workspace_holds_every_level_up_to_sah_max():
     '''round-3 ADVICE (high), restated for the round-6 pass: the chunk-bin workspace of the on-device SAH pass must hold every
-    level it can reach -- a level of nseg segments (each of more than 512 triangles) has at most n / chunk + nseg chunks of
+    level it can reach -- a level of nseg segments (each of more than 1024 triangles) has at most n / chunk + nseg chunks of
     21 x bins words, bins falling from 1024 to 32 as the segments multiply.  The pure sizing rule (mpt_sah_workspace: no GPU)
     is checked for models up to sah_max = 2^22 faces, every segment count near the break points and a sweep up to the capacity.'''
     import ctypes as C
@@ -195,7 +195,7 @@ def test_device_sah_workspace_holds_every_level_up_to_sah_max():
     for n in (33, 1000, 60000, 1 << 20, 1_080_000, 1_100_000, 2_000_000, 2_600_000, 1 << 22):
         assert lib.mpt_sah_workspace(n, 1, out) == 0
         cap, ws = out[0], out[1]
-        assert cap >= n // 513 + 1 and out[3] == 1024
+        assert cap >= n // 1025 + 1 and out[3] == 1024
         probe = set(range(1, min(cap, 3000) + 1)) | {cap, max(cap - 1, 1)}
         for k in range(5, 21):                              # around every change of the bin count
             probe |= {x for x in ((1 << k) - 1, 1 << k, (1 << k) + 1) if 1 <= x <= cap}

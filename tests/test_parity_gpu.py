@@ -1334,11 +1334,12 @@ def _check_wide_tree(w, n, nw):
     assert np.all(np.isfinite(lo[used])) and np.all(np.isfinite(hi[used])) and np.all(lo[used] <= hi[used])
 
 
-@pytest.mark.parametrize('n', [2, 3, 4, 7, 33, 64, 65, 129, 300, 511, 512])
+@pytest.mark.parametrize('n', [2, 3, 4, 7, 33, 64, 65, 129, 300, 511, 512, 513, 700, 1023, 1024])
 def test_device_sah_finish_kernel_is_the_host_pass_node_for_node(fresh, n):
-    '''sah_build.hip, finish kernel: a range of at most 512 triangles is built by one wave in LDS with the host pass's exact sweep
+    '''sah_build.hip, finish kernel: a range of at most 1024 triangles is built by one wave in LDS with the host pass's exact sweep
     (every split of every axis, sorted by (centre, slot); lowest cost, then lowest axis, then lowest split; an axis along which
-    the centres do not differ is skipped).  For n <= 512 the whole tree is that kernel's: the same records as the host pass's,
+    the centres do not differ is skipped; 8 positions per lane up to 512 triangles, 16 above).  For n <= 1024 the whole tree is
+    that kernel's: the same records as the host pass's,
     byte for byte (through the 4-wide collapse, which is a function of the binary records), the same depth.  With exact
     duplicates in the model (equal centres: ties go to the lower slot)'''
     from ptina_amd.things import init_things, ModelPool
@@ -1356,10 +1357,10 @@ def test_device_sah_finish_kernel_is_the_host_pass_node_for_node(fresh, n):
     _check_wide_tree(dev[0], n, dev[3])
 
 
-@pytest.mark.parametrize('n', [513, 700, 1025, 2049, 5000, 20000, 99382])
+@pytest.mark.parametrize('n', [1025, 1100, 2049, 2100, 5000, 20000, 99382])
 def test_device_sah_pass_is_a_valid_deterministic_tree(fresh, n):
-    '''sah_build.hip above 512 triangles: binned levels (chunks, plan, stable scatter) down to ranges of <= 512, then the finish
-    kernel.  A valid tree over the same leaf slots at sizes around the switch, one / several chunks per segment and the size of
+    '''sah_build.hip above 1024 triangles: binned levels (chunks, plan, stable scatter) down to ranges of <= 1024, then the
+    finish kernels.  A valid tree over the same leaf slots at sizes around the switch, one / several chunks per segment and the size of
     BASELINE config 4; built twice: the same bytes; depth within the stack; surface-area cost (sum of the areas of the
     boxes that are fetched) no worse than 1.1 x the host pass's'''
     from ptina_amd.things import init_things, ModelPool
