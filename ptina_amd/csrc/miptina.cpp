@@ -416,6 +416,13 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "sah_build") *value = c->sah_build;
     else if (k == "sah_fallback") *value = c->sah_fallback;
     else if (k == "build_phases") *value = c->build_phases;
+    else if (k == "sah_levels") *value = c->sah_stats.levels;
+    else if (k == "sah_kelems") *value = (int)(c->sah_stats.elems / 1000);
+    else if (k == "sah_chunks") *value = (int)c->sah_stats.chunks;
+    else if (k == "sah_segments") *value = (int)c->sah_stats.segments;
+    else if (k == "sah_part_kwords") *value = (int)(c->sah_stats.part_words / 1000);
+    else if (k == "sah_tasks_small") *value = c->sah_stats.tasks_small;
+    else if (k == "sah_tasks_big") *value = c->sah_stats.tasks_big;
     else if (k.rfind("build_phase_us_", 0) == 0 && k.size() == 16 && k[15] >= '0' && k[15] <= '5') *value = (int)(c->build_phase_us[k[15] - '0'] + 0.5);
     else if (k == "wide_nodes") *value = c->wide_nodes;
     else if (k == "wide_stack") *value = c->wide_stack;

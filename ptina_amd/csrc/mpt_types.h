@@ -72,6 +72,15 @@ struct MptLight {              // light/__init__.py:14-18
 // one contiguous float4 range of the film gather's pack / unpack (comm.cpp): count elements from src to dst
 struct MptPiece { long long src, dst, count; };
 
+// what the last SAH re-partition did (diagnostics / the traffic model of profiles/r06_build_table.json)
+struct MptSahStats {
+    int levels;                      // binned levels
+    long long elems;                 // positions streamed, summed over the binned levels
+    long long chunks, segments;      // summed over the binned levels
+    long long part_words;            // words of chunk bins written, summed over the levels
+    int tasks_small, tasks_big;      // ranges finished in LDS: <= 512 triangles, 513 ... 1024
+};
+
 // device workspace of the SAH re-partition (sah_build.hip); capacities from mpt_sah_*_capacity(n)
 struct MptSahBuffers {
     const float *verts; const int *leaf; int n;          // the LBVH build's inputs / leaf order, on the device
@@ -82,7 +91,8 @@ struct MptSahBuffers {
     int *part; size_t part_words;                        // chunk bins of one level
     int *segbins; size_t segbin_words;                   // the bins of the segments that have several chunks
     int *tasks; size_t task_cap;                         // [task_cap][8] ranges the finish kernel takes
-    int *meta;                                           // [8]
+    int *meta;                                           // [16]
+    MptSahStats *stats;                                  // host, optional
     MptVec4 *fnode;                                      // out: [n-1][4]
 };
 

@@ -55,18 +55,27 @@
 #define SB_CHUNK_MIN 2048      // positions per chunk (workgroup): max(SB_CHUNK_MIN, 16 x bins), so a chunk's bins stay below its records' bytes
 #define SB_SEG_INTS 16         // segment record: b, e, node, parent * 2 + side, centre bounds [6] (ordered ints), first chunk, chunks
 #define SB_DEC_INTS 8          // decision record: axis (-1: halve the range), first bin of the right side, m, child segments [2] (-1: none)
+#define SB_CHUNK_WORDS(nb) (24 * (nb))  // a chunk's bins: [3][nb]{count, lo3, hi3}, then the running bin counts [3][nb]
 #define SB_TASK_INTS 8         // task record: b, e, node, parent * 2 + side, level, buffer
 
 enum { SEG_B = 0, SEG_E, SEG_NODE, SEG_PAR, SEG_CB, SEG_CHUNK0 = 10, SEG_NCHUNK = 11 };
 enum { DEC_AXIS = 0, DEC_Q, DEC_M, DEC_CHILD0, DEC_CHILD1 };
-enum { META_NSEG = 0, META_NCHUNK, META_NB, META_CH, META_NTASK, META_DEPTH, META_BAD, META_NTASK2 };
+enum { META_NSEG = 0, META_NCHUNK, META_NB, META_CH, META_NTASK, META_DEPTH, META_BAD, META_NTASK2, META_ELEMS, META_INTS = 16 };
 
 __host__ __device__ __forceinline__ int sb_bins_for(long long nseg) {
     int nb = SB_MINBINS;
     while (nb < SB_MAXBINS && nseg * 2 * nb <= (long long)SB_BIN_BUDGET) nb *= 2;
     return nb;
 }
-__host__ __device__ __forceinline__ int sb_chunk_for(int nb) { return 16 * nb > SB_CHUNK_MIN ? 16 * nb : SB_CHUNK_MIN; }
+// positions per chunk (workgroup) at a level that streams `elems` positions with nb bins: 16 x bins, so that a chunk's bins stay
+// well below its records' bytes -- but no more than 1/256 of the level (a level wants a few hundred workgroups: with 16 384
+// positions per chunk the first levels of a 100 000-triangle model ran on 7 CUs), and never less than SB_CHUNK_MIN
+__host__ __device__ __forceinline__ int sb_chunk_for(int nb, long long elems) {
+    long long ch = 16 * nb;
+    const long long spread = ((elems / 256 + 255) / 256) * 256;
+    if (ch > spread) ch = spread;
+    return ch > SB_CHUNK_MIN ? (int)ch : SB_CHUNK_MIN;
+}
 
 __device__ __forceinline__ int sb_f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float sb_ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
@@ -87,9 +96,15 @@ __device__ __forceinline__ void sb_write_child(MptVec4 *__restrict__ fnode, int 
 }
 
 // ------------------------------------------------------------------ records of the leaf slots + the root's centre bounds
-// verts [3n][8], leaf: slot -> face.  prim[slot] = {lo.xyz, slot} {hi.xyz, 0}
+// verts [3n][8], leaf: slot -> face.  prim[slot] = {lo.xyz, slot} {hi.xyz, 0}.  The centre bounds: per workgroup into
+// partial[block][6], and the workgroup that finishes last reduces those into the root segment's record (6 atomics per WAVE on
+// one cache line were 0.27 of this kernel's 0.30 ms at a million triangles).  What crosses between workgroups is written and
+// read with agent-scope atomic accesses (memory side, sc1) and ordered by the s_waitcnt in front of the ticket (lbvh_build.hip).
 __global__ __launch_bounds__(SB_BLOCK) void sb_prims_kernel(const float *__restrict__ verts, const int *__restrict__ leaf, int n,
-                                                           MptVec4 *__restrict__ prim, int *__restrict__ seg0) {
+                                                           MptVec4 *__restrict__ prim, int *__restrict__ seg0, int *partial,
+                                                           int *ticket) {
+    __shared__ int red[SB_BLOCK / 64][6];
+    __shared__ int is_last;
     int cb[6] = { 0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000 };
     for (int slot = blockIdx.x * SB_BLOCK + threadIdx.x; slot < n; slot += gridDim.x * SB_BLOCK) {
         const float *p0 = verts + (size_t)leaf[slot] * 24, *p1 = p0 + 8, *p2 = p0 + 16;
@@ -107,10 +122,37 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_prims_kernel(const float *__restr
             const int o = __shfl_xor(cb[k], off);
             cb[k] = k < 3 ? min(cb[k], o) : max(cb[k], o);
         }
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 6; k++) red[threadIdx.x >> 6][k] = cb[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int v = red[0][threadIdx.x];
+        for (int w = 1; w < SB_BLOCK / 64; w++) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        __hip_atomic_store(partial + blockIdx.x * 6 + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    for (int k = 0; k < 6; k++) cb[k] = k < 3 ? 0x7fffffff : (int)0x80000000;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += SB_BLOCK)
         for (int k = 0; k < 6; k++) {
-            if (k < 3) atomicMin(seg0 + SEG_CB + k, cb[k]); else atomicMax(seg0 + SEG_CB + k, cb[k]);
+            const int v = __hip_atomic_load(partial + b * 6 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cb[k] = k < 3 ? min(cb[k], v) : max(cb[k], v);
         }
+    for (int k = 0; k < 6; k++)
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(cb[k], off);
+            cb[k] = k < 3 ? min(cb[k], o) : max(cb[k], o);
+        }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 6; k++) red[threadIdx.x >> 6][k] = cb[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int v = red[0][threadIdx.x];
+        for (int w = 1; w < SB_BLOCK / 64; w++) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        seg0[SEG_CB + threadIdx.x] = v;
+    }
 }
 
 // ------------------------------------------------------------------ top phase: bin
@@ -143,8 +185,25 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_bin_kernel(const MptVec4 *__restr
         }
     }
     __syncthreads();
-    int *out = part + (size_t)j * words;
+    int *out = part + (size_t)j * SB_CHUNK_WORDS(nb);
     for (int k = threadIdx.x; k < words; k += SB_BLOCK) out[k] = lb[k];
+    // the running counts along every axis (how many of the chunk's positions fall into bins 0 .. q): the choose kernel reads ONE
+    // of them per chunk to know how many of the chunk go left of its split
+    __shared__ int wtot[SB_BLOCK / 64];
+    const int per = nb >= SB_BLOCK ? nb / SB_BLOCK : 1, q0 = threadIdx.x * per, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int a = 0; a < 3; a++) {
+        int own = 0;
+        if (q0 < nb) for (int t = 0; t < per; t++) own += lb[(a * nb + q0 + t) * 7];
+        int inc = own;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        __syncthreads();
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int run = inc - own;
+        for (int w = 0; w < wave; w++) run += wtot[w];
+        if (q0 < nb)
+            for (int t = 0; t < per; t++) { run += lb[(a * nb + q0 + t) * 7]; out[words + a * nb + q0 + t] = run; }
+    }
 }
 
 // ------------------------------------------------------------------ top phase: choose
@@ -236,10 +295,11 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_reduce_kernel(const int *__restri
     const int chunk0 = S[SEG_CHUNK0], nchunk = S[SEG_NCHUNK];
     if (nchunk < 2 || k >= words) return;
     const int f = k % 7;
-    const int *p = part + (size_t)chunk0 * words + k;
+    const size_t stride = SB_CHUNK_WORDS(nb);
+    const int *p = part + (size_t)chunk0 * stride + k;
     int acc = p[0];
     for (int c = 1; c < nchunk; c++) {
-        const int v = p[(size_t)c * words];
+        const int v = p[(size_t)c * stride];
         acc = f == 0 ? acc + v : (f < 4 ? min(acc, v) : max(acc, v));
     }
     segbins[(size_t)s * words + k] = acc;
@@ -257,7 +317,7 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_choose_kernel(const int *__restri
     const int b = S[SEG_B], e = S[SEG_E], me = S[SEG_NODE], par = S[SEG_PAR], chunk0 = S[SEG_CHUNK0], nchunk = S[SEG_NCHUNK];
     const int words = 21 * nb;
     {
-        const int *src = nchunk == 1 ? part + (size_t)chunk0 * words : segbins + (size_t)s * words;
+        const int *src = nchunk == 1 ? part + (size_t)chunk0 * SB_CHUNK_WORDS(nb) : segbins + (size_t)s * words;
         for (int k = tid; k < words; k += SB_BLOCK) lb[k] = src[k];
     }
     __syncthreads();
@@ -306,16 +366,12 @@ __global__ __launch_bounds__(SB_BLOCK) void sb_choose_kernel(const int *__restri
     int *lc = lb;                                                // (the bins are done with)
     const bool in_lds = nchunk <= words;
     __syncthreads();
-    for (int c = wave; c < nchunk; c += SB_BLOCK / 64) {
+    for (int c = tid; c < nchunk; c += SB_BLOCK) {
         const int cstart = b + c * CH, ccnt = min(CH, e - cstart);
         int left = 0;
         if (axis < 0) left = min(max(m - cstart, 0), ccnt);
-        else {
-            const int *p = part + (size_t)(chunk0 + c) * words + (size_t)axis * nb * 7;
-            for (int q = lane; q < bq; q += 64) left += p[q * 7];
-            for (int d = 32; d > 0; d >>= 1) left += __shfl_xor(left, d);
-        }
-        if (lane == 0) { if (in_lds) lc[c] = left; else ch_left[chunk0 + c] = left; }
+        else if (bq > 0) left = part[(size_t)(chunk0 + c) * SB_CHUNK_WORDS(nb) + words + axis * nb + bq - 1];
+        if (in_lds) lc[c] = left; else ch_left[chunk0 + c] = left;
     }
     __syncthreads();
     if (tid == 0) {
@@ -346,8 +402,9 @@ __device__ __forceinline__ int sb_block_scan_1024(int v, int *total, int *wsum /
 __global__ __launch_bounds__(1024) void sb_plan_kernel(int nseg, const int *__restrict__ seg, int *__restrict__ dec,
                                                       int *__restrict__ seg_next, int *__restrict__ ch_seg, int *__restrict__ meta) {
     __shared__ int wsum[16];
-    __shared__ int sh_nb, sh_ch;
+    __shared__ int sh_nb, sh_ch, sh_elems;
     const int tid = threadIdx.x;
+    if (tid == 0) sh_elems = 0;
     // 1. number the children that go on as segments: parents in order, left before right
     int carry = 0;
     for (int base = 0; base < nseg; base += 1024) {
@@ -366,13 +423,14 @@ __global__ __launch_bounds__(1024) void sb_plan_kernel(int nseg, const int *__re
                 int *N = seg_next + (size_t)(at + (k ? f0 : 0)) * SB_SEG_INTS;
                 N[SEG_B] = k ? m : b; N[SEG_E] = k ? e : m; N[SEG_NODE] = k ? me + (m - b) : me + 1; N[SEG_PAR] = me * 2 + k;
                 for (int r = 0; r < 6; r++) N[SEG_CB + r] = r < 3 ? 0x7fffffff : (int)0x80000000;
+                atomicAdd(&sh_elems, N[SEG_E] - N[SEG_B]);         // positions the next level streams
             }
         }
         carry += tot;
         __syncthreads();
     }
     const int nnext = carry;
-    if (tid == 0) { sh_nb = sb_bins_for(nnext); sh_ch = sb_chunk_for(sh_nb); }
+    if (tid == 0) { sh_nb = sb_bins_for(nnext); sh_ch = sb_chunk_for(sh_nb, sh_elems); }
     __syncthreads();
     const int CH = sh_ch;
     // 2. chunks of every new segment
@@ -380,7 +438,10 @@ __global__ __launch_bounds__(1024) void sb_plan_kernel(int nseg, const int *__re
     for (int base = 0; base < nnext; base += 1024) {
         const int s = base + tid;
         int nch = 0;
-        if (s < nnext) nch = (seg_next[(size_t)s * SB_SEG_INTS + SEG_E] - seg_next[(size_t)s * SB_SEG_INTS + SEG_B] + CH - 1) / CH;
+        if (s < nnext) {
+            const int sz = seg_next[(size_t)s * SB_SEG_INTS + SEG_E] - seg_next[(size_t)s * SB_SEG_INTS + SEG_B];
+            nch = (sz + CH - 1) / CH;
+        }
         int tot;
         const int at = carry + sb_block_scan_1024(nch, &tot, wsum);
         if (s < nnext) { seg_next[(size_t)s * SB_SEG_INTS + SEG_CHUNK0] = at; seg_next[(size_t)s * SB_SEG_INTS + SEG_NCHUNK] = nch; }
@@ -399,7 +460,7 @@ __global__ __launch_bounds__(1024) void sb_plan_kernel(int nseg, const int *__re
         }
         ch_seg[j] = lo;
     }
-    if (tid == 0) { meta[META_NSEG] = nnext; meta[META_NCHUNK] = nchunks; meta[META_NB] = sh_nb; meta[META_CH] = CH; }
+    if (tid == 0) { meta[META_NSEG] = nnext; meta[META_NCHUNK] = nchunks; meta[META_NB] = sh_nb; meta[META_CH] = CH; meta[META_ELEMS] = sh_elems; }
 }
 
 // ------------------------------------------------------------------ top phase: scatter
@@ -797,29 +858,25 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
 // ------------------------------------------------------------------ driver
 MPT_KERNEL_API size_t mpt_sah_seg_capacity(int n) { return (size_t)n / (SB_K2 + 1) + 2; }
 MPT_KERNEL_API size_t mpt_sah_chunk_capacity(int n) { return (size_t)n / SB_CHUNK_MIN + mpt_sah_seg_capacity(n) + 2; }
-// words of chunk bins a level can need: a level of nseg segments has at most n / CH + nseg chunks of 21 nb words, with
-// nb / CH <= 1 / 16 and nb x nseg <= the budget (or 32 x nseg at the floor)
+// words of chunk bins a level can need: a level of nseg segments streaming `elems` positions has at most elems / CH + nseg chunks
+// of 24 nb words; nb / CH <= 1 / 16 where CH = 16 nb, elems / CH <= 256 + 1 where CH is the level's 256th part (or the
+// 2048 floor under it); nb x nseg <= the budget (or 32 x nseg at the floor)
 MPT_KERNEL_API size_t mpt_sah_part_words(int n) {
     const size_t sc = mpt_sah_seg_capacity(n);
     const size_t segbins = std::max((size_t)SB_BIN_BUDGET, (size_t)SB_MINBINS * sc);
-    return 21 * ((size_t)n / 16 + SB_MAXBINS + segbins);
+    return 24 * ((size_t)n / 16 + (size_t)SB_MAXBINS * 258 + segbins);
 }
 // words of per-segment bins a level can need: 21 nb nseg
 MPT_KERNEL_API size_t mpt_sah_segbin_words(int n) {
     return 21 * std::max((size_t)SB_BIN_BUDGET, (size_t)SB_MINBINS * mpt_sah_seg_capacity(n));
 }
+// the most a level of nseg segments of a model of n triangles can write (it streams at most all n positions)
 MPT_KERNEL_API size_t mpt_sah_level_words(int n, size_t nseg, int *nb_out) {
-    const int nb = sb_bins_for((long long)nseg), ch = sb_chunk_for(nb);
+    const int nb = sb_bins_for((long long)nseg), ch = sb_chunk_for(nb, n);
     if (nb_out) *nb_out = nb;
-    return (size_t)21 * nb * ((size_t)n / ch + nseg);
+    return (size_t)SB_CHUNK_WORDS(nb) * ((size_t)n / ch + nseg);
 }
 MPT_KERNEL_API size_t mpt_sah_task_capacity(int n) { return (size_t)n / 2 + 2; }
-// what a level of nseg segments uses: bins per axis, positions per chunk
-MPT_KERNEL_API void mpt_sah_level_shape(long long nseg, int *nb, int *ch) {
-    const int b = sb_bins_for(nseg);
-    if (nb) *nb = b;
-    if (ch) *ch = sb_chunk_for(b);
-}
 MPT_KERNEL_API int mpt_sah_task_max(void) { return SB_K2; }
 
 static hipError_t sb_big_lds(const void *fn) {
@@ -837,14 +894,16 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
         if ((e = sb_big_lds((const void *)sb_choose_kernel)) != hipSuccess) return e;
         attr_done = true;
     }
-    int meta[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    if ((e = hipMemsetAsync(B->meta, 0, 8 * sizeof(int), stream)) != hipSuccess) return e;
-    int nb = sb_bins_for(1), CH = sb_chunk_for(nb);
+    int meta[META_INTS] = { 0 };
+    if ((e = hipMemsetAsync(B->meta, 0, sizeof meta, stream)) != hipSuccess) return e;
+    MptSahStats st{};
+    int nb = sb_bins_for(1), CH = sb_chunk_for(nb, n);
     int seg0[SB_SEG_INTS] = { 0, n, 0, -1, 0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000,
                               0, (n + CH - 1) / CH, 0, 0, 0, 0 };
     if ((e = hipMemcpyAsync(B->seg[0], seg0, sizeof seg0, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    const int gp = std::min((n + SB_BLOCK - 1) / SB_BLOCK, 1024);
-    hipLaunchKernelGGL(sb_prims_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, B->verts, B->leaf, n, B->prim[0], B->seg[0]);
+    const int gp = std::min((n + SB_BLOCK - 1) / SB_BLOCK, 2048);       // (their partial bounds take 6 words each of B->part: far below its size)
+    hipLaunchKernelGGL(sb_prims_kernel, dim3(gp), dim3(SB_BLOCK), 0, stream, B->verts, B->leaf, n, B->prim[0], B->seg[0], B->part,
+                       B->meta + META_INTS - 1);
     int ntasks = 0, ntasks2 = 0;
     if (n <= SB_K2) {
         // the whole tree is one task
@@ -857,9 +916,11 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
         if ((e = hipMemsetAsync(B->ch_seg, 0, (size_t)nchunks * sizeof(int), stream)) != hipSuccess) return e;
         while (nseg > 0) {
             if (level > 60) return hipErrorInvalidValue;
-            if ((size_t)nchunks * 21 * nb > B->part_words || (size_t)nseg > B->seg_cap || (size_t)nchunks > B->chunk_cap ||
+            if ((size_t)nchunks * SB_CHUNK_WORDS(nb) > B->part_words || (size_t)nseg > B->seg_cap || (size_t)nchunks > B->chunk_cap ||
                 (size_t)nseg * 21 * nb > B->segbin_words) return hipErrorOutOfMemory;
             const size_t lds = (size_t)21 * nb * sizeof(int);
+            st.levels++; st.elems += level == 1 ? n : meta[META_ELEMS]; st.chunks += nchunks; st.part_words += (long long)nchunks * SB_CHUNK_WORDS(nb);
+            st.segments += nseg;
             // (the chunk list is double-buffered like the segment table: the plan kernel writes the next level's while the scatter
             // pass still reads this level's)
             int *chs_cur = B->ch_seg + (size_t)cur * B->chunk_cap, *chs_next = B->ch_seg + (size_t)(cur ^ 1) * B->chunk_cap;
@@ -890,5 +951,7 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
     if ((e = hipMemcpyAsync(meta, B->meta, sizeof meta, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     *depth = meta[META_DEPTH];
+    st.tasks_small = ntasks; st.tasks_big = ntasks2;
+    if (B->stats) *B->stats = st;
     return hipGetLastError();
 }

@@ -434,7 +434,7 @@ static int build_sah_device(mpt_ctx *c) {
     const size_t SC = mpt_sah_seg_capacity(n), CC = mpt_sah_chunk_capacity(n), TC = mpt_sah_task_capacity(n), PW = mpt_sah_part_words(n);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t SW = mpt_sah_segbin_words(n);
-    const size_t total = 2 * al((size_t)n * 32) + 2 * al(SC * 64) + al(SC * 32) + al(2 * CC * 4) + al(CC * 4) + al(PW * 4) + al(SW * 4) + al(TC * 32) + al(32);
+    const size_t total = 2 * al((size_t)n * 32) + 2 * al(SC * 64) + al(SC * 32) + al(2 * CC * 4) + al(CC * 4) + al(PW * 4) + al(SW * 4) + al(TC * 32) + al(64);
     if (total > c->sah_ws_bytes) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         hipFree(c->sah_ws); c->sah_ws = nullptr; c->sah_ws_bytes = 0;
@@ -453,7 +453,8 @@ static int build_sah_device(mpt_ctx *c) {
     B.part = (int *)take(PW * 4); B.part_words = PW;
     B.segbins = (int *)take(SW * 4); B.segbin_words = SW;
     B.tasks = (int *)take(TC * 32); B.task_cap = TC;
-    B.meta = (int *)take(32);
+    B.meta = (int *)take(64);
+    B.stats = &c->sah_stats;
     B.fnode = c->fnode;
     int depth = 0;
     hipError_t e = mpt_sah_build(&B, &depth, c->stream);

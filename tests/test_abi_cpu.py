@@ -186,7 +186,7 @@ def test_rank_device_selection(monkeypatch):
 def test_device_sah_workspace_holds_every_level_up_to_sah_max():
     '''round-3 ADVICE (high), restated for the round-6 pass: the chunk-bin workspace of the on-device SAH pass must hold every
     level it can reach -- a level of nseg segments (each of more than 1024 triangles) has at most n / chunk + nseg chunks of
-    21 x bins words, bins falling from 1024 to 32 as the segments multiply.  The pure sizing rule (mpt_sah_workspace: no GPU)
+    24 x bins words, bins falling from 1024 to 32 as the segments multiply.  The pure sizing rule (mpt_sah_workspace: no GPU)
     is checked for models up to sah_max = 2^22 faces, every segment count near the break points and a sweep up to the capacity.'''
     import ctypes as C
     from ptina_amd import _lib
@@ -204,5 +204,6 @@ def test_device_sah_workspace_holds_every_level_up_to_sah_max():
             assert lib.mpt_sah_workspace(n, nseg, out) == 0
             assert out[2] <= ws, (n, nseg, out[2], ws)
             nb = out[3]
-            assert nb in (32, 64, 128, 256, 512, 1024) and out[2] == 21 * nb * (n // max(2048, 16 * nb) + nseg)
+            ch = max(2048, min(16 * nb, (n // 256 + 255) // 256 * 256))       # positions per chunk when a level streams all n
+            assert nb in (32, 64, 128, 256, 512, 1024) and out[2] == 24 * nb * (n // ch + nseg)
     assert lib.mpt_sah_workspace(0, 1, out) == 1 and lib.mpt_sah_workspace(10, -1, out) == 1

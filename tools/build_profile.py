@@ -30,7 +30,10 @@ def main():
     c = ctx()
     for kv in filter(None, os.environ.get('MIPTINA_OPTS', '').split(',')):
         c.set_option(kv.split('=')[0], int(kv.split('=')[1]))
-    c.set_option('build_phases', int(os.environ.get('BUILD_PHASES', '1')))
+    try:
+        c.set_option('build_phases', int(os.environ.get('BUILD_PHASES', '1')))
+    except RuntimeError:
+        pass                                      # (a library from before round 6: wall times only)
     out = {'scene': name, 'ntri': n, 'runs': []}
     for _ in range(reps):
         c.call('mpt_synchronize')
@@ -44,13 +47,18 @@ def main():
                 run[ph + '_ms'] = c.get_option(f'build_phase_us_{k}') / 1e3
         except RuntimeError:
             pass
+        try:
+            for k in ('sah_levels', 'sah_kelems', 'sah_chunks', 'sah_segments', 'sah_part_kwords', 'sah_tasks_small', 'sah_tasks_big'):
+                run[k] = c.get_option(k)
+        except RuntimeError:
+            pass
         run['fast_depth'] = c.get_option('fast_depth')
         run['wide_nodes'] = c.get_option('wide_nodes')
         run['wide_depth'] = c.get_option('wide_depth')
         out['runs'].append(run)
         print(json.dumps(run), flush=True)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', f'build_profile_{name}.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', f'build_profile_{name}{os.environ.get("BUILD_TAG", "")}.json'), 'w'), indent=1)
     reset_all()
 
 
