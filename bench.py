@@ -363,6 +363,12 @@ def run_other_configs(mode, stub=False):
             BVHTree().build()                     # mpt_build_tree again, timed alone (the model is resident): LBVH (+ SAH + 4-wide collapse)
             c.call('mpt_synchronize')
             build_s = time.perf_counter() - t0
+            # the build by phase (a third build, with a synchronisation after every phase: its total is not the figure above)
+            c.set_option('build_phases', 1)
+            BVHTree().build()
+            phases = {ph: round(c.get_option(f'build_phase_us_{k}') / 1e3, 3)
+                      for k, ph in enumerate(('upload_ms', 'lbvh_ms', 'sah_ms', 'triangle_records_ms', 'wide_collapse_ms'))}
+            c.set_option('build_phases', 0)
             eng.render()                          # exams/benchmark.py:25-27
             film.get_image()
             film.clear()
@@ -383,6 +389,18 @@ def run_other_configs(mode, stub=False):
                         'ms_per_step': round(dt * 1e3, 3), 'kernel': kernel, 'avg_kernel_ms': round(kms / max(nl, 1), 4),
                         'launches_per_step': nl // steps, 'steps': steps, 'build_tree_ms': round(build_s * 1e3, 2),
                         'msamples_s_incl_build': round(n * n * spp / (dt + build_s) / 1e6, 1), 'scene_generation_s': round(gen_s, 2)}
+            ntri = int(scene[1].shape[0])
+            if ntri > 8192:
+                # mpt_build_tree against what it has to move: the model in once (96-byte vertices + material id), the records the
+                # kernels walk out once (reference nodes 32 B, binary nodes 64 B, triangle records 64 + 64 + 48 B, 4-wide nodes 128 + 64 B)
+                nw = c.get_option('wide_nodes')
+                bbytes = ntri * (100 + 64 + 64 + 48) + (ntri - 1) * 96 + nw * 192
+                out[key]['build'] = {
+                    'bytes': bbytes, 'ms': round(build_s * 1e3, 2), 'GB/s': round(bbytes / build_s / 1e9, 1),
+                    'frac': round(bbytes / build_s / 1e9 / HBM_PEAK_GBS, 4), 'peak': HBM_PEAK_GBS, 'phases': phases,
+                    'sah_levels': c.get_option('sah_levels'), 'fast_depth': c.get_option('fast_depth'), 'wide_nodes': nw,
+                    'note': 'bytes = the model read once + every record written once; ms = the whole mpt_build_tree call with the model in host '
+                            'memory (the PCIe upload is phases.upload_ms); per-kernel table: profiles/r06_build_table_*.json'}
             if kernel == 'render_kernel_wide' and name in GATHER_L2_HIT:
                 # what bounds these kernels is the vector memory path's rate of divergent 16-byte gathers, not HBM bytes (their L2 hit
                 # rate is 67 / 90 %) and not MFMA: records of one launch (counting build) / its duration, against the micro-benchmark's

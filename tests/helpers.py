@@ -160,3 +160,130 @@ def soak_finalisation(launches, nx=512, ny=512, frames=4, per_round=50, stripes=
                 % (done, nx, ny, frames, stripes, stress_copies, stress_mb, dict(opts)))
     reset_all()
     return done
+
+
+def stress_scene(seed):
+    '''the seeded random scene of tools/stress_random_scenes.py / test_forty_random_scenes_*: the cornell walls plus 1 .. 900
+    triangles of random place, size and (smooth) normals, 2 .. 5 random opaque Disney materials, 1 .. 3 point / area lights, a
+    random constant world light, a random film size, sample count and batch size.  Returns (scene, lights, world, nx, ny, spp,
+    batches) -- batches: one batch size per kernel run, drawn in the tool's order'''
+    from ptina_amd.tools.matrix import translate
+    rng = np.random.default_rng(seed)
+    walls = scenes.cornell_walls()
+    k = int(rng.integers(1, 900))
+    c = rng.uniform([-1.6, 0.3, -1.6], [1.6, 3.4, 1.2], (k, 1, 3))
+    P = c + rng.normal(0, 1, (k, 3, 3)) * rng.uniform(0.03, 0.7, (k, 1, 1))
+    fn = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    fn /= np.linalg.norm(fn, axis=1, keepdims=True) + 1e-30
+    N = fn[:, None, :] + rng.normal(0, 0.25, (k, 3, 3))
+    N /= np.linalg.norm(N, axis=2, keepdims=True)
+    T = rng.uniform(0, 1, (k, 3, 2))
+    nm = int(rng.integers(2, 6))
+    M = rng.integers(3, 3 + nm, k).astype(np.int32)
+    v, m = scenes._compose([walls, (P, N, T, M)])
+    mats = list(scenes.WALL_MATERIALS)
+    for _ in range(nm):
+        mats.append(scenes.material(basecolor=tuple(rng.uniform(0, 1, 3) * (rng.random() > 0.15)), metallic=float(rng.random() ** 2),
+                                    roughness=float(rng.uniform(0.05, 1)), specular=float(rng.random()), specularTint=float(rng.random()),
+                                    subsurface=float(rng.random() * (rng.random() > 0.5)), sheen=float(rng.random() * (rng.random() > 0.5)),
+                                    sheenTint=float(rng.random())))
+    scene = (v, m, mats, [])
+    rot = np.eye(4)
+    rot[:3, :3] = [[1, 0, 0], [0, 0, 1], [0, -1, 0]]
+    lights = []
+    for _ in range(int(rng.integers(1, 4))):
+        pos = rng.uniform([-1.5, 2.2, -1.5], [1.5, 3.8, 1.5])
+        if rng.random() < 0.5:
+            lights.append((translate(list(pos)) @ rot, rng.uniform(4, 20, 3), float(rng.uniform(0.2, 0.7)), 'AREA'))
+        else:
+            lights.append((translate(list(pos)), rng.uniform(4, 20, 3), float(rng.uniform(0.05, 0.4)), 'POINT'))
+    world = ([float(x) for x in rng.uniform(0, 0.4, 3)] + [1.0], -1)
+    nx, ny, spp = int(rng.integers(20, 200)), int(rng.integers(20, 160)), int(rng.integers(1, 40))
+    batches = [int(rng.integers(1, 33)) for _ in range(5)]
+    return scene, lights, world, nx, ny, spp, batches
+
+
+STRESS_KERNELS = (('strict', 'strict', {}), ('lds4', 'fast', {}), ('lds', 'fast', {'lds_wide': 0}), ('bin', 'fast', {'lds': 0, 'wide': 0}),
+                  ('wide', 'fast', {'lds': 0}))
+
+
+def _largest_sample(scene, nx, ny, spp, mode, lights, world):
+    '''per pixel: the largest single-sample radiance (L2 over rgb) of the film rendered one frame at a time -- the same frames,
+    the same sums (batching does not change a film), read back after every frame'''
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd.things import FilmTable
+    reset_all()
+    eng = setup_engine(scene, nx, ny, mode=mode, lights=lights, world=world)
+    ctx().set_option('batch', 1)
+    prev = np.zeros((nx, ny, 3), np.float64)
+    big = np.zeros((nx, ny), np.float64)
+    for _ in range(spp):
+        eng.render(1)
+        raw = FilmTable().get_raw().reshape(nx, ny, 4)[..., :3].astype(np.float64)
+        big = np.maximum(big, np.sqrt(((raw - prev) ** 2).sum(axis=-1)))
+        prev = raw
+    return big
+
+
+def stress_compare(seed, log=print):
+    '''One random scene through the strict build and the four production kernels, each production film against the strict film at
+    the STATED fast bounds (helpers.FAST: 99.5 % of the pixels within 1e-3 (1 + |ref|), rel-RMSE <= 1e-3) with explicit
+    firefly accounting: a path whose discrete decision (lobe, edge hit, shadow) falls the other way replaces
+    ONE sample of a pixel, so such a pixel may leave the per-pixel bound by at most the largest single sample of that pixel in
+    either film / spp; at most ceil(0.0005 x pixels) pixels may claim that, they still count as outliers, and the rel-RMSE is
+    taken without them.  A pixel that is further off than one sample explains fails the scene.
+    Returns (ok, fireflies, messages).'''
+    import math
+    from ptina_amd.common import ctx, reset_all
+    from ptina_amd.things import FilmTable
+    scene, lights, world, nx, ny, spp, batches = stress_scene(seed)
+    imgs, kernels = {}, {}
+    for (name, mode, opts), batch in zip(STRESS_KERNELS, batches):
+        reset_all()
+        eng = setup_engine(scene, nx, ny, mode=mode, lights=lights, world=world)
+        for a, b in opts.items():
+            ctx().set_option(a, b)
+        ctx().set_option('batch', batch)
+        eng.render(spp)
+        raw = FilmTable().get_raw().reshape(nx, ny, 4)
+        assert np.all(raw[..., 3] == spp), (seed, name)
+        imgs[name] = FilmTable().get_image()
+        kernels[name] = ctx().get_option('last_kernel')
+    ok, msgs, flies, big = True, [], 0, None
+    kmax = math.ceil(0.0005 * nx * ny)
+    for name in ('lds4', 'lds', 'bin', 'wide'):
+        d, refn, rel = image_stats(imgs[name], imgs['strict'])
+        tol = FAST[0] * (1 + refn)
+        out = d > tol
+        k_used, rel_used = 0, rel
+        if rel > FAST[2] or out.mean() > FAST[1]:
+            # only now the (expensive) per-sample films: which of the outliers can one replaced sample explain?
+            if big is None:
+                big = np.maximum(_largest_sample(scene, nx, ny, spp, 'strict', lights, world),
+                                 _largest_sample(scene, nx, ny, spp, 'fast', lights, world))
+            fly = out & (d <= tol + big / spp * (1 + 1e-3) + 1e-6)
+            order = np.argsort(-(d * fly).ravel())[:kmax]                # the kmax worst explainable pixels
+            mask = np.zeros(nx * ny, bool)
+            mask[order] = True
+            mask &= fly.ravel()
+            k_used = int(mask.sum())
+            d2 = d.copy().ravel()
+            d2[mask] = 0.0
+            rel_used = float(np.sqrt((d2 ** 2).mean()) / max(np.sqrt((refn ** 2).mean()), 1e-30))
+            unexplained = out & ~fly
+            if unexplained.any():
+                ix = np.argwhere(unexplained)[0]
+                msgs.append(f'{name}: pixel {tuple(ix)} is {d[tuple(ix)]:.3e} off with tolerance {tol[tuple(ix)]:.3e} and a largest sample / spp of '
+                            f'{big[tuple(ix)] / spp:.3e}: more than one replaced sample explains')
+                ok = False
+        good = rel_used <= FAST[2] and out.mean() <= FAST[1]
+        ok = ok and good
+        flies = max(flies, k_used)
+        msgs.append(f'{name} rel {rel:.1e}' + (f' ({rel_used:.1e} without {k_used} firefly pixel(s) of at most {kmax})' if k_used else '') +
+                    f' out {out.mean() * 100:.2f}%' + ('' if good else ' <<<<'))
+    same = np.array_equal(imgs['lds'].view(np.uint32), imgs['bin'].view(np.uint32))
+    same4 = float((imgs['lds4'].view(np.uint32) == imgs['lds'].view(np.uint32)).all(axis=-1).mean())
+    log(f'{seed} {scene[1].shape[0]} tris {nx}x{ny} {spp} spp | ' + ' | '.join(msgs) + f' | lds==bin {same} | lds4==lds on {100 * same4:.3f} % of the pixels | '
+        f'fireflies {flies} of at most {kmax} | kernels {kernels}')
+    reset_all()
+    return ok and same, flies, msgs

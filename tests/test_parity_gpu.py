@@ -837,6 +837,26 @@ def test_random_scenes_parity(fresh, oracle_mod, seed):
         assert_parity(FilmTable().get_image(), want, *bounds(mode), what=f'random scene {seed} ({k} triangles) {mode} {opts}')
     reset_all()
 
+def test_forty_random_scenes_at_the_stated_bounds(fresh):
+    '''the 40 seeded random scenes of tools/stress_random_scenes.py (1 .. 900 triangles beside the walls,
+    random opaque materials, lights, film sizes, 1 .. 39 spp, batch sizes) through the strict build and the four production
+    kernels, every production film against the strict film at the STATED bounds (99.5 % of the pixels within 1e-3 (1 + |ref|),
+    rel-RMSE <= 1e-3 -- no silent factor) with explicit firefly accounting: a pixel may leave the per-pixel bound only by what
+    ONE replaced sample explains (the largest single sample of that pixel in either film / spp; the films are rendered a
+    frame at a time for that), at most ceil(0.0005 x pixels) pixels per scene may, and the rel-RMSE is taken without them.
+    Also: the binary LDS kernel and the binary gather kernel agree bit for bit on every scene'''
+    from helpers import stress_compare
+    lines, bad, most = [], [], 0
+    for seed in range(100, 140):
+        ok, flies, msgs = stress_compare(seed, log=lines.append)
+        most = max(most, flies)
+        if not ok:
+            bad.append(seed)
+    print('\n'.join(lines))
+    print(f'firefly pixels claimed: at most {most} in a scene; scenes failing: {bad}')
+    assert not bad, (bad, [l for l in lines if '<<<<' in l or 'more than one' in l])
+
+
 def test_textures_and_environment_parity(fresh, oracle_mod):
     from helpers import setup_oracle, assert_parity
     from ptina_amd.things import FilmTable
