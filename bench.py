@@ -445,6 +445,10 @@ def parse_args(argv=None):
     ap.add_argument('--force-comm', action='store_true', help='create the RCCL communicator even for one rank')
     ap.add_argument('--c3-steps', type=int, default=2, help='N > 1: timed steps of the 2048x2048 leg, each --c3-spp samples per pixel (0 = skip it)')
     ap.add_argument('--c3-spp', type=int, default=C3_SPP, help='samples per pixel of one c3 step (BASELINE configs[2]: 256)')
+    ap.add_argument('--host-gather', action='store_true',
+                    help='dress rehearsal on ONE GPU: every rank renders its stripes on device 0 at the same time and the shares travel '
+                         'through files instead of RCCL (which refuses two ranks on one device); not a measurement of anything multi-GPU')
+    ap.add_argument('--save-film', default='', help='rank 0 saves the raw headline film (numpy, [nx * ny, 4] f32) here after the timed steps')
     ap.add_argument('--stub-hang', default='', help='tests only (--stub): "RANK:PHASE" -- that rank stops responding in that phase')
     ap.add_argument('--stub', action='store_true',
                     help='tests only: a stand-in renderer that touches no GPU (checks the launcher and the line format)')
@@ -545,9 +549,13 @@ def _run_rank(args, rank, world, pmc, pmc_source, phases):
         # N > 1 also renders BASELINE configs[2]'s 2048 x 2048 film: capacity at init_things, as in the reference
         eng = setup_engine(scene, NX, NY, mode=args.mode, max_filmsize=(C3_N * C3_N if world > 1 else 2**21))
         c = ctx()
-        if c.lib.mpt_device_count() < world and not _lib.devices_isolated():
+        if c.lib.mpt_device_count() < world and not _lib.devices_isolated() and not args.host_gather:
             raise SystemExit(f'--gpus {world} but only {c.lib.mpt_device_count()} GPU(s) visible')
-        comm = RcclFilm(rank, world, phases) if (world > 1 or args.force_comm) else None
+        if args.host_gather:
+            from ptina_amd.dist import HostFilm
+            comm = HostFilm(rank, world, phases)
+        else:
+            comm = RcclFilm(rank, world, phases) if (world > 1 or args.force_comm) else None
         film = FilmTable()
     if args.chunk >= 0:
         c.set_option('chunk', args.chunk)
@@ -556,7 +564,7 @@ def _run_rank(args, rank, world, pmc, pmc_source, phases):
     c.set_option('batch', SPP)
     if comm:
         comm.set_stripes(NX)                  # every world-th stripe of 16 columns: even load
-    n_gpus = c.get_option('nranks') if comm else 1
+    n_gpus = (comm.world if args.host_gather else c.get_option('nranks')) if comm else 1
     if n_gpus != world:
         raise SystemExit(f'communicator has {n_gpus} ranks, expected {world}')
 
@@ -632,6 +640,13 @@ def _run_rank(args, rank, world, pmc, pmc_source, phases):
     if comm:
         dt_resolve = comm.allreduce_max(dt_resolve)
 
+    if args.save_film and rank == 0:
+        # (tests: the film after every step so far -- the assembled one of a rehearsal, the device's otherwise)
+        import numpy
+        if comm and world > 1 and not args.host_gather:
+            c.call('mpt_flush')
+        numpy.save(args.save_film, comm.film if (args.host_gather and comm and comm.film is not None) else film.get_raw())
+
     # ---- N > 1: BASELINE configs[2] as stated: 2048 x 2048 film, 256 spp per step, striped and gathered the same way
     c3 = None
     if comm and world > 1 and args.c3_steps > 0:
@@ -662,7 +677,10 @@ def _run_rank(args, rank, world, pmc, pmc_source, phases):
         dt3 = comm.allreduce_max(time.perf_counter() - t3)
         kms3, nl3 = c.kernel_time()
         if rank == 0:
-            assert img3 is not None and img3.shape == (C3_N, C3_N, 4) and float(img3[..., 3].min()) == 1.0
+            if args.host_gather:              # (a rehearsal: the device film of rank 0 holds its own stripes only; the assembled film is on the host)
+                assert comm.film.shape == (C3_N * C3_N, 4) and float(comm.film[:, 3].min()) == float(comm.film[:, 3].max()) == c3_spp
+            else:
+                assert img3 is not None and img3.shape == (C3_N, C3_N, 4) and float(img3[..., 3].min()) == 1.0
             m = MODEL['c3']
             launches = (c3_spp + SPP - 1) // SPP
             c3 = {'msamples_s': round(C3_N * C3_N * c3_spp * args.c3_steps / dt3 / 1e6, 3),
@@ -677,7 +695,7 @@ def _run_rank(args, rank, world, pmc, pmc_source, phases):
                            'the clear, the gather and the 64 MiB read-back are not in the model'}
 
     if rank == 0:
-        assert img is not None and img.shape == (NX, NY, 4) and float(img[..., 3].min()) == 1.0
+        assert img is not None and img.shape == (NX, NY, 4) and (args.host_gather or float(img[..., 3].min()) == 1.0)
         total = NX * NY * SPP * args.steps
         avg_kernel_s = kms / 1e3 / max(nlaunch, 1)
         # small launches (N > 1 shares) take 1/G of the CUs each and G of them are resident at once
@@ -710,7 +728,9 @@ def _run_rank(args, rank, world, pmc, pmc_source, phases):
                                    'unidirectional MIS path tracer, depth<=5; step = 32 x render() + get_image() '
                                    '(resolve + D2H), exams/benchmark.py:29-36', 'film': [NX, NY], 'spp': SPP,
                        'mode': args.mode,
-                       'parallelism': f'film columns in 16-wide stripes over {n_gpus} GPUs, RCCL gather' if n_gpus > 1 else 'single GPU'},
+                       'parallelism': (f'REHEARSAL: {n_gpus} processes on ONE GPU, film columns in 16-wide stripes, shares over files (--host-gather)'
+                                       if args.host_gather else
+                                       f'film columns in 16-wide stripes over {n_gpus} GPUs, RCCL gather' if n_gpus > 1 else 'single GPU')},
             'value_resolve_only': round(total / dt_resolve / 1e6, 3),
             'ms_per_step_resolve_only': round(dt_resolve / args.steps * 1e3, 4),
             'roofline': roof,
@@ -756,8 +776,11 @@ def main():
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # nobody launched ranks for us: do it here, before this process makes any HIP call
         from ptina_amd.dist import launch_ranks
+        env = None
+        if args.host_gather:                      # every rank on device 0 (ptina_amd._lib.rank_device reads MIPTINA_DEVICE)
+            env = dict(os.environ, MIPTINA_DEVICE=os.environ.get('MIPTINA_DEVICE', '0'))
         rc, out = launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                               timeout=float(os.environ.get('MIPTINA_LAUNCH_TIMEOUT', '900')))
+                               timeout=float(os.environ.get('MIPTINA_LAUNCH_TIMEOUT', '900')), env=env)
         sys.stdout.write(out)
         sys.stdout.flush()
         sys.exit(rc)

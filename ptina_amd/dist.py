@@ -345,3 +345,111 @@ class RcclFilm:
 
     def close(self):
         self.ctx.call('mpt_comm_destroy')
+
+
+class HostFilm:
+    '''The transport of a dress rehearsal on ONE GPU (bench.py --host-gather; tests/test_parity_gpu.py): RCCL refuses two ranks
+    on one device, so R processes -- each with its own HIP context on device 0, its stripes of the film
+    (mpt_set_stripes(16, r, R)), rendering at the same time -- hand their shares to rank 0 through files in the job's private
+    directory instead of ncclSend / ncclRecv.  Same interface as RcclFilm, the same split (comm_plan = mpt_comm_plan), the same
+    phases in the PhaseLog; everything but the RCCL calls themselves is the code a multi-GPU run executes.  Rank 0 keeps the
+    film it assembled last in `.film` ([nx * ny, 4] f32, index x * ny + y).'''
+
+    def __init__(self, rank=None, world=None, phases=None):
+        from .common import ctx
+        r, w, _ = env_rank()
+        self.rank = r if rank is None else rank
+        self.world = w if world is None else world
+        self.ctx = ctx()
+        self.phases = phases
+        self.dir = phase_dir()
+        if self.world > 1 and not self.dir:
+            raise RuntimeError('HostFilm needs the job directory of launch_ranks (MIPTINA_RDZV_DIR)')
+        self.seq = 0
+        self.stripe_w = 0
+        self.film = None
+        self._gathers = 0
+        self._phase('first barrier')
+        self.barrier()
+        self._phase('communicator ready')
+
+    def _phase(self, name):
+        if self.phases is not None:
+            self.phases.enter(name)
+
+    def _put(self, tag, payload):
+        path = os.path.join(self.dir, '%s_%d_%d' % (tag, self.seq, self.rank))
+        with open(path + '.tmp', 'wb') as f:
+            f.write(payload)
+        os.replace(path + '.tmp', path)
+
+    def _get(self, tag, r, remove=False):
+        path = os.path.join(self.dir, '%s_%d_%d' % (tag, self.seq, r))
+        while True:                                   # (a rank that never comes is the PhaseLog watchdog's business)
+            try:
+                with open(path, 'rb') as f:
+                    data = f.read()
+                if remove:
+                    os.remove(path)
+                return data
+            except FileNotFoundError:
+                time.sleep(0.0005)
+
+    def _allgather(self, tag, payload):
+        if self.world == 1:
+            return [payload]
+        self._put(tag, payload)
+        out = [self._get(tag, r) for r in range(self.world)]
+        self.seq += 1
+        # everybody has passed exchange seq - 2 by now (it took part in seq - 1): its file can go
+        old = os.path.join(self.dir, '%s_%d_%d' % (tag, self.seq - 3, self.rank))
+        try:
+            os.remove(old)
+        except OSError:
+            pass
+        return out
+
+    def set_stripes(self, nx, width=STRIPE):
+        self.stripe_w = int(width)
+        self.ctx.call('mpt_set_stripes', int(width), self.rank, self.world)
+        return stripe_columns(nx, self.world, self.rank, width)
+
+    def gather(self, id=0, root=0):
+        import ctypes as C
+        from ._lib import fptr
+        if self._gathers == 0:
+            self._phase('first gather')
+        nx, ny = C.c_int(0), C.c_int(0)
+        self.ctx.call('mpt_get_size', C.byref(nx), C.byref(ny))
+        nx, ny = nx.value, ny.value
+        raw = np.empty((nx * ny, 4), np.float32)
+        self.ctx.call('mpt_get_film_raw', int(id), fptr(raw))
+        mine = comm_plan(nx, ny, self.stripe_w, self.rank, self.world)
+        if self.world > 1 and self.rank != root:
+            self._put('share', b''.join(raw[o:o + n].tobytes() for o, n in mine))
+        elif self.world > 1:
+            for r in range(self.world):
+                if r == root:
+                    continue
+                data = np.frombuffer(self._get('share', r, remove=True), np.float32).reshape(-1, 4)
+                at = 0
+                for o, n in comm_plan(nx, ny, self.stripe_w, r, self.world):
+                    raw[o:o + n] = data[at:at + n]
+                    at += n
+                assert at == data.shape[0]
+        if self.rank == root:
+            self.film = raw
+        self.seq += 1
+        if self._gathers == 0:
+            self._phase('first gather done')
+        self._gathers += 1
+
+    def barrier(self):
+        self._allgather('barrier', b'')
+
+    def allreduce_max(self, value):
+        import struct
+        return max(struct.unpack('d', b)[0] for b in self._allgather('max', struct.pack('d', float(value))))
+
+    def close(self):
+        pass

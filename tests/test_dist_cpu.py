@@ -330,3 +330,59 @@ def test_bench_rank_that_never_returns_is_reported_with_every_ranks_phase():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--stub',
                         '--stub-hang', '0:CommInitRank:raise', '--c3-steps', '0'], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "failed in phase 'CommInitRank'" in r.stderr, r.stderr
+
+
+def _hostfilm_rank(rank, world, d, nx, ny, q):
+    '''one rank of the HostFilm protocol test: a fake context whose film holds this rank's stripes only'''
+    import ctypes as C
+    os.environ['MIPTINA_RDZV_DIR'] = d
+    from ptina_amd import dist, common
+
+    full = (np.arange(nx * ny * 4, dtype=np.float32).reshape(nx * ny, 4) * 0.5 + 1.0)
+
+    class FakeCtx:
+        def call(self, name, *a):
+            if name == 'mpt_get_size':
+                C.cast(a[0], C.POINTER(C.c_int))[0] = nx
+                C.cast(a[1], C.POINTER(C.c_int))[0] = ny
+            elif name == 'mpt_get_film_raw':
+                out = np.ctypeslib.as_array(C.cast(a[1], C.POINTER(C.c_float)), shape=(nx * ny, 4))
+                out[:] = 0.0
+                for o, n in dist.comm_plan(nx, ny, self.w, rank, world):
+                    out[o:o + n] = full[o:o + n]
+            elif name == 'mpt_set_stripes':
+                self.w = a[0]
+    fake = FakeCtx()
+    common.ctx = lambda: fake
+    dist_ctx = dist.__dict__
+    import ptina_amd.common
+    ptina_amd.common.ctx = lambda: fake
+    hf = dist.HostFilm(rank, world)
+    hf.set_stripes(nx)
+    got = []
+    for k in range(3):
+        hf.gather(0, 0)
+        got.append(hf.allreduce_max(float(rank * 10 + k)))
+        hf.barrier()
+    q.put((rank, got, None if hf.film is None else bool(np.array_equal(hf.film, full))))
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_host_film_rehearsal_transport(tmp_path, world):
+    '''dist.HostFilm (the file transport of `bench.py --host-gather`: R processes on one GPU, because RCCL refuses two ranks on one
+    device): barriers, max-reductions and three gathers in a row over the job directory, world_size 2 and 3, every rank its own
+    process; rank 0 assembles the whole film from the ranks' stripes (the split is mpt_comm_plan's), the others keep none'''
+    import multiprocessing as mp
+    ctxm = mp.get_context('spawn')
+    q = ctxm.Queue()
+    nx, ny = 70, 9
+    ps = [ctxm.Process(target=_hostfilm_rank, args=(r, world, str(tmp_path), nx, ny, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(30)
+        assert p.exitcode == 0
+    for r, got, film_ok in res:
+        assert got == [float((world - 1) * 10 + k) for k in range(3)]
+        assert film_ok is (True if r == 0 else None)

@@ -2296,3 +2296,40 @@ def test_bench_refuses_more_gpus_than_the_box_has(fresh):
                         '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert '"n_gpus"' not in p.stdout
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_processes_render_their_stripes_concurrently_on_one_gpu(fresh, tmp_path, world):
+    '''a dress rehearsal of the N-GPU run with real HIP contexts.  `bench.py --gpus R --host-gather` starts R
+    fresh processes through bench.py's own launcher (ptina_amd.dist.launch_ranks: self-launch before any GPU call, a private
+    rendezvous directory, RANK / WORLD_SIZE / MASTER_*), every rank creates its own context on the one GPU, takes its stripes
+    (mpt_set_stripes(16, r, R)) and renders them WHILE the others render theirs; warm-up, counting steps, timed steps and the
+    2048 x 2048 leg run as in a multi-GPU run, with the PhaseLog watching.  RCCL refuses two ranks on one device, so the shares
+    travel through files (dist.HostFilm) instead of ncclSend / ncclRecv -- the only part of an R > 1 run this does not execute.
+    The film rank 0 assembles must be the single-process film of the same steps, bit for bit.  (R = 4, not 8: a GPU box
+    allows six processes on its card, and this test runner is one of them.)'''
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from ptina_amd.common import reset_all
+    reset_all()                                          # (this process keeps its HIP context but holds no film / slabs meanwhile)
+    common = ['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-pmc', '--no-configs']
+    env = dict(os.environ, MIPTINA_PHASE_TIMEOUT='240', MIPTINA_LAUNCH_TIMEOUT='500')
+    ref = tmp_path / 'ref.npy'
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--save-film', str(ref)] + common,
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    got = tmp_path / f'r{world}.npy'
+    run = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--host-gather', '--c3-steps', '1',
+                          '--c3-spp', '32', '--save-film', str(got)] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == world and 'REHEARSAL' in line['config']['parallelism'] and line['value'] > 0
+    assert line['c3']['n_gpus'] == world and line['c3']['msamples_s'] > 0
+    a, b = np.load(ref), np.load(got)
+    assert a.shape == b.shape == (512 * 512, 4)
+    assert np.all(a[:, 3] == a[0, 3]) and a[0, 3] > 0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    print(f'{world} processes on one GPU: {line["value"]:.0f} Msamples/s (a rehearsal, not a measurement), film == the single-process film, '
+          f'{int(a[0, 3])} samples per pixel')
