@@ -28,6 +28,11 @@ __device__ __forceinline__ MptVec4 film_resolve(MptVec4 v) {
 // (store_sample, render_kernel.hip), which is single-copy atomic: a reader that finds the launch's tag in a half has that half's data,
 // whatever it sees of the other half -- so the tail finalisation's "the data is its own ready flag" needs no property of 16-byte
 // stores (rounds 1-4 used {r, g, b, tag} behind ONE 16-byte store, whose halves are only OBSERVED to land together).
+// What is left as an assumption (round-5 ADVICE): the READER takes an entry with one 16-byte load (raw_buffer_load_b128), and relies
+// on each naturally aligned 8-byte half of that load being read as a unit -- the hardware's memory path moves at least 8-byte
+// aligned units (its granule is 32 bytes), the language's memory model does not spell that out for a vector load.  Two 8-byte
+// relaxed atomic loads per entry would remove the assumption for 0.9 % of the launch; the soaks (profiles/r05_soak_*.log: 120 360
+// launches compared on data) have never seen a torn half.
 typedef unsigned int mpt_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ mpt_u4 slab_pack(float r, float g, float b, unsigned tag16) {
     const unsigned gb = (unsigned)__float_as_int(g);

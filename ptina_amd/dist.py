@@ -74,7 +74,10 @@ def _torchrun_job_dir():
     if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
         raise RuntimeError('%s is not a private directory of this user: remove it or set MIPTINA_RDZV_DIR' % base)
     run = ''.join(ch if ch.isalnum() else '_' for ch in os.environ.get('TORCHELASTIC_RUN_ID', 'none'))[:32]
-    d = os.path.join(base, 'job_%s_%d_%s' % (os.environ.get('MASTER_PORT', '0'), os.getppid(), run))
+    # (the attempt number too: an elastic restart of the same agent must not find the unique id a dead attempt left behind --
+    # it is 128 bytes like a good one, and RCCL's initialisation would hang on it: round-5 ADVICE)
+    attempt = ''.join(ch for ch in os.environ.get('TORCHELASTIC_RESTART_COUNT', '0') if ch.isdigit()) or '0'
+    d = os.path.join(base, 'job_%s_%d_%s_a%s' % (os.environ.get('MASTER_PORT', '0'), os.getppid(), run, attempt))
     os.makedirs(d, mode=0o700, exist_ok=True)
     return d
 

@@ -11,32 +11,43 @@ from .engine.path import PathEngine as DefaultEngine
 from .engine.preview import PreviewEngine
 from .common import ctx
 
-# worker function -> (singleton class, method): pure pass-throughs (reference worker.py:54-87)
+# worker function -> (singleton class, method, the worker function's own parameters: name or (name, default)).  Pure
+# pass-throughs (reference worker.py:29-30,50-87).  The parameter names are the worker API's -- callers may pass them by keyword
+# (round-5 ADVICE: `fast_export_image(pixels=...)`, `load_model(vertices=...)`) -- and the values go on positionally, so the
+# method behind may name its own parameters as it likes.
 _PASS_THROUGH = {
-    'set_size': ('FilmTable', 'set_size'),
-    'get_image': ('FilmTable', 'get_image'),
-    'fast_export_image': ('FilmTable', 'fast_export_image'),
-    'clear_lights': ('LightPool', 'clear'),
-    'set_world_light': ('WorldLight', 'set'),
-    'add_light': ('LightPool', 'add'),
-    'load_model': ('ModelPool', 'load'),
-    'load_images': ('ImagePool', 'load'),
-    'load_materials': ('MaterialPool', 'load'),
-    'build_tree': ('BVHTree', 'build'),
-    'set_camera': ('Camera', 'set_perspective'),
+    'set_size': ('FilmTable', 'set_size', ('nx', 'ny')),
+    'get_image': ('FilmTable', 'get_image', (('id', 0),)),
+    'fast_export_image': ('FilmTable', 'fast_export_image', ('pixels', ('id', 0))),
+    'clear_lights': ('LightPool', 'clear', ()),
+    'set_world_light': ('WorldLight', 'set', ('fac', 'tex')),
+    'add_light': ('LightPool', 'add', ('world', 'color', 'size', 'type')),
+    'load_model': ('ModelPool', 'load', ('vertices', 'mtlids')),
+    'load_images': ('ImagePool', 'load', ('images',)),
+    'load_materials': ('MaterialPool', 'load', ('materials',)),
+    'build_tree': ('BVHTree', 'build', ()),
+    'set_camera': ('Camera', 'set_perspective', ('pers',)),
 }
 
 
-def _pass_through(owner, method):
+def _pass_through(name, owner, method, params):
+    import inspect
+    P = inspect.Parameter
+    sig = inspect.Signature([P(p, P.POSITIONAL_OR_KEYWORD) if isinstance(p, str) else P(p[0], P.POSITIONAL_OR_KEYWORD, default=p[1])
+                             for p in params])
+
     def call(*args, **kwargs):
-        return getattr(getattr(_things, owner)(), method)(*args, **kwargs)
-    call.__doc__ = '%s().%s(...)' % (owner, method)
+        bound = sig.bind(*args, **kwargs)           # (TypeError for a missing / unknown / doubled argument, like a plain def)
+        bound.apply_defaults()
+        return getattr(getattr(_things, owner)(), method)(*bound.args)
+    call.__name__ = call.__qualname__ = name
+    call.__signature__ = sig
+    call.__doc__ = '%s().%s%s' % (owner, method, sig)
     return call
 
 
-for _name, (_owner, _method) in _PASS_THROUGH.items():
-    globals()[_name] = _pass_through(_owner, _method)
-    globals()[_name].__name__ = _name
+for _name, (_owner, _method, _params) in _PASS_THROUGH.items():
+    globals()[_name] = _pass_through(_name, _owner, _method, _params)
 
 
 def init():

@@ -181,7 +181,13 @@ def test_rendezvous_needs_a_common_key(monkeypatch):
     import tempfile
     path = D.rendezvous_path()
     base = os.path.join(tempfile.gettempdir(), 'miptina_%d' % os.getuid())
-    assert path == os.path.join(base, 'job_29511_%d_none' % os.getppid(), 'rccl_uid')
+    assert path == os.path.join(base, 'job_29511_%d_none_a0' % os.getppid(), 'rccl_uid')
+    # an elastic restart of the same agent gets a directory of its own: a unique id the dead attempt left is not found (round-5 ADVICE)
+    monkeypatch.setenv('TORCHELASTIC_RESTART_COUNT', '2')
+    assert D.rendezvous_path() == os.path.join(base, 'job_29511_%d_none_a2' % os.getppid(), 'rccl_uid')
+    import shutil as _sh
+    _sh.rmtree(os.path.dirname(D.rendezvous_path()))
+    monkeypatch.delenv('TORCHELASTIC_RESTART_COUNT')
     st = os.lstat(base)
     assert stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o077)
     assert D.phase_dir() == os.path.dirname(path)

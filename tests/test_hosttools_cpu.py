@@ -8,6 +8,7 @@ import json
 import threading
 
 import numpy as np
+import pytest
 
 
 def test_readobj_layout_and_triangulation():
@@ -230,3 +231,33 @@ def test_readgltf_pinned_to_the_reference_loaders_steps():
             pair.load(i, fac, tex)
     assert np.allclose(pool._fac[1, 0], [0.2, 0.4, 0.6, 1.0]) and pool._tex[1, 0] == 1
     assert np.all(pool._fac[1, 3:] == 0)                                          # the nine unset parameters stay zero (Q7)
+
+
+def test_worker_functions_take_the_reference_parameter_names():
+    '''round-5 ADVICE: the worker facade (reference worker.py:29-87) is called by keyword too -- `fast_export_image(pixels=...)`,
+    `load_model(vertices=..., mtlids=...)`: the generated pass-throughs carry the reference's parameter names and defaults,
+    reject what a plain def would reject, and hand the values on positionally'''
+    import inspect
+    from ptina_amd import worker, things
+    want = {'set_size': '(nx, ny)', 'get_image': '(id=0)', 'fast_export_image': '(pixels, id=0)', 'clear_lights': '()',
+            'set_world_light': '(fac, tex)', 'add_light': '(world, color, size, type)', 'load_model': '(vertices, mtlids)',
+            'load_images': '(images)', 'load_materials': '(materials)', 'build_tree': '()', 'set_camera': '(pers)'}
+    for name, sig in want.items():
+        assert str(inspect.signature(getattr(worker, name))) == sig and getattr(worker, name).__name__ == name
+    with pytest.raises(TypeError):
+        worker.set_size(1)
+    with pytest.raises(TypeError):
+        worker.load_model(vertices=1, faces=2)
+    seen = []
+
+    class FakeFilm:
+        def fast_export_image(self, out, id=0):
+            seen.append((out, id))
+    old = things.FilmTable
+    things.FilmTable = FakeFilm
+    try:
+        worker.fast_export_image(pixels='P', id=2)
+        worker.fast_export_image('Q')
+    finally:
+        things.FilmTable = old
+    assert seen == [('P', 2), ('Q', 0)]

@@ -255,9 +255,25 @@ def shares_sync(name='s978', spp=32, n=512, steps=20):
             FilmTable().get_image()
         dt = (time.perf_counter() - t0) / steps * 1e3
         kms, nl = c.kernel_time()
+        # the same step as a rank that is NOT the root ends it in bench.py (render, flush, wait: no image), and the read-back alone
+        # (resolve + the 4 MiB image over PCIe) on a film nobody is rendering to: what `step - kernel` of a share is made of
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.render(spp)
+            c.call('mpt_flush')
+            c.call('mpt_synchronize')
+        dt_nonroot = (time.perf_counter() - t0) / steps * 1e3
+        kms2, nl2 = c.kernel_time()
+        FilmTable().get_image()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            FilmTable().get_image()
+        dt_read = (time.perf_counter() - t0) / steps * 1e3
         key = f'{parts}' + (f' grid_div={forced}' if forced else '')
         res[key] = {'step_ms': round(dt, 4), 'kernel_ms': round(kms / max(nl, 1), 4), 'last_div': c.get_option('last_div'),
-                    'cur_div': c.get_option('cur_div'), 'speedup_vs_1': None}
+                    'cur_div': c.get_option('cur_div'), 'speedup_vs_1': None,
+                    'step_without_image_ms': round(dt_nonroot, 4), 'kernel_without_image_ms': round(kms2 / max(nl2, 1), 4),
+                    'get_image_alone_ms': round(dt_read, 4)}
         res[key]['speedup_vs_1'] = round(res.get('1', res[key])['step_ms'] / dt, 3)
         print('shares_sync', key, json.dumps(res[key]), flush=True)
     out['shares_sync'] = res
