@@ -59,11 +59,18 @@ if not os.path.exists(PROFILE_FALLBACK):
     PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r04_pmc_summary.json')
 # The gather kernels' roofline (scenes that do not fit LDS): 64-byte records per second against what tools/microbench/gather_microbench
 # reaches with nothing else to do -- a dependent chain of random 64-byte records, four 16-byte loads each, 5 workgroups of 256 lanes per
-# CU, 58 % of the lanes taking part in a step (profiles/r04_gather_microbench.log, MI355X): 193.5 G records/s inside L2, and per size of
+# CU, 58 % of the lanes taking part in a step (profiles/r06_gather_microbench.log, MI355X, re-measured this round): 194.0 G records/s inside L2, and per size of
 # the table beyond it.  A traversal step reads one 64-byte node (four gathers), a triangle test one 48-byte record (three: 0.75 record).
-GATHER_IN_L2_GRECS = 193.48
-GATHER_BEYOND_L2_GRECS = {'c4': 78.4, 'c5': 59.3}     # 16.8 MB table (C4's records: ~15 MB) / 67 MB table (C5's: ~80 MB), same log
-GATHER_L2_HIT = {'c4': 0.67, 'c5': 0.90}              # TCC_HIT / (TCC_HIT + TCC_MISS) of the launches, profiles/r05_pmc_big_summary.json
+GATHER_IN_L2_GRECS = 193.98                           # ... at the kernels' own lane activity (58 %), 5 workgroups per CU
+GATHER_BEYOND_L2_GRECS = {'c4': 79.31, 'c5': 59.18}   # 16.8 MB table (C4's records: ~15 MB) / 67 MB table (C5's: ~80 MB), profiles/r06_gather_microbench.log
+# `frac` is quoted against the FULL-LANE ceiling of the same access form (every lane of every wave taking part:
+# what the kernel would reach if its steps were never short of lanes): 211.4 G records/s inside L2, 79.1 / 58.7 beyond it
+# (profiles/r06_gather_microbench.log, rows "own ... W 5 active 1.00")
+GATHER_FULL_IN_L2_GRECS = 211.41
+GATHER_FULL_BEYOND_L2_GRECS = {'c4': 79.06, 'c5': 58.72}
+GATHER_L2_HIT = {'c4': 0.67, 'c5': 0.90}              # fallback when the run collects no counters: TCC_HIT / (TCC_HIT + TCC_MISS), profiles/r05_pmc_big_summary.json
+CONFIG_PMC_PASSES = [['FETCH_SIZE', 'GRBM_GUI_ACTIVE'], ['WRITE_SIZE', 'TCC_HIT_sum', 'TCC_MISS_sum'],
+                     ['SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES', 'SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU']]
 C3_N = 2048                  # BASELINE.json configs[2]: 2048 x 2048 film ...
 C3_SPP = 256                 # ... at 256 spp: one c3 step = render(256) (eight launches of 32 frames, pipelined) + gather + get_image()
 # the launch model of DESIGN.md section 6, measured on ONE MI355X (tools/gpu_diag.py shares_sync): a launch of 1/N of
@@ -104,7 +111,7 @@ def render_kernel_name(mode, last_kernel):
     return ('render_kernel_fast', 'render_kernel_lds', 'render_kernel_wide', 'render_kernel_pool', 'render_kernel_oct', 'render_kernel_lds4')[last_kernel]
 
 
-def collect_pmc(argv_tail, budget_s=150):
+def collect_pmc(argv_tail, budget_s=150, passes=None, role='pmc-child'):
     '''run this script (role pmc-child: the same steps, nothing printed) under `rocprofv3 --pmc`, one
     pass per counter group, and return {counter: median per 32-spp render launch}.  Called BEFORE the
     parent has made any HIP call; rocprofv3 gets the interpreter itself after `--`.'''
@@ -118,10 +125,11 @@ def collect_pmc(argv_tail, budget_s=150):
     # that the counters come from the queue configuration the timed run uses (option "hw_queues")
     env.setdefault('GPU_MAX_HW_QUEUES', '12')
     try:
-        for i, counters in enumerate(PMC_PASSES):
+        passes = PMC_PASSES if passes is None else passes
+        for i, counters in enumerate(passes):
             d = os.path.join(work, f'pass{i}')
             cmd = [exe, '--pmc', *counters, '--output-format', 'csv', '-d', d, '--',
-                   sys.executable, os.path.abspath(__file__), '--role', 'pmc-child', *argv_tail]
+                   sys.executable, os.path.abspath(__file__), '--role', role, *argv_tail]
             try:
                 p = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                                      start_new_session=True)
@@ -153,7 +161,7 @@ def collect_pmc(argv_tail, budget_s=150):
                 # the 1-spp warm-up frame of the benchmark sequence is a render launch too: keep the big ones
                 big = [v for v in vals if v >= 0.5 * vals[-1]] if vals[-1] > 0 else vals
                 out[cn] = {'median': big[len(big) // 2], 'n': len(big), 'kernel': k}
-        return out, 'rocprofv3 --pmc in this run (%d passes, %s)' % (len(PMC_PASSES), os.path.basename(exe))
+        return out, 'rocprofv3 --pmc in this run (%d passes, %s)' % (len(passes), os.path.basename(exe))
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
@@ -336,6 +344,60 @@ OTHER_CONFIGS = [
 ]
 
 
+CONFIG_PMC = {}      # key -> (counters per launch of the production render kernel, where they come from): filled by main() before the GPU is touched
+
+
+def run_config_child(key, mode):
+    '''role pmc-config-child (under rocprofv3 --pmc): the render launches of one of OTHER_CONFIGS and nothing else'''
+    from ptina_amd import scenes, common
+    from ptina_amd.common import ctx
+    from ptina_amd.things import FilmTable
+    from helpers import setup_engine
+    cfg = [c for c in OTHER_CONFIGS if c[0] == key]
+    if not cfg:
+        raise SystemExit(f'no such configuration: {key}')
+    _, _, name, kw, n, spp, world, _ = cfg[0]
+    eng = setup_engine(scenes.get_scene(name, **kw), n, n, mode=mode, world=world, max_filmsize=max(n * n, 1 << 21))
+    ctx().set_option('batch', SPP)
+    film = FilmTable()
+    eng.render()
+    film.get_image()
+    film.clear()
+    for _ in range(3):
+        eng.render(min(spp, SPP))             # one launch of 32 (c5: 16) frames at a time: the counters are per launch
+        film.get_image()
+    common.reset_all()
+
+
+def gather_roofline(key, name, cnt, n, spp, dt, frames):
+    '''the roofline object of a gather-kernel leg (c4 / c5): 64-byte records per second against tools/microbench/gather_microbench's
+    dependent random 64-byte records, blended harmonically by the L2 hit rate of the leg's own launches'''
+    recs_per_sample = (cnt['n_node'] + 0.75 * cnt['n_tri']) / max(cnt['samples'], 1)
+    achieved = recs_per_sample * n * n * spp / dt / 1e9       # G records/s over the whole step (its launches overlap; the read-back is in it)
+    got, src = CONFIG_PMC.get(key, (None, 'not collected in this run'))
+    g = (lambda c: got[c]['median'] if got and c in got else None)
+    h, h_src = GATHER_L2_HIT[name], 'profiles/r05_pmc_big_summary.json (fallback: ' + src + ')'
+    if g('TCC_HIT_sum') is not None and g('TCC_MISS_sum') is not None and g('TCC_HIT_sum') + g('TCC_MISS_sum') > 0:
+        h, h_src = g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')), src
+    peak_full = 1.0 / (h / GATHER_FULL_IN_L2_GRECS + (1.0 - h) / GATHER_FULL_BEYOND_L2_GRECS[name])
+    peak_own = 1.0 / (h / GATHER_IN_L2_GRECS + (1.0 - h) / GATHER_BEYOND_L2_GRECS[name])
+    traffic = int((g('FETCH_SIZE') + g('WRITE_SIZE')) * 1024) if g('FETCH_SIZE') is not None and g('WRITE_SIZE') is not None else None
+    roof = {
+        'bound': 'gather', 'achieved': round(achieved, 2), 'peak': round(peak_full, 2), 'unit': 'G 64-B records/s', 'frac': round(achieved / peak_full, 4),
+        'traffic': traffic, 'traffic_unit': f'HBM bytes (FETCH_SIZE + WRITE_SIZE) per launch of {frames} frames' if traffic is not None else None,
+        'peak_at_own_lane_activity': round(peak_own, 2), 'frac_at_own_lane_activity': round(achieved / peak_own, 4),
+        'records_per_sample': round(recs_per_sample, 2), 'node_steps_per_ray': round(cnt['n_node'] / max(cnt['rays'], 1), 2),
+        'triangle_tests_per_ray': round(cnt['n_tri'] / max(cnt['rays'], 1), 2), 'l2_hit_rate': round(h, 4), 'l2_hit_rate_from': h_src,
+        'wave_cycles_wait_frac': round(g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'), 3) if g('SQ_WAIT_ANY') and g('SQ_WAVE_CYCLES') else None,
+        'lane_occupancy': round(g('SQ_THREAD_CYCLES_VALU') / (64.0 * g('SQ_ACTIVE_INST_VALU')), 4) if g('SQ_THREAD_CYCLES_VALU') and g('SQ_ACTIVE_INST_VALU') else None,
+        'note': 'records = 4-wide node steps + 0.75 x triangle tests of one step (counting build) / the step\'s wall time; peak = '
+                'tools/microbench/gather_microbench (random dependent 64-byte records, 5 workgroups per CU) with EVERY lane taking part: '
+                f'{GATHER_FULL_IN_L2_GRECS} G records/s inside L2 and {GATHER_FULL_BEYOND_L2_GRECS[name]} beyond, blended harmonically by the L2 hit rate of '
+                'these launches; peak_at_own_lane_activity = the same at the 58 percent of the lanes the kernel\'s steps have '
+                f'({GATHER_IN_L2_GRECS} / {GATHER_BEYOND_L2_GRECS[name]}). HBM bytes are not the limit: `traffic` / launch time is 7-14 percent of the peak'}
+    return roof
+
+
 def run_other_configs(mode, stub=False):
     '''{key: {msamples_s, ms_per_step, kernel, avg_kernel_ms, ...}} for OTHER_CONFIGS; drops the headline's context first'''
     out = {}
@@ -385,11 +447,24 @@ def run_other_configs(mode, stub=False):
             kms, nl = c.kernel_time()
             assert img.shape == (n, n, 4) and float(img[..., 3].min()) == 1.0
             kernel = render_kernel_name(mode, c.get_option('last_kernel'))
+            # launches of one step are pipelined (up to `pipe_depth` in flight, each on its own stream): avg_kernel_ms is a launch's own
+            # duration while it shares the chip, so avg_kernel_ms x launches_per_step / concurrent_launches <= ms_per_step is the check
+            conc = max(1, min(nl // steps, c.get_option('cur_depth')))       # (cur_depth: the slots the launches rotate through, 2 for whole-chip launches)
             out[key] = {'workload': title, 'ntri': int(scene[1].shape[0]), 'msamples_s': round(n * n * spp / dt / 1e6, 1),
                         'ms_per_step': round(dt * 1e3, 3), 'kernel': kernel, 'avg_kernel_ms': round(kms / max(nl, 1), 4),
-                        'launches_per_step': nl // steps, 'steps': steps, 'build_tree_ms': round(build_s * 1e3, 2),
+                        'launches_per_step': nl // steps, 'concurrent_launches': conc, 'steps': steps, 'build_tree_ms': round(build_s * 1e3, 2),
                         'msamples_s_incl_build': round(n * n * spp / (dt + build_s) / 1e6, 1), 'scene_generation_s': round(gen_s, 2)}
             ntri = int(scene[1].shape[0])
+            if kernel in ('render_kernel_lds4', 'render_kernel_lds'):
+                # the same VALU roofline object as the headline's, from this configuration's own counters (collected in this run)
+                got, src = CONFIG_PMC.get(key, (None, 'not collected in this run'))
+                try:
+                    roof, hbm = roofline_blocks(got, src, kernel, kms / 1e3 / max(nl, 1), c.get_option('clock_khz') * 1e3 or 2.4e9, conc)
+                    out[key]['roofline'] = roof
+                    if hbm:
+                        out[key]['hbm'] = hbm
+                except Exception as e:
+                    out[key]['roofline'] = {'bound': 'valu', 'achieved': None, 'counters_from': f'counters unusable ({type(e).__name__}: {e})'}
             if ntri > 8192:
                 # mpt_build_tree against what it has to move: the model in once (96-byte vertices + material id), the records the
                 # kernels walk out once (reference nodes 32 B, binary nodes 64 B, triangle records 64 + 64 + 48 B, 4-wide nodes 128 + 64 B)
@@ -413,18 +488,7 @@ def run_other_configs(mode, stub=False):
                 c.call('mpt_synchronize')
                 cnt = c.counters()
                 c.set_option('count', 0)
-                recs_per_sample = (cnt['n_node'] + 0.75 * cnt['n_tri']) / max(cnt['samples'], 1)
-                achieved = recs_per_sample * n * n * spp / dt / 1e9       # G records/s over the whole step (its launches overlap; the read-back is in it)
-                h = GATHER_L2_HIT[name]
-                peak = 1.0 / (h / GATHER_IN_L2_GRECS + (1.0 - h) / GATHER_BEYOND_L2_GRECS[name])
-                out[key]['roofline'] = {
-                    'bound': 'gather', 'achieved': round(achieved, 2), 'peak': round(peak, 2), 'unit': 'G 64-B records/s', 'frac': round(achieved / peak, 4),
-                    'traffic': None, 'records_per_sample': round(recs_per_sample, 2), 'node_steps_per_ray': round(cnt['n_node'] / max(cnt['rays'], 1), 2),
-                    'triangle_tests_per_ray': round(cnt['n_tri'] / max(cnt['rays'], 1), 2), 'l2_hit_rate': h,
-                    'note': 'records = 4-wide node steps + 0.75 x triangle tests of one step (counting build) / the step\'s wall time; peak = '
-                            'tools/microbench/gather_microbench (random dependent 64-byte records, 5 workgroups per CU, 58 percent of the lanes): 193.5 G records/s '
-                            f'inside L2 and {GATHER_BEYOND_L2_GRECS[name]} beyond, blended harmonically by the L2 hit rate of these launches '
-                            '(profiles/r05_pmc_big_summary.json). HBM bytes are not the limit: FETCH_SIZE of a launch is 7-14 percent of the peak'}
+                out[key]['roofline'] = gather_roofline(key, name, cnt, n, spp, dt, frames)
         except Exception as e:                    # a configuration that fails must not cost the run its headline
             out[key] = {'workload': title, 'error': f'{type(e).__name__}: {e}'}
     common.reset_all()
@@ -452,8 +516,10 @@ def parse_args(argv=None):
     ap.add_argument('--stub-hang', default='', help='tests only (--stub): "RANK:PHASE" -- that rank stops responding in that phase')
     ap.add_argument('--stub', action='store_true',
                     help='tests only: a stand-in renderer that touches no GPU (checks the launcher and the line format)')
-    ap.add_argument('--role', default='main', choices=['main', 'pmc-child'],
-                    help='pmc-child: the same render steps with nothing else around them (run under rocprofv3)')
+    ap.add_argument('--role', default='main', choices=['main', 'pmc-child', 'pmc-config-child'],
+                    help='pmc-child: the same render steps with nothing else around them (run under rocprofv3); pmc-config-child: the '
+                         'render launches of one of the other configurations (--config)')
+    ap.add_argument('--config', default='', help='pmc-config-child: which of OTHER_CONFIGS (c4, c5)')
     return ap.parse_args(argv)
 
 
@@ -807,6 +873,23 @@ def main():
                 pass
         else:
             print('bench.py: ' + pmc_source, file=sys.stderr)
+        # the gather kernels of BASELINE configs 4 and 5: HBM bytes, L2 hit rate and wait fraction of their launches, collected in this run
+        # too (the TA_* / TCP_* counters hung rocprofv3 on this pool and are not asked for)
+        if not args.no_configs and args.scene == 's978':
+            for key in ('c1', 'c3_film_1gpu', 'c4', 'c5'):
+                got, src = collect_pmc(['--config', key, '--mode', args.mode], budget_s=120, role='pmc-config-child',
+                                       passes=CONFIG_PMC_PASSES if key in ('c4', 'c5') else PMC_PASSES[:3])
+                CONFIG_PMC[key] = (got, src)
+                if got is None:
+                    print(f'bench.py: {key}: {src}', file=sys.stderr)
+            try:
+                with open(os.path.join(ROOT, 'gpurun_out', 'bench_pmc_configs.json'), 'w') as f:
+                    json.dump({k: {'counters': v[0], 'from': v[1]} for k, v in CONFIG_PMC.items()}, f, indent=1, sort_keys=True)
+            except OSError:
+                pass
+    if args.role == 'pmc-config-child':
+        run_config_child(args.config, args.mode)
+        return
     run_rank(args, rank, world, pmc, pmc_source)
 
 
