@@ -90,6 +90,7 @@ SIGNATURES = {
     'mpt_get_counters': (_i, [_vp, C.POINTER(Counters)]),
     'mpt_get_timeline': (_i, [_vp, C.POINTER(C.c_ulonglong), _i, C.POINTER(_i)]),
     'mpt_reset_counters': (_i, [_vp]),
+    'mpt_get_lane_hist': (_i, [_vp, C.POINTER(C.c_uint64), _i]),
     'mpt_probe_kernel': (_i, [_vp, _i, _i, C.POINTER(C.c_double)]),
     'mpt_stress_copies': (_i, [_vp, _i, _i]),
     'mpt_kernel_time': (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),

@@ -129,7 +129,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
     if (dev_alloc(&c->mats, (size_t)c->caps.max_materials + 1)) return bail("materials");   // + the default material's record
     if (dev_alloc(&c->images, c->caps.max_textures)) return bail("images");
     if (dev_alloc(&c->lights, MPT_MAX_LIGHTS)) return bail("lights");
-    if (dev_alloc(&c->d_counters, 20)) return bail("counters");
+    if (dev_alloc(&c->d_counters, MPT_COUNTER_WORDS)) return bail("counters");
     if (dev_alloc(&c->d_scratch, 2)) return bail("scratch");
     if (dev_alloc(&c->d_work, MPT_QUEUE_WORDS)) return bail("work counters");   // 8 queue heads, a cache line each
     for (int k = 0; k < MPT_MAX_PIPE; k++) {
@@ -157,7 +157,7 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
         *c->h_watchdog = 0;
         c->d_watchdog = (unsigned int *)dp;
     }
-    hipMemsetAsync(c->d_counters, 0, 20 * sizeof(unsigned long long), c->stream);
+    hipMemsetAsync(c->d_counters, 0, MPT_COUNTER_WORDS * sizeof(unsigned long long), c->stream);
     hipMemsetAsync(c->d_work, 0, MPT_QUEUE_WORDS * sizeof(unsigned int), c->stream);
     {   // unset materials: factor 0 (field-zero, mtllib.py:12-13), texture -1 (deviation Q6)
         std::vector<MptMaterial> z((size_t)c->caps.max_materials + 1);
@@ -367,6 +367,8 @@ extern "C" int mpt_set_option(mpt_ctx *c, const char *key, int value) {
         c->sah_inject_fail = value != 0; c->tree_valid = false;
     } else if (k == "build_phases") {
         c->build_phases = value ? 1 : 0;
+    } else if (k == "lane_hist") {
+        c->lane_hist = value ? 1 : 0;
     } else if (k == "sah_max") {
         c->sah_max = value; c->tree_valid = false;
     } else {
@@ -416,6 +418,7 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "sah_build") *value = c->sah_build;
     else if (k == "sah_fallback") *value = c->sah_fallback;
     else if (k == "build_phases") *value = c->build_phases;
+    else if (k == "lane_hist") *value = c->lane_hist;
     else if (k == "sah_levels") *value = c->sah_stats.levels;
     else if (k == "sah_kelems") *value = (int)(c->sah_stats.elems / 1000);
     else if (k == "sah_chunks") *value = (int)c->sah_stats.chunks;
@@ -740,6 +743,7 @@ static int fill_params(mpt_ctx *c, MptRenderParams &p, int nframes) {
     p.P = c->sP;
     p.film0 = c->film[0]; p.film1 = c->film[1]; p.film2 = c->film[2];
     p.counters = c->d_counters;
+    p.lane_hist = c->lane_hist;
     p.watchdog = c->d_watchdog;
     if (p.world_tex != -1 && (p.world_tex < 0 || p.world_tex >= (int)c->h_images.size()))
         return fail("world light texture %d is not a loaded image", p.world_tex);
@@ -1259,6 +1263,17 @@ extern "C" int mpt_get_counters(mpt_ctx *c, mpt_counters *out) {
     return 0;
 }
 
+// diagnostics (option "lane_hist" = 1 and "count" = 1): out[0 .. 3 x 65) = issued NODE / LEAF / SHADE stages by the number of lanes
+// that took part; out[195 ..) = [stage][depth 0 .. 5][closest, shadow] lane-steps.  Zeroed by mpt_reset_counters
+extern "C" int mpt_get_lane_hist(mpt_ctx *c, unsigned long long *out, int n) {
+    if (use_ro(c)) return 1;
+    if (!out || n < MPT_HIST_WORDS) return fail("mpt_get_lane_hist: the buffer must hold %d words", (int)MPT_HIST_WORDS);
+    if (mpt_flush(c)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, c->d_counters + MPT_HIST_BASE, MPT_HIST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // diagnostics: out[wave][4] = {start, scene ready, queue empty, exit} of the last LDS-kernel launch, 100 MHz ticks
 extern "C" int mpt_get_timeline(mpt_ctx *c, unsigned long long *out, int cap_waves, int *nwaves) {
     if (use_ro(c)) return 1;
@@ -1337,7 +1352,7 @@ extern "C" int mpt_unit_eval(mpt_ctx *c, int kind, const void *in, int in_cols, 
 
 extern "C" int mpt_reset_counters(mpt_ctx *c) {
     if (use(c)) return 1;
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 20 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, MPT_COUNTER_WORDS * sizeof(unsigned long long), c->stream));
     return 0;
 }
 

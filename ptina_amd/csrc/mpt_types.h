@@ -111,6 +111,7 @@ struct MptImage { int32_t nx, ny, base, pad; };   // image.py:14-16
 // 16-bit tags of a launch's sample entries (film_ops.h): 0 = zeroed memory, 1 = a launch that keeps the combine pass, 2 ... 65535 =
 // finalising launches in turn
 enum { MPT_TAG_COMBINE = 1, MPT_TAG_FIRST = 2, MPT_TAG_PERIOD = 65534 };
+enum { MPT_HIST_BASE = 32, MPT_HIST_WORDS = 3 * 65 + 3 * 6 * 2, MPT_COUNTER_WORDS = MPT_HIST_BASE + MPT_HIST_WORDS };
 
 struct MptRenderParams {
     int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders
@@ -160,6 +161,9 @@ struct MptRenderParams {
     unsigned int *fin_counter;
     MptVec4 *image_out;
     uint32_t slab_tag;                       // MPT_TAG_COMBINE, or MPT_TAG_FIRST + launch number mod MPT_TAG_PERIOD
+    // Diagnostics (option "lane_hist", counting kernels only): counters + MPT_HIST_BASE holds, per issued NODE / LEAF / SHADE stage, how
+    // many of the wave's 64 lanes took part ([3][65] stage counts) and whose lanes they were ([3][6 depths][2 ray kinds] lane-steps)
+    int32_t lane_hist;
     // render_kernel_lds4 measures distances along a ray in units of 1 / t_scale (a power of two, so every comparison comes out as it
     // would unscaled): no box of the scene is entered farther than 1 / t_scale from any ray origin, which lets the clamp bit of an
     // FMA stand for max(t, 0) (pt_device.h Stack16W::T_SCALED).  t_unscale = 1 / t_scale

@@ -809,6 +809,18 @@ DEV int lane_from(int v, int byte_lane) { return __builtin_amdgcn_ds_bpermute(by
 #define MPT_STAMP_BEGIN
 #define MPT_STAMP_END(acc)
 #endif
+// diagnostics (counting kernels, option "lane_hist"): one issued stage -- how many lanes took part, and whose (depth, ray kind) they were
+DEV void lane_hist_add(const MptRenderParams &p, int stage, bool part, int depth, int shadow) {
+    unsigned long long *h = p.counters + MPT_HIST_BASE;
+    const bool l0 = (threadIdx.x & 63) == 0;
+    const int n = (int)__builtin_popcountll(__ballot(part));
+    if (l0) atomicAdd(h + stage * 65 + n, 1ull);
+    for (int d = 0; d < 6; d++)
+        for (int k = 0; k < 2; k++) {
+            const int c = (int)__builtin_popcountll(__ballot(part && min(depth, 5) == d && (shadow != 0) == (k != 0)));
+            if (l0 && c) atomicAdd(h + 3 * 65 + (stage * 6 + d) * 2 + k, (unsigned long long)c);
+        }
+}
 DEV int wave_count(bool pred) { return (int)__builtin_popcountll(__ballot(pred)); }
 DEV int wave_count32(bool pred) {            // a count that stays on the scalar unit when compared
     unsigned long long m = __ballot(pred);
@@ -923,6 +935,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
 #endif
             if (cn * MPT_PREF_NODE >= cl * MPT_PREF_LEAF) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
+                if (COUNT && p.lane_hist) lane_hist_add(p, 0, L.st == ST_NODE, L.depth, L.shadow);
                 if (L.st == ST_NODE) {
                     if constexpr (SCENE::OCT) stage_node8_if_built<COUNT>(sc, stk, L, cnt);
                     else if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
@@ -936,6 +949,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 for (int rep = 0; rep < SCENE::NODE_REP; rep++) {
                     if (__ballot(L.st == ST_NODE) == 0ull) break;
                     if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
+                    if (COUNT && p.lane_hist) lane_hist_add(p, 0, L.st == ST_NODE, L.depth, L.shadow);
                     if (L.st == ST_NODE) {
                         if constexpr (SCENE::OCT) stage_node8_if_built<COUNT>(sc, stk, L, cnt);
                         else if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
@@ -945,6 +959,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 MPT_STAMP_END(acc_node)
             } else {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
+                if (COUNT && p.lane_hist) lane_hist_add(p, 1, L.st == ST_LEAF, L.depth, L.shadow);
                 if (L.st == ST_LEAF) {
                     if constexpr (SCENE::OCT) stage_leaf8_if_built<COUNT>(sc, stk, L, cnt);
                     else stage_leaf<COUNT>(sc, stk, L, cnt);
@@ -953,6 +968,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                 for (int rep = 0; rep < SCENE::LEAF_REP; rep++) {
                     if (__ballot(L.st == ST_LEAF) == 0ull) break;
                     if (COUNT && (threadIdx.x & 63) == 0) cnt.it_leaf++;
+                    if (COUNT && p.lane_hist) lane_hist_add(p, 1, L.st == ST_LEAF, L.depth, L.shadow);
                     if (L.st == ST_LEAF) {
                         if constexpr (SCENE::OCT) stage_leaf8_if_built<COUNT>(sc, stk, L, cnt);
                         else stage_leaf<COUNT>(sc, stk, L, cnt);
@@ -983,6 +999,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             }
 #endif
             if (COUNT && (threadIdx.x & 63) == 0) cnt.it_shade++;
+            if (COUNT && p.lane_hist) lane_hist_add(p, 2, L.st == ST_DONE && !L.shadow, L.depth, 0);
             MPT_STAMP_BEGIN
             if (L.st == ST_DONE && !L.shadow) {
                 V3 hitpos, sdir;

@@ -631,8 +631,52 @@ def stamps(name='s978', spp=32, n=512):
     common.reset_all()
 
 
+def lane_hist():
+    '''how many of a wave's 64 lanes take part in an issued NODE / LEAF / SHADE stage, and whose lanes they are
+    (bounce depth, closest-hit or shadow ray) -- counting kernels with option lane_hist, for the headline scene (LDS-resident 4-wide
+    kernel) and the two gather scenes.  Writes gpurun_out/lane_histogram.json'''
+    import ctypes as C
+    res = {}
+    for key, name, kw, n, spp, world in (('s978', 's978', {}, 512, 32, None), ('c4', 'c4', {}, 1024, 16, ([1.0, 1.0, 1.0, 1.0], 0)),
+                                         ('c5', 'c5', {'n': 1000000}, 1024, 8, None)):
+        common.reset_all()
+        eng = setup_engine(scenes.get_scene(name, **kw), n, n, mode='fast', world=world, max_filmsize=max(n * n, 1 << 21))
+        c = ctx()
+        c.set_option('batch', min(spp, 32))
+        eng.render(1)
+        c.call('mpt_synchronize')
+        c.set_option('count', 1)
+        c.set_option('lane_hist', 1)
+        c.call('mpt_reset_counters')
+        eng.render(spp)
+        h = (C.c_uint64 * 231)()
+        c.call('mpt_get_lane_hist', h, 231)
+        c.set_option('count', 0)
+        c.set_option('lane_hist', 0)
+        h = np.array(list(h), dtype=np.float64)
+        out_k = {'kernel': ('gather', 'lds', 'gather4', 'lds_pool', 'gather8', 'lds4')[c.get_option('last_kernel')], 'film': [n, n], 'spp': spp}
+        for si, stage in enumerate(('NODE', 'LEAF', 'SHADE')):
+            hist = h[si * 65:(si + 1) * 65]
+            stages = hist.sum()
+            lanes = (hist * np.arange(65)).sum()
+            comp = h[195 + si * 12:195 + (si + 1) * 12].reshape(6, 2)
+            out_k[stage] = {
+                'stages_issued': int(stages), 'mean_lanes': round(lanes / max(stages, 1), 2),
+                'stages_by_lanes_1_8__57_64': [round(float(hist[1 + 8 * b:9 + 8 * b].sum() / max(stages, 1)), 4) for b in range(8)],
+                'lane_steps_by_depth_closest': [round(float(comp[d, 0] / max(lanes, 1)), 4) for d in range(6)],
+                'lane_steps_by_depth_shadow': [round(float(comp[d, 1] / max(lanes, 1)), 4) for d in range(6)]}
+        res[key] = out_k
+        print('lane_hist', key, json.dumps(out_k), flush=True)
+    out['lane_hist'] = res
+    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'lane_histogram.json'), 'w'), indent=1)
+    save()
+    common.reset_all()
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['parity', 'timing']
+    if 'lane_hist' in what:
+        lane_hist()
     if 'stamps' in what:
         stamps()
     if 'readback' in what:
