@@ -7,10 +7,13 @@
 //   one pass per LEVEL of the wide tree (breadth first, so wide node numbers are the host pass's):
 //     expand   one lane per wide node of the level: grows its four children from the binary records, writes the
 //              128-byte record with exact boxes (wnode) and the 64-byte record with 8-bit child boxes rounded
-//              outwards (qnode), and counts its internal children
-//     scan     exclusive prefix sum of those counts (rocPRIM): where the children's numbers start
+//              outwards (qnode), counts its internal children; the workgroup's exclusive prefix of those counts
+//     totals   one workgroup: prefix sum of the workgroups' totals; the next level's {first node, count}
 //     link     gives the internal children their numbers (level end + prefix + rank) in both records and records
 //              which binary node each of them grows from
+//   The level's first node and count live in a device-side table (lv[level]); the host enqueues eight levels at a time
+//   with grids sized for the most a level can hold (4^level, at most every node) and reads the table back once per group
+//   (round 6: the read-back + rocPRIM scan per level were 0.6 of the 0.9 ms this took at 100 000 triangles).
 // The arithmetic of the quantisation is the host pass's, operation for operation, without contraction (this file
 // is compiled with -ffp-contract=off): both passes produce the same bytes (tests/test_parity_gpu.py).
 // An unused child slot holds the id of leaf slot n -- one extra triangle record of NaNs that no ray can hit -- and a
@@ -18,11 +21,11 @@
 
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 #include <cmath>
 #include "mpt_types.h"
 
 #define WB_BLOCK 256
+#define WB_MAX_LEVELS 64      // levels of the wide tree the level table holds (a binary tree of depth <= 62 collapses into no more)
 
 struct WbChild { int id; float lo[3], hi[3]; };
 
@@ -56,9 +59,12 @@ __device__ __forceinline__ unsigned long long wb_area_fixed(const MptVec4 *__res
 }
 
 // expand: wide nodes [lo, lo + count) of one level.  ncount[t] = internal children of wide node lo + t (0 beyond the level)
-__global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__restrict__ fnode, const int *__restrict__ bin_of, int lo,
-                                                            int count, int empty_id, MptVec4 *__restrict__ wnode, MptVec4 *__restrict__ qnode,
-                                                            int *__restrict__ ncount, unsigned long long *__restrict__ area_sum) {
+__global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__restrict__ fnode, const int *__restrict__ bin_of,
+                                                            const int *__restrict__ lv, int empty_id, MptVec4 *__restrict__ wnode,
+                                                            MptVec4 *__restrict__ qnode, int *__restrict__ offset, int *__restrict__ btot,
+                                                            unsigned long long *__restrict__ area_sum) {
+    const int lo = lv[0], count = lv[1];
+    if ((int)(blockIdx.x * WB_BLOCK) >= count) return;            // (the grid is sized for the most this level can hold)
     const int t = blockIdx.x * WB_BLOCK + threadIdx.x;
     const bool live = t < count;
     const int w = lo + (live ? t : 0);                        // (lanes past the level stay for the wave reduction below and add 0)
@@ -81,7 +87,8 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__re
             if (t) atomicAdd(area_sum, t);
         }
     }
-    if (!live) return;
+    int nint = 0;
+    if (live) {
     while (cnt < 4) {
         int best = -1; float ba = -1.f;
         for (int k = 0; k < cnt; k++)
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__re
     // ---- the exact record: {lo.x[4]} {hi.x[4]} {lo.y[4]} {hi.y[4]} {lo.z[4]} {hi.z[4]} {id[4]} {-}
     float rec[32];
     for (int k = 0; k < 32; k++) rec[k] = 0.f;
-    int ids[4], nint = 0;
+    int ids[4];
     for (int k = 0; k < 4; k++) {
         float l[3] = { 1e30f, 1e30f, 1e30f }, h[3] = { 1e30f, 1e30f, 1e30f };   // unused child: out of every ray's reach
         ids[k] = empty_id;
@@ -138,19 +145,57 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__re
     qo[1] = { scale[1], scale[2], wb_asf((int)qlo[0]), wb_asf((int)qhi[0]) };
     qo[2] = { wb_asf((int)qlo[1]), wb_asf((int)qhi[1]), wb_asf((int)qlo[2]), wb_asf((int)qhi[2]) };
     qo[3] = { wb_asf(ids[0]), wb_asf(ids[1]), wb_asf(ids[2]), wb_asf(ids[3]) };
-    ncount[t] = nint;
+    }
+    // where this node's internal children start among the workgroup's (exclusive prefix, node order), and the workgroup's total
+    __shared__ int wsum[WB_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = nint;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < WB_BLOCK / 64; w++) { const int x = wsum[w]; if (w < wave) base += x; tot += x; }
+    if (live) offset[t] = base + inc - nint;
+    if (threadIdx.x == 0) btot[blockIdx.x] = tot;
+}
+
+// the workgroups' totals -> where each workgroup's children start (bbase), and the next level: {first node, count, levels so far, -}
+__global__ __launch_bounds__(1024) void wb_totals_kernel(const int *__restrict__ lv, int *__restrict__ lv_next, const int *__restrict__ btot,
+                                                        int *__restrict__ bbase, int ni, int *__restrict__ bad) {
+    __shared__ int wsum[16];
+    const int lo = lv[0], count = lv[1], nblk = (count + WB_BLOCK - 1) / WB_BLOCK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < nblk ? btot[b] : 0;
+        int inc = v;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = 0, tot = 0;
+        for (int w = 0; w < 16; w++) { const int x = wsum[w]; if (w < wave) base += x; tot += x; }
+        if (b < nblk) bbase[b] = carry + base + inc - v;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        if (lo + count + carry > ni) { *bad = 1; carry = 0; }              // (a binary tree has ni internal nodes: cannot happen)
+        lv_next[0] = lo + count; lv_next[1] = carry; lv_next[2] = lv[2] + (count > 0 ? 1 : 0); lv_next[3] = 0;
+    }
 }
 
 // link: the internal children of wide node lo + t get the numbers next + offset[t] ... in slot order (the host pass's
 // queue order), in both records; bin_of of the new nodes = the binary node they grow from
-__global__ __launch_bounds__(WB_BLOCK) void wb_link_kernel(int lo, int count, int next, const int *__restrict__ offset,
+__global__ __launch_bounds__(WB_BLOCK) void wb_link_kernel(const int *__restrict__ lv, const int *__restrict__ offset, const int *__restrict__ bbase,
                                                           MptVec4 *__restrict__ wnode, MptVec4 *__restrict__ qnode, int *__restrict__ bin_of) {
+    const int lo = lv[0], count = lv[1], next = lo + count;
     const int t = blockIdx.x * WB_BLOCK + threadIdx.x;
     if (t >= count) return;
     const int w = lo + t;
     MptVec4 idv = wnode[(size_t)w * 8 + 6];
     int ids[4] = { wb_asi(idv.x), wb_asi(idv.y), wb_asi(idv.z), wb_asi(idv.w) };
-    int at = next + offset[t];
+    int at = next + bbase[blockIdx.x] + offset[t];
     bool any = false;
     for (int k = 0; k < 4; k++)
         if (ids[k] >= 0) { bin_of[at] = ids[k]; ids[k] = at++; any = true; }
@@ -183,46 +228,59 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_area_kernel(const MptVec4 *__rest
     }
 }
 
-MPT_KERNEL_API hipError_t mpt_wide_scan_bytes(int ni, size_t *bytes) {
-    int *p = nullptr;
-    return rocprim::exclusive_scan(nullptr, *bytes, p, p, 0, (size_t)std::max(ni, 1), rocprim::plus<int>());
+MPT_KERNEL_API hipError_t mpt_wide_scan_bytes(int ni, size_t *bytes) {      // (the level table + the workgroups' totals and bases)
+    *bytes = ((size_t)WB_MAX_LEVELS + 2) * 4 * sizeof(int) + 2 * ((size_t)std::max(ni, 1) / WB_BLOCK + 2) * sizeof(int) + 64;
+    return hipSuccess;
 }
 
 // Builds the wide records of the binary tree in fnode (ni = n - 1 internal nodes) into wnode [ni][8] / qnode [ni][4]
 // (capacity: one wide node per binary node, the worst case).  Outputs: *nwide, *depth (levels), area sums [0] over the wide
-// nodes' source nodes, [1] over all binary nodes.  Reads back one integer per level (<= ~20 levels).
+// nodes' source nodes, [1] over all binary nodes.  `ncount` [ni] holds the nodes' offsets within their workgroup, `scan_tmp`
+// (mpt_wide_scan_bytes) the level table and the workgroups' totals; `offset` is not used any more.  One read-back per eight levels.
 MPT_KERNEL_API hipError_t mpt_wide_build(const MptVec4 *fnode, int n, MptVec4 *wnode, MptVec4 *qnode, int *bin_of, int *ncount,
                                      int *offset, void *scan_tmp, size_t scan_bytes, double *d_area, int *nwide, int *depth,
                                      double area[2], hipStream_t stream) {
     const int ni = n > 1 ? n - 1 : 0;
     *nwide = 0; *depth = 0; area[0] = area[1] = 0.0;
     if (ni < 1) return hipSuccess;
+    (void)offset;
     hipError_t e;
+    size_t need = 0;
+    mpt_wide_scan_bytes(ni, &need);
+    if (scan_bytes < need) return hipErrorInvalidValue;
+    int *lv = (int *)scan_tmp;                                           // [WB_MAX_LEVELS + 2][4]
+    int *bad = lv + (WB_MAX_LEVELS + 1) * 4;                             // (the last row: error flag)
+    int *btot = lv + (WB_MAX_LEVELS + 2) * 4, *bbase = btot + (ni / WB_BLOCK + 2);
     if ((e = hipMemsetAsync(d_area, 0, 2 * sizeof(double), stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(bin_of, 0, sizeof(int), stream)) != hipSuccess) return e;        // wide node 0 grows from the root
+    if ((e = hipMemsetAsync(lv, 0, (WB_MAX_LEVELS + 2) * 4 * sizeof(int), stream)) != hipSuccess) return e;
+    const int first[4] = { 0, 1, 0, 0 };
+    if ((e = hipMemcpyAsync(lv, first, sizeof first, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     unsigned long long *d_fixed = (unsigned long long *)d_area;          // (two 8-byte words either way)
     hipLaunchKernelGGL(wb_area_kernel, dim3(std::min((ni + WB_BLOCK - 1) / WB_BLOCK, 512)), dim3(WB_BLOCK), 0, stream, fnode, ni, d_fixed + 1);
-    int lo = 0, count = 1, levels = 0;
-    while (count > 0) {
-        levels++;
-        const int grid = (count + WB_BLOCK - 1) / WB_BLOCK;
-        hipLaunchKernelGGL(wb_expand_kernel, dim3(grid), dim3(WB_BLOCK), 0, stream, fnode, bin_of, lo, count, ~n, wnode, qnode, ncount,
-                           d_fixed);
-        if ((e = rocprim::exclusive_scan(scan_tmp, scan_bytes, ncount, offset, 0, (size_t)count, rocprim::plus<int>(), stream)) != hipSuccess) return e;
-        int last[2] = { 0, 0 };
-        if ((e = hipMemcpyAsync(&last[0], offset + (count - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(&last[1], ncount + (count - 1), sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    int level = 0, row[4] = { 0, 1, 0, 0 };
+    long long most = 1;                                                  // the most nodes level `level` can hold: 4^level, at most ni
+    while (row[1] > 0) {
+        if (level >= WB_MAX_LEVELS) return hipErrorInvalidValue;
+        const int group = std::min(level + 8, (int)WB_MAX_LEVELS);
+        for (; level < group; level++) {
+            const int grid = (int)((std::min(most, (long long)ni) + WB_BLOCK - 1) / WB_BLOCK);
+            hipLaunchKernelGGL(wb_expand_kernel, dim3(grid), dim3(WB_BLOCK), 0, stream, fnode, bin_of, lv + level * 4, ~n, wnode, qnode, ncount,
+                               btot, d_fixed);
+            hipLaunchKernelGGL(wb_totals_kernel, dim3(1), dim3(1024), 0, stream, lv + level * 4, lv + (level + 1) * 4, btot, bbase, ni, bad);
+            hipLaunchKernelGGL(wb_link_kernel, dim3(grid), dim3(WB_BLOCK), 0, stream, lv + level * 4, ncount, bbase, wnode, qnode, bin_of);
+            most = std::min(most * 4, (long long)ni);
+        }
+        int isbad = 0;
+        if ((e = hipMemcpyAsync(row, lv + level * 4, sizeof row, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(&isbad, bad, sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        const int made = last[0] + last[1];
-        if (lo + count + made > ni) return hipErrorInvalidValue;            // (a binary tree has ni internal nodes: cannot happen)
-        if (made > 0)
-            hipLaunchKernelGGL(wb_link_kernel, dim3(grid), dim3(WB_BLOCK), 0, stream, lo, count, lo + count, offset, wnode, qnode, bin_of);
-        lo += count; count = made;
+        if (isbad) return hipErrorInvalidValue;
     }
     unsigned long long fixed[2] = { 0ull, 0ull };
     if ((e = hipMemcpyAsync(fixed, d_fixed, sizeof fixed, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     area[0] = (double)fixed[0]; area[1] = (double)fixed[1];              // in units of 2^-40 of the root's area: only their ratio is used
-    *nwide = lo; *depth = levels;
+    *nwide = row[0]; *depth = row[2];
     return hipGetLastError();
 }
