@@ -540,6 +540,7 @@ extern "C" int mpt_load_model(mpt_ctx *c, const float *verts, const int32_t *mtl
         if (!std::isfinite(c->scene_rad)) c->scene_rad = 1e30;
     }
     c->tree_valid = false;
+    c->d_model_stale = true;
     return 0;
 }
 

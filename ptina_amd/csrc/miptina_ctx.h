@@ -154,6 +154,7 @@ struct mpt_ctx {
     int sah_exact_max = 8192;                         // host SAH pass: ranges up to this size are swept exactly (diagnostics)
     int sah_inject_fail = 0;                          // test door: treat the device SAH pass as failed after it ran
     MptSahStats sah_stats{};                          // what the last device SAH pass did
+    bool d_model_stale = true;                        // the device copy of the model (d_verts, d_mtlids) is behind the host's: the next device build uploads
     int lane_hist = 0;                                // diagnostics: counting kernels fill the lane histogram (mpt_get_lane_hist)
     int build_phases = 0;                             // diagnostics: synchronise at the end of every phase of mpt_build_tree and time it
     double build_phase_us[6] = { 0, 0, 0, 0, 0, 0 };   // upload | LBVH | SAH pass | triangle records | 4-wide collapse | total (host clock)

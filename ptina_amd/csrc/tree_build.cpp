@@ -504,6 +504,7 @@ static int build_tree_gpu(mpt_ctx *c, BuildClock &clk) {
         hipFree(c->d_verts); hipFree(c->d_mtlids); c->d_verts = nullptr; c->d_mtlids = nullptr;
         if (dev_alloc(&c->d_verts, (size_t)std::max(n, 1) * 24) || dev_alloc(&c->d_mtlids, (size_t)std::max(n, 1))) return 1;
         c->d_model_cap = std::max(n, 1);
+        c->d_model_stale = true;
     }
     if ((size_t)std::max(n, 1) > c->d_build_cap) {
         hipFree(c->d_cen); hipFree(c->d_bounds); hipFree(c->d_depth); hipFree(c->d_keys_in); hipFree(c->d_keys_out);
@@ -532,10 +533,13 @@ static int build_tree_gpu(mpt_ctx *c, BuildClock &clk) {
         if (dev_alloc(&c->tgeo, (size_t)std::max(n, 1) * 4) || dev_alloc(&c->tshade, (size_t)std::max(n, 1) * 4)) return 1;
         c->tri_cap = std::max(n, 1);
     }
-    if (n > 0) {
+    // the model travels to the device once per ModelPool.load (the reference's load is that copy too, model.py:71-86): a rebuild of
+    // the tree -- another option, another tree kind -- finds it there (1.8 of 5.5 ms at a million triangles)
+    if (n > 0 && c->d_model_stale) {
         HIP_TRY(hipMemcpyAsync(c->d_verts, c->verts.data(), (size_t)n * 24 * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_mtlids, c->mtlids.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     }
+    c->d_model_stale = false;
     clk.mark(0);
     MptLbvhBuffers b{};
     b.verts = c->d_verts; b.mtlids = c->d_mtlids; b.n = n;

@@ -35,7 +35,10 @@ def main():
     except RuntimeError:
         pass                                      # (a library from before round 6: wall times only)
     out = {'scene': name, 'ntri': n, 'runs': []}
+    from ptina_amd.things import ModelPool
     for _ in range(reps):
+        if os.environ.get('BUILD_RESIDENT', '0') != '1':
+            ModelPool().load(scene[0], scene[1])          # (the model in host memory: the build uploads it, as rounds 1-5 timed it)
         c.call('mpt_synchronize')
         t0 = time.perf_counter()
         BVHTree().build()
