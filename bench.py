@@ -54,9 +54,9 @@ SPP = 32
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_SIMD = 256 * 4             # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 SIMD_LANES = 32              # a wave64 VALU instruction issues over 2 cycles on a SIMD-32
-PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r05_pmc_summary.json')
+PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r06_pmc_summary.json')
 if not os.path.exists(PROFILE_FALLBACK):
-    PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r04_pmc_summary.json')
+    PROFILE_FALLBACK = os.path.join(ROOT, 'profiles', 'r05_pmc_summary.json')
 # The gather kernels' roofline (scenes that do not fit LDS): 64-byte records per second against what tools/microbench/gather_microbench
 # reaches with nothing else to do -- a dependent chain of random 64-byte records, four 16-byte loads each, 5 workgroups of 256 lanes per
 # CU, 58 % of the lanes taking part in a step (profiles/r06_gather_microbench.log, MI355X, re-measured this round): 194.0 G records/s inside L2, and per size of
@@ -457,10 +457,14 @@ def run_other_configs(mode, stub=False):
             kernel = render_kernel_name(mode, c.get_option('last_kernel'))
             # launches of one step are pipelined (up to `pipe_depth` in flight, each on its own stream): avg_kernel_ms is a launch's own
             # duration while it shares the chip, so avg_kernel_ms x launches_per_step / concurrent_launches <= ms_per_step is the check
-            conc = max(1, min(nl // steps, c.get_option('cur_depth')))       # (cur_depth: the slots the launches rotate through, 2 for whole-chip launches)
+            # ... `launch_slots` = how many may be in flight (cur_depth: 2 for whole-chip launches), `concurrent_launches` = how many ARE on
+            # average: the launches' summed durations over the step's wall time (1 when a step is one launch)
+            slots = max(1, min(nl // steps, c.get_option('cur_depth')))
+            conc = max(1.0, round(kms / max(steps, 1) / (dt * 1e3), 3)) if nl // steps > 1 else 1
             out[key] = {'workload': title, 'ntri': int(scene[1].shape[0]), 'msamples_s': round(n * n * spp / dt / 1e6, 1),
                         'ms_per_step': round(dt * 1e3, 3), 'kernel': kernel, 'avg_kernel_ms': round(kms / max(nl, 1), 4),
-                        'launches_per_step': nl // steps, 'concurrent_launches': conc, 'steps': steps, 'build_tree_ms': round(build_s * 1e3, 2),
+                        'launches_per_step': nl // steps, 'concurrent_launches': conc, 'launch_slots': slots, 'steps': steps,
+                        'build_tree_ms': round(build_s * 1e3, 2),
                         'rebuild_tree_ms_model_resident': round(rebuild_s * 1e3, 2),
                         'msamples_s_incl_build': round(n * n * spp / (dt + build_s) / 1e6, 1), 'scene_generation_s': round(gen_s, 2)}
             ntri = int(scene[1].shape[0])
