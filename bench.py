@@ -76,7 +76,7 @@ C3_SPP = 256                 # ... at 256 spp: one c3 step = render(256) (eight 
 # the launch model of DESIGN.md section 6, measured on ONE MI355X (tools/gpu_diag.py shares_sync): a launch of 1/N of
 # a film costs a / N + b -- b = the end-of-launch drain, independent of N
 MODEL = {'headline': {'a_ms': 2.18, 'b_ms': 0.17}, 'c3': {'a_ms': 34.0, 'b_ms': 0.17},
-         'from': 'one-GPU share measurements, DESIGN.md section 6 (round 5, render_kernel_lds4: 2.35 / 1.28 / 0.72 / 0.44 ms per launch for N = 1 / 2 / 4 / 8; profiles/r05_shares_sync.json)'}
+         'from': 'one-GPU share measurements, DESIGN.md section 6 (render_kernel_lds4: 2.35 / 1.30 / 0.74 / 0.45 ms per launch for N = 1 / 2 / 4 / 8; profiles/r06_shares_sync.json)'}
 
 PMC_PASSES = [
     ['SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES',

@@ -160,8 +160,8 @@ struct mpt_ctx {
     double build_phase_us[6] = { 0, 0, 0, 0, 0, 0 };   // upload | LBVH | SAH pass | triangle records | 4-wide collapse | total (host clock)
     int sah_fallback = 0;                             // last build: the device SAH pass gave up (1: error, 2: depth) and the host pass ran
     int sah_build = -1;                               // SAH re-partition: 1 on the device (sah_build.hip), 0 host pass, -1 auto
-                                                      // (device above 131072 faces: the host's exact sweep is the better tree
-                                                      // for small scenes and costs them milliseconds)
+                                                      // (device above 8192 faces; below, all of the host pass's splits are exact
+                                                      // sweeps and it costs a millisecond)
     void *sah_ws = nullptr; size_t sah_ws_bytes = 0;  // one allocation, carved up in build_sah_device
     int wide_build = 1;                               // 1: the 4-wide collapse runs on the device (wide_build.hip), 0: host pass
     int *wb_bin_of = nullptr, *wb_ncount = nullptr, *wb_offset = nullptr; void *wb_scan = nullptr; size_t wb_scan_bytes = 0;
