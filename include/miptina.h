@@ -223,7 +223,8 @@ int mpt_get_timeline(mpt_ctx *ctx, unsigned long long *out /* [cap_waves][8] */,
 int mpt_reset_counters(mpt_ctx *ctx);
 /* Diagnostics (options "lane_hist" = 1 and "count" = 1; no counterpart in the reference): out[0 .. 195) = how many NODE / LEAF / SHADE
  * stages the waves issued with k of their 64 lanes taking part ([3][65]); out[195 .. 231) = the lane-steps of those stages by bounce
- * depth and ray kind ([3][6][closest, shadow]).  n = words `out` holds (>= 231). */
+ * depth and ray kind ([3][6][closest, shadow]); out[231 .. 255) = the gather kernels' NODE lane-steps by log2 bucket of the node's
+ * (breadth-first) number.  n = words `out` holds (>= 255). */
 int mpt_get_lane_hist(mpt_ctx *ctx, unsigned long long *out, int n);
 /* Diagnostics: launch a one-workgroup kernel (`threads` lanes, `lds_bytes` of LDS) on a stream of its own
  * while the enqueued render launches keep running, and return the wall time until it has completed --

@@ -1265,7 +1265,8 @@ extern "C" int mpt_get_counters(mpt_ctx *c, mpt_counters *out) {
 }
 
 // diagnostics (option "lane_hist" = 1 and "count" = 1): out[0 .. 3 x 65) = issued NODE / LEAF / SHADE stages by the number of lanes
-// that took part; out[195 ..) = [stage][depth 0 .. 5][closest, shadow] lane-steps.  Zeroed by mpt_reset_counters
+// that took part; out[195 ..) = [stage][depth 0 .. 5][closest, shadow] lane-steps; out[231 .. 255) = the gather kernels' NODE
+// lane-steps by the bucket of the node's number (0 | 1 | 2-3 | 4-7 | ...).  Zeroed by mpt_reset_counters
 extern "C" int mpt_get_lane_hist(mpt_ctx *c, unsigned long long *out, int n) {
     if (use_ro(c)) return 1;
     if (!out || n < MPT_HIST_WORDS) return fail("mpt_get_lane_hist: the buffer must hold %d words", (int)MPT_HIST_WORDS);

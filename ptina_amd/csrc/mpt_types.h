@@ -111,7 +111,7 @@ struct MptImage { int32_t nx, ny, base, pad; };   // image.py:14-16
 // 16-bit tags of a launch's sample entries (film_ops.h): 0 = zeroed memory, 1 = a launch that keeps the combine pass, 2 ... 65535 =
 // finalising launches in turn
 enum { MPT_TAG_COMBINE = 1, MPT_TAG_FIRST = 2, MPT_TAG_PERIOD = 65534 };
-enum { MPT_HIST_BASE = 32, MPT_HIST_WORDS = 3 * 65 + 3 * 6 * 2, MPT_COUNTER_WORDS = MPT_HIST_BASE + MPT_HIST_WORDS };
+enum { MPT_HIST_BASE = 32, MPT_HIST_WORDS = 3 * 65 + 3 * 6 * 2 + 24, MPT_COUNTER_WORDS = MPT_HIST_BASE + MPT_HIST_WORDS };   // + 24: node steps by log2 of the node's number (gather kernels)
 
 struct MptRenderParams {
     int32_t nx, ny, x0, x1;                 // film size and the slab [x0,x1) this context renders

@@ -379,9 +379,22 @@ struct QuantScene {
     static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
     static constexpr bool ODD_IDS = false, T_SCALED = false;
     const MptVec4 *qnode, *tgeo;
+#if MPT_X_TOPCACHE
+    // A/B build (-DMPT_X_TOPCACHE=N): the first N records (the 4-wide nodes are numbered breadth first: the top of the tree) are kept
+    // in the workgroup's LDS; a lane whose node is among them reads it there
+    typedef float top_f4 __attribute__((ext_vector_type(4)));
+    __attribute__((address_space(3))) const top_f4 *top;
+#endif
     DEV void node4q(int i, MptVec4 &a, MptVec4 &b, MptVec4 &c, MptVec4 &id) const {
         const char *base = (const char *)qnode;
         const unsigned o = (unsigned)i << 6;
+#if MPT_X_TOPCACHE
+        if (i < MPT_X_TOPCACHE) {
+            const top_f4 v0 = top[i * 4], v1 = top[i * 4 + 1], v2 = top[i * 4 + 2], v3 = top[i * 4 + 3];
+            a = { v0.x, v0.y, v0.z, v0.w }; b = { v1.x, v1.y, v1.z, v1.w }; c = { v2.x, v2.y, v2.z, v2.w }; id = { v3.x, v3.y, v3.z, v3.w };
+            return;
+        }
+#endif
         a = *(const MptVec4 *)(base + o); b = *(const MptVec4 *)(base + 16 + o);
         c = *(const MptVec4 *)(base + 32 + o); id = *(const MptVec4 *)(base + 48 + o);
 #if MPT_X_DUP_QNODE

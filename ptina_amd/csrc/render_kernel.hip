@@ -821,6 +821,16 @@ DEV void lane_hist_add(const MptRenderParams &p, int stage, bool part, int depth
             if (l0 && c) atomicAdd(h + 3 * 65 + (stage * 6 + d) * 2 + k, (unsigned long long)c);
         }
 }
+// diagnostics: a NODE stage's lane-steps by the bucket of the node's number (0 | 1 | 2-3 | 4-7 | ...): the 4-wide nodes are numbered
+// breadth first, so "number < N" is "the top of the tree" -- what share of the fetches a cache of the top N records would serve
+DEV void node_id_hist_add(const MptRenderParams &p, bool part, int id) {
+    unsigned long long *h = p.counters + MPT_HIST_BASE + 3 * 65 + 3 * 6 * 2;
+    const int b = id <= 0 ? 0 : 32 - __builtin_clz((unsigned)id);
+    for (int k = 0; k < 24; k++) {
+        const int c = (int)__builtin_popcountll(__ballot(part && b == k));
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(h + k, (unsigned long long)c);
+    }
+}
 DEV int wave_count(bool pred) { return (int)__builtin_popcountll(__ballot(pred)); }
 DEV int wave_count32(bool pred) {            // a count that stays on the scalar unit when compared
     unsigned long long m = __ballot(pred);
@@ -936,6 +946,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
             if (cn * MPT_PREF_NODE >= cl * MPT_PREF_LEAF) {
                 if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
                 if (COUNT && p.lane_hist) lane_hist_add(p, 0, L.st == ST_NODE, L.depth, L.shadow);
+                if constexpr (!STACK::ODD_IDS) { if (COUNT && p.lane_hist) node_id_hist_add(p, L.st == ST_NODE, L.curr); }
                 if (L.st == ST_NODE) {
                     if constexpr (SCENE::OCT) stage_node8_if_built<COUNT>(sc, stk, L, cnt);
                     else if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
@@ -950,6 +961,7 @@ DEV void trace_stream(const MptRenderParams &p, const SCENE &sc, STACK stk, Work
                     if (__ballot(L.st == ST_NODE) == 0ull) break;
                     if (COUNT && (threadIdx.x & 63) == 0) cnt.it_node++;
                     if (COUNT && p.lane_hist) lane_hist_add(p, 0, L.st == ST_NODE, L.depth, L.shadow);
+                    if constexpr (!STACK::ODD_IDS) { if (COUNT && p.lane_hist) node_id_hist_add(p, L.st == ST_NODE, L.curr); }
                     if (L.st == ST_NODE) {
                         if constexpr (SCENE::OCT) stage_node8_if_built<COUNT>(sc, stk, L, cnt);
                         else if constexpr (SCENE::WIDE) stage_node4<COUNT>(sc, stk, L, cnt);
@@ -1344,6 +1356,12 @@ __global__ __launch_bounds__(MPT_BLOCK, MPT_WIDE_WAVES) void render_kernel_wide(
     WorkQueue wq; wq.ctr = p.work_counter; wq.nitems = p.nitems; wq.q0 = blockIdx.x & 7; wq.qoff = 0;
     if constexpr (QUANT) {
         QuantScene sc; sc.qnode = p.qnode; sc.tgeo = p.tfast;
+#if MPT_X_TOPCACHE
+        __shared__ __attribute__((aligned(16))) float s_top[MPT_X_TOPCACHE * 16];
+        for (int k = threadIdx.x; k < min(p.nwide, MPT_X_TOPCACHE) * 4; k += MPT_BLOCK) ((MptVec4 *)s_top)[k] = p.qnode[k];
+        __syncthreads();
+        sc.top = (__attribute__((address_space(3))) const QuantScene::top_f4 *)(void *)s_top;
+#endif
         trace_stream<COUNT>(p, sc, stk, wq, cnt);
     } else {
         WideScene sc; sc.wnode = p.wnode; sc.tgeo = p.tfast;

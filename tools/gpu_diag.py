@@ -649,8 +649,8 @@ def lane_hist():
         c.set_option('lane_hist', 1)
         c.call('mpt_reset_counters')
         eng.render(spp)
-        h = (C.c_uint64 * 231)()
-        c.call('mpt_get_lane_hist', h, 231)
+        h = (C.c_uint64 * 255)()
+        c.call('mpt_get_lane_hist', h, 255)
         c.set_option('count', 0)
         c.set_option('lane_hist', 0)
         h = np.array(list(h), dtype=np.float64)
@@ -665,6 +665,11 @@ def lane_hist():
                 'stages_by_lanes_1_8__57_64': [round(float(hist[1 + 8 * b:9 + 8 * b].sum() / max(stages, 1)), 4) for b in range(8)],
                 'lane_steps_by_depth_closest': [round(float(comp[d, 0] / max(lanes, 1)), 4) for d in range(6)],
                 'lane_steps_by_depth_shadow': [round(float(comp[d, 1] / max(lanes, 1)), 4) for d in range(6)]}
+        idh = h[231:255]
+        if idh.sum() > 0:
+            cum = np.cumsum(idh) / idh.sum()
+            out_k['node_steps_with_number_below'] = {str(1 << k): round(float(cum[k]), 4) for k in range(6, 21)}
+            out_k['wide_nodes'] = c.get_option('wide_nodes')
         res[key] = out_k
         print('lane_hist', key, json.dumps(out_k), flush=True)
     out['lane_hist'] = res
