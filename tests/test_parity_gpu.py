@@ -1408,6 +1408,51 @@ def test_device_sah_pass_is_a_valid_deterministic_tree(fresh, n):
     assert cost(a[0]) <= 1.1 * cost(h[0])
 
 
+@pytest.mark.parametrize('kind', ['identical', 'on_a_line', 'huge', 'two_clusters'])
+def test_device_sah_pass_on_degenerate_models(fresh, kind):
+    '''sah_build.hip where no split can be chosen by cost: 3000 copies of ONE triangle (every centre equal: the binned levels halve
+    the ranges by position, the finish kernel in the order of axis 0 -- ties by slot), triangles whose centres differ along x only
+    (two axes never take part), coordinates around 1e18 (areas overflow to infinity: no finite cost, the halving fallback), and two
+    far-apart clusters of identical triangles (one bin boundary separates everything, then nothing does).  A valid tree every
+    time, depth within the stack, built twice: the same bytes; the film finite and every pixel counted'''
+    from ptina_amd.things import init_things, ModelPool, FilmTable, MaterialPool, ImagePool, Camera
+    from ptina_amd.engine.path import PathEngine
+    from ptina_amd.common import ctx
+    n = 3000
+    v, m, mats, _ = scenes.scene_random_tris(n, seed=7, edge=0.05)
+    v = v.reshape(n, 3, 8).copy()
+    if kind == 'identical':
+        v[:] = v[0]
+    elif kind == 'on_a_line':
+        v[:, :, 1:3] = v[0, :, 1:3]
+        v[:, :, 0] = v[0, :, 0] + np.arange(n, dtype=np.float32)[:, None] * 1e-3
+    elif kind == 'huge':
+        v[:, :, :3] *= np.float32(1e18)
+    else:
+        v[:] = v[0]
+        v[n // 3:, :, :3] += np.float32(5.0)
+    v = v.reshape(n * 3, 8)
+    init_things(max_faces=n + 1)
+    eng = PathEngine()
+    FilmTable().set_size(24, 16)
+    ModelPool().load(v, m)
+    MaterialPool().load(mats)
+    ImagePool().load([])
+    c = ctx()
+    a = _sah_tree(c, n, 1)
+    b = _sah_tree(c, n, 1)
+    assert np.array_equal(a[0], b[0]) and a[2] == b[2]
+    ids = a[0][:, 6, :].view(np.int32)
+    assert np.array_equal(np.sort(ids[ids > 0]), np.arange(1, a[3]))
+    assert np.array_equal(np.sort(~ids[(ids < 0) & (ids != ~n)]), np.arange(n))
+    assert 2 < a[2] <= 62
+    Camera().set_perspective(scenes.BENCH_CAMERA)
+    eng.render(2)
+    raw = FilmTable().get_raw()
+    assert np.all(raw[:, 3] == 2) and np.isfinite(raw).all()
+    print(f'{kind}: depth {a[2]}, {a[3]} wide nodes')
+
+
 def test_device_sah_pass_builds_a_tree_as_good_as_the_host_pass(fresh, oracle_mod):
     '''the SAH re-partition on the device (sah_build.hip: binned above 32 triangles, the host pass's exact sweep below)
     against the round-2 host pass (exact sweep up to 8192) on 60 000 random triangles: a valid tree over the same leaf
