@@ -374,7 +374,10 @@ struct WideScene {
 struct QuantScene {
     static constexpr int LEAF_REP = MPT_WIDE_LEAF_REP;
     static constexpr bool AVOID_IN_LEAF = MPT_WIDE_AVOID_IN_LEAF != 0;
-    static constexpr int SHADE_MIN = 0;                // (render_kernel.hip trace_stream: lanes SHADE waits for)
+#ifndef MPT_WIDE_SHADE_MIN
+#define MPT_WIDE_SHADE_MIN 0
+#endif
+    static constexpr int SHADE_MIN = MPT_WIDE_SHADE_MIN;   // (render_kernel.hip trace_stream: lanes SHADE waits for; 0: it never waits)
     static constexpr int NODE_REP = MPT_WIDE_REP;      // extra NODE steps per scheduling decision
     static constexpr bool WIDE = true, QUANT = true, SIGNED_PLANES = false, LDS_MATS = false, OCT = false;
     static constexpr bool ODD_IDS = false, T_SCALED = false;
