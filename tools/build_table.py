@@ -39,6 +39,7 @@ def model(n, nw, st):
         ('sb_reset / pred / newseg / pack (r05)', ['sb_reset_kernel', 'sb_pred_kernel', 'sb_newseg_kernel', 'sb_pack_kernel'], None),
         ('wb_area_kernel', ['wb_area_kernel'], n * 64),
         ('wb_expand_kernel', ['wb_expand_kernel'], nw * 384),
+        ('wb_totals_kernel', ['wb_totals_kernel'], nw * 4 // 256 * 8 + 64),
         ('wb_link_kernel', ['wb_link_kernel'], nw * 48),
         ('rocPRIM scans', ['scan'], None),
         ('copies / fills', ['__amd_rocclr'], None),
