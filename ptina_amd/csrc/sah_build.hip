@@ -888,11 +888,15 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
     const int n = B->n;
     if (n < 2) return hipErrorInvalidValue;
     hipError_t e;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if ((e = sb_big_lds((const void *)sb_bin_kernel)) != hipSuccess) return e;
-        if ((e = sb_big_lds((const void *)sb_choose_kernel)) != hipSuccess) return e;
-        attr_done = true;
+    {   // the two kernels with up to 84 KB of dynamic LDS: the attribute is per device (a process may hold contexts on several)
+        static bool attr_done[64] = { false };
+        int dev = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            if ((e = sb_big_lds((const void *)sb_bin_kernel)) != hipSuccess) return e;
+            if ((e = sb_big_lds((const void *)sb_choose_kernel)) != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
     }
     int meta[META_INTS] = { 0 };
     if ((e = hipMemsetAsync(B->meta, 0, sizeof meta, stream)) != hipSuccess) return e;
