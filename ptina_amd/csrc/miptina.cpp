@@ -426,6 +426,11 @@ extern "C" int mpt_get_option(mpt_ctx *c, const char *key, int *value) {
     else if (k == "sah_part_kwords") *value = (int)(c->sah_stats.part_words / 1000);
     else if (k == "sah_tasks_small") *value = c->sah_stats.tasks_small;
     else if (k == "sah_tasks_big") *value = c->sah_stats.tasks_big;
+    else if (k == "sah_t_sort_k") *value = c->sah_stats.t_sort_k;
+    else if (k == "sah_t_loop_k") *value = c->sah_stats.t_loop_k;
+    else if (k == "sah_t_max_k") *value = c->sah_stats.t_max_k;
+    else if (k == "sah_task_levels") *value = c->sah_stats.task_levels;
+    else if (k == "sah_task_levels_max") *value = c->sah_stats.task_levels_max;
     else if (k.rfind("build_phase_us_", 0) == 0 && k.size() == 16 && k[15] >= '0' && k[15] <= '5') *value = (int)(c->build_phase_us[k[15] - '0'] + 0.5);
     else if (k == "wide_nodes") *value = c->wide_nodes;
     else if (k == "wide_stack") *value = c->wide_stack;

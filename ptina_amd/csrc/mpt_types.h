@@ -79,6 +79,8 @@ struct MptSahStats {
     long long chunks, segments;      // summed over the binned levels
     long long part_words;            // words of chunk bins written, summed over the levels
     int tasks_small, tasks_big;      // ranges finished in LDS: <= 512 triangles, 513 ... 1024
+    int t_sort_k, t_loop_k, t_max_k; // finish kernels, units of 1024 ticks of s_memtime: summed over the tasks in the sort / in the level loop, the longest task
+    int task_levels, task_levels_max; // levels the tasks ran, summed / the most of one task
 };
 
 // device workspace of the SAH re-partition (sah_build.hip); capacities from mpt_sah_*_capacity(n)

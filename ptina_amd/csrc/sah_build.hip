@@ -60,7 +60,8 @@
 
 enum { SEG_B = 0, SEG_E, SEG_NODE, SEG_PAR, SEG_CB, SEG_CHUNK0 = 10, SEG_NCHUNK = 11 };
 enum { DEC_AXIS = 0, DEC_Q, DEC_M, DEC_CHILD0, DEC_CHILD1 };
-enum { META_NSEG = 0, META_NCHUNK, META_NB, META_CH, META_NTASK, META_DEPTH, META_BAD, META_NTASK2, META_ELEMS, META_INTS = 16 };
+enum { META_NSEG = 0, META_NCHUNK, META_NB, META_CH, META_NTASK, META_DEPTH, META_BAD, META_NTASK2, META_ELEMS,
+       META_T_SORT, META_T_LOOP, META_T_MAX, META_T_LEVELS, META_T_MAXLEVELS, META_INTS = 16 };   // META_T_*: the finish kernels' clocks (units of 1024 shader cycles) and levels
 
 __host__ __device__ __forceinline__ int sb_bins_for(long long nseg) {
     int nb = SB_MINBINS;
@@ -553,16 +554,55 @@ struct SfCross { int f[SF_W]; float v[SF_W][6]; };
 // end up to the first range boundary inside it, f = there is such a boundary.  The carry a lane receives is what its
 // positions in front of its first boundary still miss: the aggregates of the lanes before it, walking away from it until
 // one with a boundary has been taken -- first inside its wave (shuffles), then over the waves before (LDS, one barrier).
-__device__ __forceinline__ SfBox sf_carry_from_below(bool f, SfBox v, int lane, int wave, SfCross &X) {      // prefix direction
-    for (int d = 1; d < 64; d <<= 1) {
-        const SfBox ov = sf_shfl_up(v, d);
-        const int of = __shfl_up((int)f, d);
-        if (lane >= d && !f) { sf_add(v, ov); f = of != 0; }
+// The in-wave part runs on DPP moves and v_readlane (VALU), not on ds_bpermute: the finish kernel is bound by the CU's LDS pipe, and
+// with shuffles three quarters of what it put through that pipe were the scans' 42 + 7 ds_bpermute each (round 6: a task of 1024
+// triangles took 0.35 ms; the LDS pipe is shared by every wave of the CU).  A Kogge-Stone scan inside each row of 16 lanes (row_shr /
+// row_shl: 1, 2, 4, 8; a lane without a source gets the identity), then the rows take the aggregates of the rows before them (the
+// row's last / first lane, read with v_readlane), then a one-lane shift of the whole wave makes the result exclusive.
+template <int CTRL> __device__ __forceinline__ int sf_dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ float sf_dpp(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int sf_rl(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ float sf_rl(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+// what lane l receives in the six steps of a scan towards the HIGHER lanes (UP: from l - 1, 2, 4, 8 inside its row; rows 1, 3 from
+// lane 15 / 47; rows 2, 3 from lane 31) and towards the LOWER ones (DN: from l + 1, 2, 4, 8; rows 0, 2 from lane 16 / 48; rows 0, 1
+// from lane 32); I = the identity a lane without a source gets
+template <int STEP, bool UP, class T> __device__ __forceinline__ T sf_from(T I, T x, int row) {
+    if constexpr (STEP == 0) return UP ? sf_dpp<0x111>(I, x) : sf_dpp<0x101>(I, x);
+    else if constexpr (STEP == 1) return UP ? sf_dpp<0x112>(I, x) : sf_dpp<0x102>(I, x);
+    else if constexpr (STEP == 2) return UP ? sf_dpp<0x114>(I, x) : sf_dpp<0x104>(I, x);
+    else if constexpr (STEP == 3) return UP ? sf_dpp<0x118>(I, x) : sf_dpp<0x108>(I, x);
+    else if constexpr (STEP == 4) {
+        const T a = sf_rl(x, UP ? 15 : 16), b = sf_rl(x, UP ? 47 : 48);
+        return UP ? (row == 1 ? a : (row == 3 ? b : I)) : (row == 0 ? a : (row == 2 ? b : I));
+    } else {
+        const T a = sf_rl(x, UP ? 31 : 32);
+        return UP ? (row >= 2 ? a : I) : (row <= 1 ? a : I);
     }
+}
+// the neighbour's value across the whole wave (exclusive result): lane l from l - 1 (UP; lane 0 gets I) or l + 1 (lane 63 gets I)
+template <bool UP, class T> __device__ __forceinline__ T sf_next(T I, T x) { return UP ? sf_dpp<0x138>(I, x) : sf_dpp<0x130>(I, x); }
+
+template <int STEP, bool UP> __device__ __forceinline__ void sf_box_step(int &f, SfBox &v, int row) {
+    SfBox ov;
+    for (int r = 0; r < 3; r++) { ov.l[r] = sf_from<STEP, UP>(INFINITY, v.l[r], row); ov.h[r] = sf_from<STEP, UP>(-INFINITY, v.h[r], row); }
+    const int of = sf_from<STEP, UP>(0, f, row);
+    if (!f) { sf_add(v, ov); f = of; }
+}
+template <bool UP> __device__ __forceinline__ void sf_box_scan(int &f, SfBox &v, int lane) {     // inclusive, in the wave
+    const int row = lane >> 4;
+    sf_box_step<0, UP>(f, v, row); sf_box_step<1, UP>(f, v, row); sf_box_step<2, UP>(f, v, row);
+    sf_box_step<3, UP>(f, v, row); sf_box_step<4, UP>(f, v, row); sf_box_step<5, UP>(f, v, row);
+}
+
+__device__ __forceinline__ SfBox sf_carry_from_below(bool fb, SfBox v, int lane, int wave, SfCross &X) {      // prefix direction
+    int f = fb ? 1 : 0;
+    sf_box_scan<true>(f, v, lane);
     if (lane == 63) { X.f[wave] = f; for (int r = 0; r < 3; r++) { X.v[wave][r] = v.l[r]; X.v[wave][3 + r] = v.h[r]; } }
-    SfBox c = sf_shfl_up(v, 1);
-    int cf = __shfl_up((int)f, 1);
-    if (lane == 0) { sf_clear(c); cf = 0; }
+    SfBox c;
+    for (int r = 0; r < 3; r++) { c.l[r] = sf_next<true>(INFINITY, v.l[r]); c.h[r] = sf_next<true>(-INFINITY, v.h[r]); }
+    const int cf = sf_next<true>(0, f);
     __syncthreads();
     if (!cf)
         for (int w = wave - 1; w >= 0; w--) {
@@ -571,16 +611,13 @@ __device__ __forceinline__ SfBox sf_carry_from_below(bool f, SfBox v, int lane, 
         }
     return c;
 }
-__device__ __forceinline__ SfBox sf_carry_from_above(bool f, SfBox v, int lane, int wave, SfCross &X) {      // suffix direction
-    for (int d = 1; d < 64; d <<= 1) {
-        const SfBox ov = sf_shfl_down(v, d);
-        const int of = __shfl_down((int)f, d);
-        if (lane + d < 64 && !f) { sf_add(v, ov); f = of != 0; }
-    }
+__device__ __forceinline__ SfBox sf_carry_from_above(bool fb, SfBox v, int lane, int wave, SfCross &X) {      // suffix direction
+    int f = fb ? 1 : 0;
+    sf_box_scan<false>(f, v, lane);
     if (lane == 0) { X.f[wave] = f; for (int r = 0; r < 3; r++) { X.v[wave][r] = v.l[r]; X.v[wave][3 + r] = v.h[r]; } }
-    SfBox c = sf_shfl_down(v, 1);
-    int cf = __shfl_down((int)f, 1);
-    if (lane == 63) { sf_clear(c); cf = 0; }
+    SfBox c;
+    for (int r = 0; r < 3; r++) { c.l[r] = sf_next<false>(INFINITY, v.l[r]); c.h[r] = sf_next<false>(-INFINITY, v.h[r]); }
+    const int cf = sf_next<false>(0, f);
     __syncthreads();
     if (!cf)
         for (int w = wave + 1; w < SF_W; w++) {
@@ -590,17 +627,22 @@ __device__ __forceinline__ SfBox sf_carry_from_above(bool f, SfBox v, int lane, 
     return c;
 }
 // (cost, position) minimum, prefix direction; equal costs: the lower position (= the lanes / waves before) wins
-__device__ __forceinline__ void sf_min_from_below(bool f, float &vc, int &vp, int lane, int wave, SfCross &X) {
-    for (int d = 1; d < 64; d <<= 1) {
-        const float oc = __shfl_up(vc, d); const int op = __shfl_up(vp, d), of = __shfl_up((int)f, d);
-        if (lane >= d && !f) {
-            if (op >= 0 && (vp < 0 || oc <= vc)) { vc = oc; vp = op; }
-            f = of != 0;
-        }
+template <int STEP> __device__ __forceinline__ void sf_min_step(int &f, float &vc, int &vp, int row) {
+    const float oc = sf_from<STEP, true>(INFINITY, vc, row);
+    const int op = sf_from<STEP, true>(-1, vp, row), of = sf_from<STEP, true>(0, f, row);
+    if (!f) {
+        if (op >= 0 && (vp < 0 || oc <= vc)) { vc = oc; vp = op; }
+        f = of;
     }
+}
+__device__ __forceinline__ void sf_min_from_below(bool fb, float &vc, int &vp, int lane, int wave, SfCross &X) {
+    int f = fb ? 1 : 0;
+    const int row = lane >> 4;
+    sf_min_step<0>(f, vc, vp, row); sf_min_step<1>(f, vc, vp, row); sf_min_step<2>(f, vc, vp, row);
+    sf_min_step<3>(f, vc, vp, row); sf_min_step<4>(f, vc, vp, row); sf_min_step<5>(f, vc, vp, row);
     if (lane == 63) { X.f[wave] = f; X.v[wave][0] = vc; X.v[wave][1] = __int_as_float(vp); }
-    float cc = __shfl_up(vc, 1); int cp = __shfl_up(vp, 1), cf = __shfl_up((int)f, 1);
-    if (lane == 0) { cc = INFINITY; cp = -1; cf = 0; }
+    float cc = sf_next<true>(INFINITY, vc); int cp = sf_next<true>(-1, vp);
+    const int cf = sf_next<true>(0, f);
     __syncthreads();
     if (!cf)
         for (int w = wave - 1; w >= 0; w--) {
@@ -610,14 +652,18 @@ __device__ __forceinline__ void sf_min_from_below(bool f, float &vc, int &vp, in
         }
     vc = cc; vp = cp;
 }
-__device__ __forceinline__ int sf_sum_from_below(bool f, int v, int lane, int wave, SfCross &X) {
-    for (int d = 1; d < 64; d <<= 1) {
-        const int ov = __shfl_up(v, d), of = __shfl_up((int)f, d);
-        if (lane >= d && !f) { v += ov; f = of != 0; }
-    }
+template <int STEP> __device__ __forceinline__ void sf_sum_step(int &f, int &v, int row) {
+    const int ov = sf_from<STEP, true>(0, v, row), of = sf_from<STEP, true>(0, f, row);
+    if (!f) { v += ov; f = of; }
+}
+__device__ __forceinline__ int sf_sum_from_below(bool fb, int v, int lane, int wave, SfCross &X) {
+    int f = fb ? 1 : 0;
+    const int row = lane >> 4;
+    sf_sum_step<0>(f, v, row); sf_sum_step<1>(f, v, row); sf_sum_step<2>(f, v, row);
+    sf_sum_step<3>(f, v, row); sf_sum_step<4>(f, v, row); sf_sum_step<5>(f, v, row);
     if (lane == 63) { X.f[wave] = f; X.v[wave][0] = __int_as_float(v); }
-    int c = __shfl_up(v, 1), cf = __shfl_up((int)f, 1);
-    if (lane == 0) { c = 0; cf = 0; }
+    int c = sf_next<true>(0, v);
+    const int cf = sf_next<true>(0, f);
     __syncthreads();
     if (!cf)
         for (int w = wave - 1; w >= 0; w--) {
@@ -633,9 +679,9 @@ template <int K> struct SfLds {
     unsigned short ord[2][3][K];             // per axis: local triangle numbers sorted by (centre, slot), ranges kept contiguous
     unsigned short pb[K];                    // per position: first position of its range
     unsigned short se[K];                    // per range start: end of the range
-    int snode[K];                            // per range start: node number
+    int snode[K];                            // per range start: node number; during the sort snode + spar hold the 64-bit keys
     int spar[K];                             // per range start: parent * 2 + side
-    int sdec[K];                             // per range start: axis << 16 | left count; during the sort: the keys
+    int sdec[K];                             // per range start: axis << 16 | left count
     unsigned char side[K];                   // per local triangle: 1 = goes left
     SfCross X[12];                           // one per scan of a level
 };
@@ -658,6 +704,7 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
     const int *T = tasks + (last ? -(ptrdiff_t)(blockIdx.x + 1) : (ptrdiff_t)blockIdx.x) * SB_TASK_INTS;
     const int b0 = T[0], c = T[1] - T[0], node0 = T[2], par0 = T[3], level0 = T[4];
     const MptVec4 *prim = T[5] ? prim1 : prim0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     int kp = 64;                                                  // positions that take part in the sort (a power of two >= c)
     while (kp < c) kp <<= 1;
     for (int i = tid; i < K; i += NT) {
@@ -672,32 +719,44 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
         L.pb[i] = (unsigned short)(i < c ? 0 : i);               // positions past the task's triangles: ranges of one, inert
         L.se[i] = (unsigned short)(i == 0 ? c : i + 1);
     }
-    if (tid == 0) { L.snode[0] = node0; L.spar[0] = par0; }
     __syncthreads();
-    // ---- the three sorted orders: bitonic over kp positions, keys (centre, slot); the padding sorts last
-    unsigned *key = (unsigned *)L.sdec;
+    // ---- the three sorted orders: bitonic over kp positions, keys (centre, slot) in ONE 64-bit word (with the slot looked up through
+    // the order array a compare-exchange was three dependent LDS round trips -- order, slot, then the writes -- and the sort a third
+    // of a task's time); the padding sorts last.  The keys use the words of snode + spar, which are not needed before the levels.
+    unsigned long long *key = (unsigned long long *)(void *)L.snode;
+    static_assert(K <= 1024, "ten bits of a sort key hold the local number");
+    static_assert(offsetof(SfLds<K>, spar) == offsetof(SfLds<K>, snode) + sizeof(int) * K && offsetof(SfLds<K>, snode) % 8 == 0, "the sort keys lie over snode + spar");
     for (int a = 0; a < 3; a++) {
         unsigned short *od = L.ord[0][a];
-        for (int i = tid; i < kp; i += NT) {
-            key[i] = i < c ? sf_key(0.5f * (L.lo[a][i] + L.hi[a][i])) : 0xffffffffu;
-            od[i] = (unsigned short)i;
-        }
+        // key = centre : 32 | slot : 22 | local number : 10 -- the order (centre, slot) and the payload in one word (mpt_sah_build takes
+        // models of up to 2^22 triangles: the cap of option sah_max)
+        for (int i = tid; i < kp; i += NT)
+            key[i] = (i < c ? ((unsigned long long)sf_key(0.5f * (L.lo[a][i] + L.hi[a][i])) << 32) | ((unsigned long long)(unsigned)L.slot[i] << 10)
+                            : 0xfffffffffffffc00ull) | (unsigned)i;
         __syncthreads();
         for (int k = 2; k <= kp; k <<= 1)
             for (int jj = k >> 1; jj > 0; jj >>= 1) {
                 for (int t = tid; t < (kp >> 1); t += NT) {
                     const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), l2 = i | jj;
                     const bool up = (i & k) == 0;
-                    const unsigned ka = key[i], kb = key[l2];
-                    const unsigned short ia = od[i], ib = od[l2];
-                    const bool gt = ka > kb || (ka == kb && L.slot[ia] > L.slot[ib]);
-                    if (gt == up) { key[i] = kb; key[l2] = ka; od[i] = ib; od[l2] = ia; }
+                    const unsigned long long ka = key[i], kb = key[l2];
+                    if ((ka > kb) == up) { key[i] = kb; key[l2] = ka; }
                 }
-                __syncthreads();
+                // A stage whose partners are at most 64 apart stays inside the 128 positions a wave works on (compare-exchange t of a
+                // stage takes positions i(t) and i(t) + jj, and the 64 consecutive t of a wave cover one aligned block of 128 for every
+                // jj <= 64): the wave's own LDS accesses are in order, nobody else's are needed.  Only the stages that reach further
+                // (6 of the 55 at 1024 positions), and the step from a phase's last stage into such a one, wait for the workgroup:
+                // the stamps showed the sort at a third of a task's time, 1 150 cycles per stage, nearly all of it the barrier.
+                if (jj >= 128 || (jj == 1 && k >= 128)) __syncthreads();
+                else __builtin_amdgcn_wave_barrier();
             }
-        for (int i = kp + tid; i < K; i += NT) od[i] = (unsigned short)i;
+        __syncthreads();
+        for (int i = tid; i < K; i += NT) od[i] = (unsigned short)(i < kp ? (unsigned)key[i] & 1023u : (unsigned)i);
         __syncthreads();
     }
+    if (tid == 0) { L.snode[0] = node0; L.spar[0] = par0; }
+    __syncthreads();
+    const unsigned long long t_sorted = __builtin_amdgcn_s_memtime();
     // ---- level by level
     int cur = 0, level = level0, deepest = 0;
     const int i0 = tid * E;
@@ -853,6 +912,14 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
         cur ^= 1; level++;
     }
     if (tid == 0 && deepest > 0) atomicMax(meta + META_DEPTH, deepest);
+    if (tid == 0) {                 // statistics (MptSahStats): where a task's time goes
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        atomicAdd(meta + META_T_SORT, (int)((t_sorted - t_begin) >> 10));
+        atomicAdd(meta + META_T_LOOP, (int)((t_end - t_sorted) >> 10));
+        atomicMax(meta + META_T_MAX, (int)((t_end - t_begin) >> 10));
+        atomicAdd(meta + META_T_LEVELS, level - level0);
+        atomicMax(meta + META_T_MAXLEVELS, level - level0);
+    }
 }
 
 // ------------------------------------------------------------------ driver
@@ -886,7 +953,7 @@ static hipError_t sb_big_lds(const void *fn) {
 // verts [3n][8] and leaf [n] on the device (the LBVH build's); writes fnode [n-1][4] and *depth.  Needs n >= 2.
 MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipStream_t stream) {
     const int n = B->n;
-    if (n < 2) return hipErrorInvalidValue;
+    if (n < 2 || n > (1 << 22)) return hipErrorInvalidValue;      // (22 bits of a sort key hold the slot: sb_finish_kernel)
     hipError_t e;
     {   // the two kernels with up to 84 KB of dynamic LDS: the attribute is per device (a process may hold contexts on several)
         static bool attr_done[64] = { false };
@@ -956,6 +1023,8 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     *depth = meta[META_DEPTH];
     st.tasks_small = ntasks; st.tasks_big = ntasks2;
+    st.t_sort_k = meta[META_T_SORT]; st.t_loop_k = meta[META_T_LOOP]; st.t_max_k = meta[META_T_MAX]; st.task_levels = meta[META_T_LEVELS];
+    st.task_levels_max = meta[META_T_MAXLEVELS];
     if (B->stats) *B->stats = st;
     return hipGetLastError();
 }

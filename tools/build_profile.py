@@ -51,7 +51,8 @@ def main():
         except RuntimeError:
             pass
         try:
-            for k in ('sah_levels', 'sah_kelems', 'sah_chunks', 'sah_segments', 'sah_part_kwords', 'sah_tasks_small', 'sah_tasks_big'):
+            for k in ('sah_levels', 'sah_kelems', 'sah_chunks', 'sah_segments', 'sah_part_kwords', 'sah_tasks_small', 'sah_tasks_big',
+                      'sah_t_sort_k', 'sah_t_loop_k', 'sah_t_max_k', 'sah_task_levels', 'sah_task_levels_max'):
                 run[k] = c.get_option(k)
         except RuntimeError:
             pass
