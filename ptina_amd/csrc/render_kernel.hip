@@ -642,7 +642,12 @@ DEV void stage_leaf(const SCENE &sc, STACK &stk, LaneState &L, Cnt &cnt) {
     }
     int next;
 #if MPT_SPEC_POP
-    if constexpr (STACK::PEEK) { next = spec; L.sp = L.sp - (STACK::SP_ADDR ? STACK::SP_STEP : 1); } else
+    if constexpr (STACK::PEEK) {
+#if MPT_X_LEAFPAIRS      // diagnostic build (counting kernels): how often the entry under a leaf is another leaf (what a two-triangle LEAF step could take along)
+        if (COUNT) { cnt.pl_trips++; if (classify<STACK>(spec) == ST_LEAF && !stop) cnt.pl_local++; }
+#endif
+        next = spec; L.sp = L.sp - (STACK::SP_ADDR ? STACK::SP_STEP : 1);
+    } else
 #endif
     {
         stk.sp = L.sp;
