@@ -156,6 +156,11 @@ extern "C" mpt_ctx *mpt_create(const mpt_caps *caps, int device) {
             hipHostGetDevicePointer(&dp, c->h_watchdog, 0) != hipSuccess) return bail("pinned watchdog flag");
         *c->h_watchdog = 0;
         c->d_watchdog = (unsigned int *)dp;
+        void *dm = nullptr;
+        if (hipHostMalloc((void **)&c->h_sahmeta, 32 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&dm, c->h_sahmeta, 0) != hipSuccess) return bail("pinned build mailbox");
+        c->d_sahmeta = (int *)dm;
+        memset(c->h_sahmeta, 0, 32 * sizeof(int));
     }
     hipMemsetAsync(c->d_counters, 0, MPT_COUNTER_WORDS * sizeof(unsigned long long), c->stream);
     hipMemsetAsync(c->d_work, 0, MPT_QUEUE_WORDS * sizeof(unsigned int), c->stream);
@@ -208,6 +213,7 @@ extern "C" void mpt_destroy(mpt_ctx *c) {
     hipFree(c->wb_bin_of); hipFree(c->wb_ncount); hipFree(c->wb_offset); hipFree(c->wb_scan); hipFree(c->wb_area);
     hipFree(c->d_counters); hipFree(c->d_scratch); hipFree(c->d_work); hipFree(c->d_timeline);
     if (c->h_watchdog) hipHostFree(c->h_watchdog);
+    if (c->h_sahmeta) hipHostFree(c->h_sahmeta);
     if (c->h_stage) hipHostFree(c->h_stage);
     hipFree(c->d_verts); hipFree(c->d_mtlids); hipFree(c->d_cen); hipFree(c->d_bounds); hipFree(c->d_depth);
     hipFree(c->d_keys_in); hipFree(c->d_keys_out); hipFree(c->d_sort_tmp);

@@ -153,6 +153,7 @@ struct mpt_ctx {
     float wide_ratio = 1.f;                           // expected fetches per ray, wide / binary (surface-area sums)
     int sah_exact_max = 8192;                         // host SAH pass: ranges up to this size are swept exactly (diagnostics)
     int sah_inject_fail = 0;                          // test door: treat the device SAH pass as failed after it ran
+    int *h_sahmeta = nullptr, *d_sahmeta = nullptr;   // host-pinned, device-mapped [32]: the SAH pass's per-level hand-back (sah_build.hip plan kernel)
     MptSahStats sah_stats{};                          // what the last device SAH pass did
     bool d_model_stale = true;                        // the device copy of the model (d_verts, d_mtlids) is behind the host's: the next device build uploads
     int lane_hist = 0;                                // diagnostics: counting kernels fill the lane histogram (mpt_get_lane_hist)

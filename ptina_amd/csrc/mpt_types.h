@@ -95,6 +95,7 @@ struct MptSahBuffers {
     int *tasks; size_t task_cap;                         // [task_cap][8] ranges the finish kernel takes
     int *meta;                                           // [16]
     MptSahStats *stats;                                  // host, optional
+    volatile int *mail_host; int *mail_dev;              // host-pinned, device-mapped [32]: where the plan kernel leaves a level's outcome, or null
     MptVec4 *fnode;                                      // out: [n-1][4]
 };
 

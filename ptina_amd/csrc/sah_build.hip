@@ -19,7 +19,7 @@
 //     plan     one workgroup: next level's segment table and chunk list (two prefix sums)
 //     scatter  stable partition of every chunk's records into the other buffer; single triangles write themselves into
 //              their parent's record; the centre bounds of the children that go on as segments are reduced on the way
-//   One 16-byte read-back per level (grid sizes of the next one).
+//   The plan kernel leaves the next level's grid sizes in a pinned host mailbox the host polls (no copy, no stream wait per level).
 //
 //   FINISH: one wave per task (<= 512 triangles), everything in 29 KB of LDS: the task's triangles are sorted once on each
 //   axis by (centre, slot); then level by level over all of the task's ranges at once: segmented suffix / prefix scans of
@@ -31,6 +31,8 @@
 // between ranges.  Deterministic: every decision is a function of sums of integers and min / max of floats, partitions are
 // stable, ties go to the lowest slot.  This file is compiled with -ffp-contract=off.
 
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -401,7 +403,8 @@ __device__ __forceinline__ int sb_block_scan_1024(int v, int *total, int *wsum /
 }
 
 __global__ __launch_bounds__(1024) void sb_plan_kernel(int nseg, const int *__restrict__ seg, int *__restrict__ dec,
-                                                      int *__restrict__ seg_next, int *__restrict__ ch_seg, int *__restrict__ meta) {
+                                                      int *__restrict__ seg_next, int *__restrict__ ch_seg, int *__restrict__ meta,
+                                                      int *mail, int seq) {
     __shared__ int wsum[16];
     __shared__ int sh_nb, sh_ch, sh_elems;
     const int tid = threadIdx.x;
@@ -461,7 +464,17 @@ __global__ __launch_bounds__(1024) void sb_plan_kernel(int nseg, const int *__re
         }
         ch_seg[j] = lo;
     }
-    if (tid == 0) { meta[META_NSEG] = nnext; meta[META_NCHUNK] = nchunks; meta[META_NB] = sh_nb; meta[META_CH] = CH; meta[META_ELEMS] = sh_elems; }
+    if (tid == 0) {
+        meta[META_NSEG] = nnext; meta[META_NCHUNK] = nchunks; meta[META_NB] = sh_nb; meta[META_CH] = CH; meta[META_ELEMS] = sh_elems;
+        if (mail) {
+            // the level's outcome straight into host memory (pinned, mapped), the sequence word last: the host polls that word instead of
+            // enqueueing a copy and waiting for the stream (25 us per level).  What the scatter pass still has to do does not matter to
+            // the host: the next level's launches go behind it on the stream
+            const int v[8] = { nnext, nchunks, sh_nb, CH, sh_elems, meta[META_NTASK], meta[META_NTASK2], meta[META_BAD] };
+            for (int k = 0; k < 8; k++) __hip_atomic_store(mail + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mail + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ top phase: scatter
@@ -966,6 +979,7 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
         }
     }
     int meta[META_INTS] = { 0 };
+    static std::atomic<int> mail_seq{0};                          // (sequence numbers of the mailbox: never reused within a process)
     if ((e = hipMemsetAsync(B->meta, 0, sizeof meta, stream)) != hipSuccess) return e;
     MptSahStats st{};
     int nb = sb_bins_for(1), CH = sb_chunk_for(nb, n);
@@ -1001,11 +1015,32 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
                                    B->segbins);
             hipLaunchKernelGGL(sb_choose_kernel, dim3(nseg), dim3(SB_BLOCK), lds, stream, B->seg[cur], nb, CH, B->part, B->segbins, level, cur ^ 1,
                                B->dec, B->ch_left, B->tasks, (int)B->task_cap, B->meta, B->fnode);
-            hipLaunchKernelGGL(sb_plan_kernel, dim3(1), dim3(1024), 0, stream, nseg, B->seg[cur], B->dec, B->seg[cur ^ 1], chs_next, B->meta);
+            const int seq = ++mail_seq;
+            hipLaunchKernelGGL(sb_plan_kernel, dim3(1), dim3(1024), 0, stream, nseg, B->seg[cur], B->dec, B->seg[cur ^ 1], chs_next, B->meta,
+                               B->mail_dev, seq);
             hipLaunchKernelGGL(sb_scatter_kernel, dim3(nchunks), dim3(SB_BLOCK), 0, stream, B->prim[cur], B->prim[cur ^ 1], B->seg[cur],
                                chs_cur, B->dec, B->ch_left, nb, CH, B->seg[cur ^ 1], B->fnode);
-            if ((e = hipMemcpyAsync(meta, B->meta, sizeof meta, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            bool mailed = false;
+            if (B->mail_host) {
+                // poll the mailbox (a stream error ends the wait; after 200 ms without the word the ordinary read-back takes over)
+                const auto t0 = std::chrono::steady_clock::now();
+                for (unsigned spin = 0;; spin++) {
+                    if (__atomic_load_n((const int *)(B->mail_host + 8), __ATOMIC_ACQUIRE) == seq) { mailed = true; break; }
+                    if ((spin & 1023u) == 1023u) {
+                        const hipError_t q = hipStreamQuery(stream);
+                        if (q != hipSuccess && q != hipErrorNotReady) return q;
+                        if (q == hipSuccess && __atomic_load_n((const int *)(B->mail_host + 8), __ATOMIC_ACQUIRE) != seq) break;   // (the stream is done and nothing came)
+                        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+                    }
+                }
+            }
+            if (mailed) {
+                meta[META_NSEG] = B->mail_host[0]; meta[META_NCHUNK] = B->mail_host[1]; meta[META_NB] = B->mail_host[2]; meta[META_CH] = B->mail_host[3];
+                meta[META_ELEMS] = B->mail_host[4]; meta[META_NTASK] = B->mail_host[5]; meta[META_NTASK2] = B->mail_host[6]; meta[META_BAD] = B->mail_host[7];
+            } else {
+                if ((e = hipMemcpyAsync(meta, B->meta, sizeof meta, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+                if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            }
             if (meta[META_BAD]) return hipErrorInvalidValue;
             nseg = meta[META_NSEG]; nchunks = meta[META_NCHUNK]; nb = meta[META_NB]; CH = meta[META_CH];
             cur ^= 1; level++;

@@ -455,6 +455,7 @@ static int build_sah_device(mpt_ctx *c) {
     B.tasks = (int *)take(TC * 32); B.task_cap = TC;
     B.meta = (int *)take(64);
     B.stats = &c->sah_stats;
+    B.mail_host = c->h_sahmeta; B.mail_dev = c->d_sahmeta;
     B.fnode = c->fnode;
     int depth = 0;
     hipError_t e = mpt_sah_build(&B, &depth, c->stream);
