@@ -67,7 +67,7 @@ MPT_KERNEL_API hipError_t mpt_sah_build(const MptSahBuffers *B, int *depth, hipS
 MPT_KERNEL_API hipError_t mpt_wide_scan_bytes(int ni, size_t *bytes);
 MPT_KERNEL_API hipError_t mpt_wide_build(const MptVec4 *fnode, int n, MptVec4 *wnode, MptVec4 *qnode, int *bin_of, int *ncount,
                                      int *offset, void *scan_tmp, size_t scan_bytes, double *d_area, int *nwide, int *depth,
-                                     double area[2], hipStream_t stream);
+                                     double area[2], hipStream_t stream, volatile int *mail_host, int *mail_dev);
 MPT_KERNEL_API hipError_t mpt_launch_permute_tris(const MptVec4 *tfast, const MptVec4 *tshade, const int32_t *perm, MptVec4 *tfast8,
                                               MptVec4 *tshade8, int n, hipStream_t stream);
 MPT_KERNEL_API hipError_t mpt_oct_blocks(int grid, int count, int *blocks);

@@ -766,7 +766,7 @@ static int make_wide_device(mpt_ctx *c) {
     int nw = 0, depth = 0;
     double area[2] = { 0.0, 0.0 };
     HIP_TRY(mpt_wide_build(c->fnode, n, c->wnode, c->qnode, c->wb_bin_of, c->wb_ncount, c->wb_offset, c->wb_scan, c->wb_scan_bytes,
-                           c->wb_area, &nw, &depth, area, c->stream));
+                           c->wb_area, &nw, &depth, area, c->stream, c->h_sahmeta, c->d_sahmeta));
     // a step pushes up to three entries: 3 x depth + sentinel must fit the LDS levels plus the spill strip
     if (3 * depth + 2 > 128) return 0;      // too deep: the gather kernel keeps walking the binary tree
     c->wide_nodes = nw; c->wide_depth = depth;

@@ -19,6 +19,8 @@
 // An unused child slot holds the id of leaf slot n -- one extra triangle record of NaNs that no ray can hit -- and a
 // box no ray enters; round 2 stored id 0 there, the root, which a ray along (1,1,1) could be sent back to.
 
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_expand_kernel(const MptVec4 *__re
 
 // the workgroups' totals -> where each workgroup's children start (bbase), and the next level: {first node, count, levels so far, -}
 __global__ __launch_bounds__(1024) void wb_totals_kernel(const int *__restrict__ lv, int *__restrict__ lv_next, const int *__restrict__ btot,
-                                                        int *__restrict__ bbase, int ni, int *__restrict__ bad) {
+                                                        int *__restrict__ bbase, int ni, int *__restrict__ bad, int *mail, int seq) {
     __shared__ int wsum[16];
     const int lo = lv[0], count = lv[1], nblk = (count + WB_BLOCK - 1) / WB_BLOCK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -181,7 +183,13 @@ __global__ __launch_bounds__(1024) void wb_totals_kernel(const int *__restrict__
     }
     if (threadIdx.x == 0) {
         if (lo + count + carry > ni) { *bad = 1; carry = 0; }              // (a binary tree has ni internal nodes: cannot happen)
-        lv_next[0] = lo + count; lv_next[1] = carry; lv_next[2] = lv[2] + (count > 0 ? 1 : 0); lv_next[3] = 0;
+        const int row[4] = { lo + count, carry, lv[2] + (count > 0 ? 1 : 0), 0 };
+        for (int k = 0; k < 4; k++) lv_next[k] = row[k];
+        if (mail) {     // the last level of a group: the row and the error flag straight into the host's pinned mailbox, the sequence word last
+            for (int k = 0; k < 4; k++) __hip_atomic_store(mail + 16 + k, row[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mail + 20, *bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mail + 24, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -239,7 +247,7 @@ MPT_KERNEL_API hipError_t mpt_wide_scan_bytes(int ni, size_t *bytes) {      // (
 // (mpt_wide_scan_bytes) the level table and the workgroups' totals; `offset` is not used any more.  One read-back per eight levels.
 MPT_KERNEL_API hipError_t mpt_wide_build(const MptVec4 *fnode, int n, MptVec4 *wnode, MptVec4 *qnode, int *bin_of, int *ncount,
                                      int *offset, void *scan_tmp, size_t scan_bytes, double *d_area, int *nwide, int *depth,
-                                     double area[2], hipStream_t stream) {
+                                     double area[2], hipStream_t stream, volatile int *mail_host, int *mail_dev) {
     const int ni = n > 1 ? n - 1 : 0;
     *nwide = 0; *depth = 0; area[0] = area[1] = 0.0;
     if (ni < 1) return hipSuccess;
@@ -263,18 +271,38 @@ MPT_KERNEL_API hipError_t mpt_wide_build(const MptVec4 *fnode, int n, MptVec4 *w
     while (row[1] > 0) {
         if (level >= WB_MAX_LEVELS) return hipErrorInvalidValue;
         const int group = std::min(level + 8, (int)WB_MAX_LEVELS);
+        static std::atomic<int> mail_seq{0};
+        const int seq = ++mail_seq;
         for (; level < group; level++) {
             const int grid = (int)((std::min(most, (long long)ni) + WB_BLOCK - 1) / WB_BLOCK);
             hipLaunchKernelGGL(wb_expand_kernel, dim3(grid), dim3(WB_BLOCK), 0, stream, fnode, bin_of, lv + level * 4, ~n, wnode, qnode, ncount,
                                btot, d_fixed);
-            hipLaunchKernelGGL(wb_totals_kernel, dim3(1), dim3(1024), 0, stream, lv + level * 4, lv + (level + 1) * 4, btot, bbase, ni, bad);
+            const bool last_of_group = level + 1 == group && mail_host != nullptr;
+            hipLaunchKernelGGL(wb_totals_kernel, dim3(1), dim3(1024), 0, stream, lv + level * 4, lv + (level + 1) * 4, btot, bbase, ni, bad,
+                               last_of_group ? mail_dev : (int *)nullptr, seq);
             hipLaunchKernelGGL(wb_link_kernel, dim3(grid), dim3(WB_BLOCK), 0, stream, lv + level * 4, ncount, bbase, wnode, qnode, bin_of);
             most = std::min(most * 4, (long long)ni);
         }
         int isbad = 0;
-        if ((e = hipMemcpyAsync(row, lv + level * 4, sizeof row, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(&isbad, bad, sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        bool mailed = false;
+        if (mail_host) {        // (the link kernel of the group's last level may still run: what follows goes behind it on the stream)
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spin = 0;; spin++) {
+                if (__atomic_load_n((const int *)(mail_host + 24), __ATOMIC_ACQUIRE) == seq) { mailed = true; break; }
+                if ((spin & 1023u) == 1023u) {
+                    const hipError_t q = hipStreamQuery(stream);
+                    if (q != hipSuccess && q != hipErrorNotReady) return q;
+                    if (q == hipSuccess && __atomic_load_n((const int *)(mail_host + 24), __ATOMIC_ACQUIRE) != seq) break;
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+                }
+            }
+        }
+        if (mailed) { for (int k = 0; k < 4; k++) row[k] = mail_host[16 + k]; isbad = mail_host[20]; }
+        else {
+            if ((e = hipMemcpyAsync(row, lv + level * 4, sizeof row, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+            if ((e = hipMemcpyAsync(&isbad, bad, sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        }
         if (isbad) return hipErrorInvalidValue;
     }
     unsigned long long fixed[2] = { 0ull, 0ull };
