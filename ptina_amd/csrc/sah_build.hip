@@ -689,15 +689,20 @@ __device__ __forceinline__ int sf_sum_from_below(bool fb, int v, int lane, int w
 template <int K> struct SfLds {
     float lo[3][K], hi[3][K];                // boxes by local triangle number
     int slot[K];
-    unsigned short ord[2][3][K];             // per axis: local triangle numbers sorted by (centre, slot), ranges kept contiguous
-    unsigned short pb[K];                    // per position: first position of its range
-    unsigned short se[K];                    // per range start: end of the range
-    int snode[K];                            // per range start: node number; during the sort snode + spar hold the 64-bit keys
-    int spar[K];                             // per range start: parent * 2 + side
-    int sdec[K];                             // per range start: axis << 16 | left count
+    unsigned short ord0[3][K];               // per axis: local triangle numbers sorted by (centre, slot), ranges kept contiguous ...
+    unsigned short pb[K];                    // per position: first position of its range; | SF_ONE for a range of one (finished)
+    // (from here to snode the words hold the 64-bit sort keys until the three orders are made: 8 K bytes)
+    unsigned short ord1[3][K];               // ... and the other half of the ping-pong
+    // tables of the ranges of two or more positions, by (first position >> 1): two such ranges never start at neighbouring positions
+    unsigned short se[K / 2];                // end of the range
+    int snode[K / 2];                        // node number
+    int spar[K / 2];                         // parent * 2 + side
+    int sdec[K / 2];                         // axis << 16 | left count
     unsigned char side[K];                   // per local triangle: 1 = goes left
     SfCross X[12];                           // one per scan of a level
+    __device__ __forceinline__ unsigned short *ord(int which, int a) { return which ? ord1[a] : ord0[a]; }
 };
+#define SF_ONE 0x8000
 
 __device__ __forceinline__ unsigned sf_key(float c) {           // order-preserving, -0 == +0
     const unsigned u = (unsigned)__float_as_int(c + 0.0f);
@@ -729,18 +734,18 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
         }
         for (int a = 0; a < 3; a++) { L.lo[a][i] = l[a]; L.hi[a][i] = h[a]; }
         L.slot[i] = sl;
-        L.pb[i] = (unsigned short)(i < c ? 0 : i);               // positions past the task's triangles: ranges of one, inert
-        L.se[i] = (unsigned short)(i == 0 ? c : i + 1);
+        L.pb[i] = (unsigned short)(i < c ? 0 : (i | SF_ONE));    // positions past the task's triangles: ranges of one, inert
     }
     __syncthreads();
     // ---- the three sorted orders: bitonic over kp positions, keys (centre, slot) in ONE 64-bit word (with the slot looked up through
     // the order array a compare-exchange was three dependent LDS round trips -- order, slot, then the writes -- and the sort a third
-    // of a task's time); the padding sorts last.  The keys use the words of snode + spar, which are not needed before the levels.
-    unsigned long long *key = (unsigned long long *)(void *)L.snode;
+    // of a task's time); the padding sorts last.  The keys use the words of ord1 + se + snode, which are not needed before the levels.
+    unsigned long long *key = (unsigned long long *)(void *)L.ord1;
     static_assert(K <= 1024, "ten bits of a sort key hold the local number");
-    static_assert(offsetof(SfLds<K>, spar) == offsetof(SfLds<K>, snode) + sizeof(int) * K && offsetof(SfLds<K>, snode) % 8 == 0, "the sort keys lie over snode + spar");
+    static_assert(offsetof(SfLds<K>, ord1) % 8 == 0 && offsetof(SfLds<K>, spar) - offsetof(SfLds<K>, ord1) >= 8 * K &&
+                  offsetof(SfLds<K>, pb) < offsetof(SfLds<K>, ord1), "the sort keys lie over ord1 + se + snode");
     for (int a = 0; a < 3; a++) {
-        unsigned short *od = L.ord[0][a];
+        unsigned short *od = L.ord0[a];
         // key = centre : 32 | slot : 22 | local number : 10 -- the order (centre, slot) and the payload in one word (mpt_sah_build takes
         // models of up to 2^22 triangles: the cap of option sah_max)
         for (int i = tid; i < kp; i += NT)
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
         for (int i = tid; i < K; i += NT) od[i] = (unsigned short)(i < kp ? (unsigned)key[i] & 1023u : (unsigned)i);
         __syncthreads();
     }
-    if (tid == 0) { L.snode[0] = node0; L.spar[0] = par0; }
+    if (tid == 0) { L.se[0] = (unsigned short)c; L.snode[0] = node0; L.spar[0] = par0; }
     __syncthreads();
     const unsigned long long t_sorted = __builtin_amdgcn_s_memtime();
     // ---- level by level
@@ -779,10 +784,11 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
         unsigned head = 0, tail = 0, act = 0;
 #pragma unroll
         for (int j = 0; j < E; j++) {
-            pb[j] = L.pb[i0 + j]; pe[j] = L.se[pb[j]];
+            const int raw = L.pb[i0 + j];
+            pb[j] = raw & (SF_ONE - 1); pe[j] = (raw & SF_ONE) ? pb[j] + 1 : L.se[pb[j] >> 1];
             if (i0 + j == pb[j]) head |= 1u << j;
             if (i0 + j == pe[j] - 1) tail |= 1u << j;
-            if (pe[j] - pb[j] >= 2) act |= 1u << j;
+            if (!(raw & SF_ONE)) act |= 1u << j;
         }
         if (!__syncthreads_or(act != 0)) break;
         deepest = level;
@@ -790,7 +796,7 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
 #pragma unroll
         for (int j = 0; j < E; j++) { best[j] = INFINITY; bestak[j] = -1; }
         for (int a = 0; a < 3; a++) {
-            const unsigned short *od = L.ord[cur][a];
+            const unsigned short *od = L.ord(cur, a);
             SfBox bx[E];
 #pragma unroll
             for (int j = 0; j < E; j++) {
@@ -811,8 +817,8 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
                     sarea[j] = sb_half_area(run.l, run.h);
                     // a range's own box (at its first position) goes into its parent's record
                     if (a == 0 && (head >> j & 1) && (act >> j & 1)) {
-                        const int par = L.spar[pb[j]];
-                        if (par >= 0) sb_write_child(fnode, par, run.l, run.h, L.snode[pb[j]]);
+                        const int par = L.spar[pb[j] >> 1];
+                        if (par >= 0) sb_write_child(fnode, par, run.l, run.h, L.snode[pb[j] >> 1]);
                     }
                 }
             }
@@ -860,23 +866,23 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
 #pragma unroll
         for (int j = 0; j < E; j++)
             if ((tail >> j & 1) && (act >> j & 1))
-                L.sdec[pb[j]] = bestak[j] >= 0 ? bestak[j] : (pe[j] - pb[j]) / 2;      // no split found: halve the range in the order of axis 0
+                L.sdec[pb[j] >> 1] = bestak[j] >= 0 ? bestak[j] : (pe[j] - pb[j]) / 2;      // no split found: halve the range in the order of axis 0
         __syncthreads();
         int kk[E];
 #pragma unroll
         for (int j = 0; j < E; j++) {
             kk[j] = 0;
             if (act >> j & 1) {
-                const int ak = L.sdec[pb[j]];
+                const int ak = L.sdec[pb[j] >> 1];
                 kk[j] = ak & 0xffff;
-                L.side[L.ord[cur][ak >> 16][i0 + j]] = (unsigned char)(i0 + j - pb[j] < kk[j]);
+                L.side[L.ord(cur, ak >> 16)[i0 + j]] = (unsigned char)(i0 + j - pb[j] < kk[j]);
             }
         }
         __syncthreads();
         // ---- stable partition of the three orders
         for (int a = 0; a < 3; a++) {
-            const unsigned short *od = L.ord[cur][a];
-            unsigned short *on = L.ord[cur ^ 1][a];
+            const unsigned short *od = L.ord(cur, a);
+            unsigned short *on = L.ord(cur ^ 1, a);
             int p[E];
             unsigned sd = 0;
             int run = 0;
@@ -899,19 +905,19 @@ __global__ __launch_bounds__(64 * SF_W) void sb_finish_kernel(int ntasks, const 
         // ---- the children: range tables for the next level, single triangles into their parent's record
         int me[E];
 #pragma unroll
-        for (int j = 0; j < E; j++) me[j] = (act >> j & 1) ? L.snode[pb[j]] : 0;
+        for (int j = 0; j < E; j++) me[j] = (act >> j & 1) ? L.snode[pb[j] >> 1] : 0;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < E; j++) {
             if (!(act >> j & 1)) continue;
             const int i = i0 + j, b = pb[j], e = pe[j], m = b + kk[j];
-            L.pb[i] = (unsigned short)(i < m ? b : m);
+            // (a child of one position is finished: marked in pb, no table entry)
+            L.pb[i] = (unsigned short)(i < m ? (m - b >= 2 ? b : b | SF_ONE) : (e - m >= 2 ? m : m | SF_ONE));
             if (i == b || i == m) {
                 const int k = i == m ? 1 : 0, end = k ? e : m, node = k ? me[j] + kk[j] : me[j] + 1;
-                L.se[i] = (unsigned short)end;
-                if (end - i >= 2) { L.snode[i] = node; L.spar[i] = me[j] * 2 + k; }
+                if (end - i >= 2) { L.se[i >> 1] = (unsigned short)end; L.snode[i >> 1] = node; L.spar[i >> 1] = me[j] * 2 + k; }
                 else {
-                    const int q = L.ord[cur ^ 1][0][i];
+                    const int q = L.ord(cur ^ 1, 0)[i];
                     const float l[3] = { L.lo[0][q], L.lo[1][q], L.lo[2][q] }, h[3] = { L.hi[0][q], L.hi[1][q], L.hi[2][q] };
                     sb_write_child(fnode, me[j] * 2 + k, l, h, ~L.slot[q]);
                 }
