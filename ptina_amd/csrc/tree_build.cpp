@@ -759,7 +759,8 @@ static int make_wide_device(mpt_ctx *c) {
         hipFree(c->wb_bin_of); hipFree(c->wb_ncount); hipFree(c->wb_offset); hipFree(c->wb_scan); hipFree(c->wb_area);
         c->wb_bin_of = c->wb_ncount = c->wb_offset = nullptr; c->wb_scan = nullptr; c->wb_area = nullptr; c->wb_cap = 0;
         HIP_TRY(mpt_wide_scan_bytes(ni, &c->wb_scan_bytes));
-        if (dev_alloc(&c->wb_bin_of, (size_t)ni + 4) || dev_alloc(&c->wb_ncount, (size_t)ni) || dev_alloc(&c->wb_offset, (size_t)ni) ||
+        // (wb_offset: not used since round 6 -- the nodes' offsets within their workgroup live in wb_ncount, the workgroups' in wb_scan)
+        if (dev_alloc(&c->wb_bin_of, (size_t)ni + 4) || dev_alloc(&c->wb_ncount, (size_t)ni) ||
             dev_alloc((char **)&c->wb_scan, std::max<size_t>(c->wb_scan_bytes, 16)) || dev_alloc(&c->wb_area, 2)) return 1;
         c->wb_cap = ni;
     }
