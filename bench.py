@@ -336,7 +336,7 @@ def cpu_baseline(scene, camera, budget_s=12.0):
 # frame + clear (exams/benchmark.py:25-27); scene generation, upload and mpt_build_tree are outside it and reported beside it.
 OTHER_CONFIGS = [
     # key, title, scene, scene kwargs, film side, spp, world light, timed steps
-    ('c1', 'BASELINE configs[0]: s34 34-tri cornell two-boxes, 512x512, 32 spp', 's34', {}, 512, 32, None, 5),
+    ('c1', 'BASELINE configs[0]: s34 34-tri cornell two-boxes, 512x512, 32 spp', 's34', {}, 512, 32, None, 20),
     ('c3_film_1gpu', 'BASELINE configs[2] on ONE GPU: s978 2048x2048, 256 spp (eight pipelined launches of 32 frames)', 's978', {}, 2048, 256, None, 1),
     ('c4', 'BASELINE configs[3]: 99 382-tri displaced blob in cornell + equirect env light, MIS, 1024x1024, 64 spp', 'c4', {}, 1024, 64,
      ([1.0, 1.0, 1.0, 1.0], 0), 1),
