@@ -889,8 +889,14 @@ def main():
         # the gather kernels of BASELINE configs 4 and 5: HBM bytes, L2 hit rate and wait fraction of their launches, collected in this run
         # too (the TA_* / TCP_* counters hung rocprofv3 on this pool and are not asked for)
         if not args.no_configs and args.scene == 's978':
-            for key in ('c1', 'c3_film_1gpu', 'c4', 'c5'):
-                got, src = collect_pmc(['--config', key, '--mode', args.mode], budget_s=120, role='pmc-config-child',
+            # (bounded: a pass normally takes 2-4 s; one that hangs costs its 45 s, and once 150 s are gone the remaining legs fall back
+            # to the committed L2 hit rates -- the default run must stay within minutes whatever the profiler does)
+            t_pmc = time.time()
+            for key in ('c4', 'c5', 'c1', 'c3_film_1gpu'):
+                if time.time() - t_pmc > 150:
+                    CONFIG_PMC[key] = (None, 'not collected: the counter passes of this run had used up their time')
+                    continue
+                got, src = collect_pmc(['--config', key, '--mode', args.mode], budget_s=45, role='pmc-config-child',
                                        passes=CONFIG_PMC_PASSES if key in ('c4', 'c5') else PMC_PASSES[:3])
                 CONFIG_PMC[key] = (got, src)
                 if got is None:
